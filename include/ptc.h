@@ -1,0 +1,192 @@
+/* ptc.h — C-ABI boundary of the MI355X path-tracing core ("ptc").
+ *
+ * This is the drop-in boundary of SURVEY.md §8(b).  The reference
+ * (WeaponizedSchizophrenia/physically-based-renderer) has no FFI/plugin
+ * interface for its render path; the seam is the C++ member call
+ *
+ *   pbr::PbrRenderSystem::render(cmd, scene, gBuffer, renderTarget, extent)
+ *       src/pbr_engine/engine/pbr/PbrRenderSystem.hpp:46-47
+ *   called from app::App::recordCommands  src/gltf_viewer/App.cpp:387-388
+ *
+ * fed by  gltf::Loader::loadAsset / Asset::loadScene
+ *       src/pbr_engine/gltf/pbr/gltf/Loader.hpp:20-21, Asset.hpp:76-78
+ * and consumed by TonemapperSystem::run
+ *       src/pbr_engine/engine/pbr/TonemapperSystem.cpp:97-134.
+ *
+ * Each entry point below names the reference interface it replaces.  Plain C:
+ * opaque handle, plain pointers and sizes, int status (0 = ok, <0 = error,
+ * text via ptc_last_error).  The caller owns every input array (copied during
+ * the call); the library owns all device memory.  A context is bound to one
+ * HIP device and is not re-entrant; distinct contexts are independent.
+ *
+ * The library behind this header is HIP-only.  There is no CPU fallback:
+ * ptc_create fails (returns NULL, ptc_last_error(NULL) says why) when no
+ * gfx950 device is usable.
+ */
+#ifndef PTC_H
+#define PTC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTC_ABI_VERSION 1
+
+typedef struct ptc_ctx ptc_ctx;
+
+/* status codes */
+enum {
+  PTC_OK = 0,
+  PTC_E_ARG = -1,      /* bad argument (null pointer, index out of range, bad size) */
+  PTC_E_STATE = -2,    /* call out of order (e.g. render before scene_commit)       */
+  PTC_E_DEVICE = -3,   /* HIP error (text carries hipGetErrorString)                */
+  PTC_E_NOMEM = -4
+};
+
+/* integrators */
+enum {
+  PTC_INTEGRATOR_PATH = 0,          /* wavefront path tracer (SURVEY §8a-2 P1–P10)                  */
+  PTC_INTEGRATOR_RASTER_COMPAT = 1  /* primary hit + the reference's Blinn-Phong pass (R6,R7,R8):
+                                       assets/shaders/pbr/lighting.glsl:19-29                       */
+};
+
+/* Vertex record == pbr::MeshVertex (src/pbr_engine/engine/pbr/MeshVertex.hpp:14-19):
+ * {vec3 position; vec3 normal; vec4 tangent; vec2 texCoords}, 48 bytes, tightly packed. */
+typedef struct ptc_vertex {
+  float position[3];
+  float normal[3];
+  float tangent[4];
+  float texcoord[2];
+} ptc_vertex;
+
+/* Counters of the last frame ("counted, not estimated"). */
+typedef struct ptc_stats {
+  uint64_t paths;             /* camera samples traced                                   */
+  uint64_t segments;          /* closest-hit rays cast (camera + continuation)           */
+  uint64_t shadow_rays;       /* any-hit (NEE) rays cast                                 */
+  uint64_t hits;              /* closest-hit rays that hit a surface                     */
+  uint64_t node_visits_closest;
+  uint64_t tri_tests_closest;
+  uint64_t node_visits_any;
+  uint64_t tri_tests_any;
+  uint64_t algorithmic_bytes; /* SURVEY §8d byte formula evaluated on the counters above */
+  double seconds_render;      /* device time of the frame's kernels (HIP events)         */
+  double seconds_trace_closest; /* HIP-event time of the dominant kernel (sum over launches) */
+  double seconds_trace_any;
+  double seconds_shade;
+  double seconds_commit;      /* flatten + LBVH + upload                                 */
+  uint32_t launches_trace_closest;
+  uint32_t launches_trace_any;
+  uint32_t n_triangles;
+  uint32_t n_bvh_nodes;
+  uint32_t n_emitters;
+  uint32_t bvh_max_depth;
+} ptc_stats;
+
+/* ---- context ------------------------------------------------------------------------------
+ * Replaces core::makeGpuHandle + MemoryAllocator bring-up
+ * (src/pbr_engine/core/pbr/core/GpuHandle.cpp:94-101, engine/pbr/memory/MemoryAllocator.cpp:68-88).
+ * device_id: HIP ordinal.  Returns NULL on failure.
+ * PTC_DEVICE_NONE gives a description-only context: the scene calls (begin/add/commit: flatten +
+ * LBVH on the host) and the ptc_debug_get_* hooks work, every call that needs the GPU fails with
+ * PTC_E_DEVICE.  It exists so that the host logic can be checked without a GPU; it renders nothing. */
+#define PTC_DEVICE_NONE (-1)
+ptc_ctx* ptc_create(int device_id);
+void ptc_destroy(ptc_ctx*);
+/* Last error text of the context (or of the last failed ptc_create when ctx == NULL). */
+const char* ptc_last_error(const ptc_ctx*);
+int ptc_abi_version(void);
+
+/* ---- scene description --------------------------------------------------------------------
+ * Replaces gltf::Asset::loadScene → MeshBuilder::build → TransferStager
+ * (src/pbr_engine/gltf/pbr/gltf/Asset.cpp:135-273, engine/pbr/MeshBuilder.cpp:16-55,
+ *  engine/pbr/TransferStager.cpp:51-177). */
+int ptc_scene_begin(ptc_ctx*);
+
+/* pbr::MaterialData{vec4 color} (engine/pbr/Material.hpp:14-16) widened with the glTF
+ * metal-rough + emissive factors the reference ignores (gltf/Asset.cpp:142-150).
+ * tex_* are texture ids from ptc_add_texture_rgba8 or -1.  Returns material id >= 0. */
+int ptc_add_material(ptc_ctx*, const float base_color[4], float metallic, float roughness,
+                     const float emissive[3], int tex_color, int tex_normal, int tex_mr);
+
+/* image::loadImage2D output: RGBA8, 4 channels forced (image/pbr/image/LoadImage.cpp:56-73);
+ * sampled NEAREST/REPEAT like the reference's default sampler (gltf/Asset.cpp:116-117).
+ * Returns texture id >= 0. */
+int ptc_add_texture_rgba8(ptc_ctx*, const uint8_t* px, int w, int h);
+
+/* One MeshBuilder::Primitive (engine/pbr/MeshBuilder.hpp:14-18) with indices widened to u32
+ * (reference: u16, Asset.cpp:197-201).  Triangle list, indices primitive-local.
+ * Returns mesh id >= 0. */
+int ptc_add_mesh(ptc_ctx*, const ptc_vertex* verts, uint32_t n_verts, const uint32_t* indices,
+                 uint32_t n_indices, int material);
+
+/* pbr::Transform + makeModelPushConstant (engine/pbr/Scene.hpp:19-23,
+ * ModelPushConstant.hpp:33-46): model = T·R·S, quaternion order (w,x,y,z). */
+int ptc_add_instance(ptc_ctx*, int mesh, const float t[3], const float q_wxyz[4],
+                     const float s[3]);
+
+/* pbr::makeCameraData (engine/pbr/CameraData.hpp:22-32): lookAtRH(pos,target,up=(0,-1,0)),
+ * perspective fovY/aspect; y-down un-flipped viewport (PbrRenderSystem.cpp:425-430). */
+int ptc_set_camera(ptc_ctx*, const float pos[3], const float target[3], float fov_y,
+                   float aspect);
+
+/* Flatten instances to world space (geometry_pass/vertex.glsl:25-36), build + flatten the LBVH,
+ * build the emitter CDF, upload everything to HBM. */
+int ptc_scene_commit(ptc_ctx*);
+
+/* ---- rendering ----------------------------------------------------------------------------
+ * Replaces PbrRenderSystem::render (engine/pbr/PbrRenderSystem.cpp:357-365).
+ * ptc_render == frame_begin + frame_add_samples(spp) + frame_resolve. */
+int ptc_render(ptc_ctx*, int w, int h, int spp, uint64_t seed, int max_bounces, int integrator);
+
+/* Progressive form.  tile_rank/tile_count select the 32×32-pixel tiles this context owns
+ * (tile t along a Morton walk belongs to rank t mod tile_count); 0/1 = whole frame.
+ * spp_total is the divisor used by frame_resolve. */
+int ptc_frame_begin(ptc_ctx*, int w, int h, int spp_total, uint64_t seed, int max_bounces,
+                    int integrator, int tile_rank, int tile_count);
+/* Trace the next n_samples samples of every owned pixel (one wavefront batch). */
+int ptc_frame_add_samples(ptc_ctx*, int n_samples);
+/* sum / spp_total → full-frame RGBA32F (zeros in pixels this context does not own). */
+int ptc_frame_resolve(ptc_ctx*);
+/* Block until all queued device work of this context has finished. */
+int ptc_sync(ptc_ctx*);
+
+/* Output == the HdrImage the tonemapper consumes (engine/pbr/HdrImage.cpp:12-45), as fp32:
+ * w*h*4 floats, row-major, y-down, alpha = 1 where owned. */
+int ptc_read_radiance_rgba32f(ptc_ctx*, float* out);
+/* Device pointer of that buffer (w*h*4 floats) for in-place RCCL reduction by the caller. */
+void* ptc_radiance_device_ptr(ptc_ctx*);
+/* Overwrite the radiance buffer from host (e.g. after a reduce) before tonemapping. */
+int ptc_write_radiance_rgba32f(ptc_ctx*, const float* in);
+
+/* TonemapperSystem::run + tonemappers/aces+gamma.glsl:10-40 on the radiance buffer → RGBA8. */
+int ptc_tonemap_rgba8(ptc_ctx*, uint8_t* out);
+
+int ptc_get_stats(ptc_ctx*, ptc_stats* out);
+
+/* ---- test hooks (parity of single stages; not needed by a renderer) -------------------------
+ * Closest-hit of n explicit rays through the same trace kernel: origins/dirs are n*3 floats;
+ * out_t n floats (t, or -1 on miss), out_prim n int32 (original primitive id or -1),
+ * out_uv n*2 floats. */
+int ptc_debug_trace_closest(ptc_ctx*, const float* origins, const float* dirs, uint32_t n,
+                            float* out_t, int32_t* out_prim, float* out_uv);
+/* Any-hit of n explicit rays with tmax each; out_occluded n uint8. */
+int ptc_debug_trace_any(ptc_ctx*, const float* origins, const float* dirs, const float* tmax,
+                        uint32_t n, uint8_t* out_occluded);
+/* World-space flattened geometry as committed: verts (n_verts*12 floats = ptc_vertex),
+ * indices (n_tris*3 u32), per-triangle material.  Pass NULL to query sizes only. */
+int ptc_debug_get_flat_scene(ptc_ctx*, uint32_t* n_verts, uint32_t* n_tris, ptc_vertex* verts,
+                             uint32_t* indices, int32_t* tri_material);
+
+/* The flattened LBVH as committed: nodes (n_nodes*16 floats: lo0 hi0 lo1 hi1, then child codes c0 c1
+ * as int32 bits and 2 pads) and Morton-ordered triangle records (n_tris*12 floats: v0,prim | e1,class |
+ * e2,0).  Pass NULL to query sizes only. */
+int ptc_debug_get_bvh(ptc_ctx*, uint32_t* n_nodes, uint32_t* n_tris, float* nodes, float* tris);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTC_H */

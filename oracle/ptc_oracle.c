@@ -1,0 +1,1029 @@
+/* ptc_oracle.c — scalar CPU restatement of the path-tracing hot path.  TEST INFRASTRUCTURE ONLY
+ * (see ptc_oracle.h: who may load it, and "parity unpinned").
+ *
+ * Arithmetic contract shared with the HIP kernels (DESIGN.md §"Arithmetic contract"):
+ *   - IEEE-754 binary32 everywhere; + - * / sqrt correctly rounded; no implicit contraction
+ *     (built with -ffp-contract=off); a fused multiply-add happens exactly where fmaf() is written.
+ *   - no libm transcendental on the render path: sin/cos/pow are the polynomials below.
+ *   - closest hit = lexicographic minimum of (t, original primitive id); traversal order is fixed
+ *     (near child first, ties to child 0), so node/triangle counters are reproducible too.
+ *   - RNG is a counter-based hash of (seed, pixel, sample, bounce, dim).
+ *
+ * Reference conventions restated here (file:line under /root/reference):
+ *   R1 vertex record            src/pbr_engine/engine/pbr/MeshVertex.hpp:14-19
+ *   R2 primitive concatenation  src/pbr_engine/engine/pbr/MeshBuilder.cpp:16-55
+ *   R3 model / normal matrix    src/pbr_engine/engine/pbr/ModelPushConstant.hpp:33-46
+ *   R4 world N/T/B              assets/shaders/geometry_pass/vertex.glsl:25-36
+ *   R5 camera                   src/pbr_engine/engine/pbr/CameraData.hpp:22-32
+ *   R6 winding / culling        src/pbr_engine/engine/pbr/PbrRenderSystem.cpp:186
+ *   R7 albedo / normal map      assets/shaders/geometry_pass/fragment.glsl:19-31
+ *   R8 Blinn-Phong lighting     assets/shaders/pbr/lighting.glsl:19-29, BlinnPhong.lib.glsl:4-10
+ *   R9 tonemap                  assets/shaders/tonemappers/aces+gamma.glsl:10-40, Gamma.lib.glsl:4-6
+ * Third-party closed forms restated (not in /root/reference; pinned cmake/Dependencies.cmake:6):
+ *   glm 1.0.1 lookAtRH, perspectiveRH_NO, translate·toMat4·scale, inverse, transpose.
+ */
+#define _GNU_SOURCE
+#include "ptc_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <unistd.h>
+
+/* ------------------------------------------------------------------------------------------ */
+/* constants of the specification                                                              */
+#define ORA_LEAF_MAX 4          /* triangles per BVH leaf                                      */
+#define ORA_STACK 64            /* traversal stack entries                                     */
+#define ORA_RR_START 3          /* Russian roulette from this bounce index on                  */
+#define ORA_RR_PMIN 0.05f
+#define ORA_ALPHA_MIN 0.001f
+#define ORA_T_INF 3.0e38f
+#define ORA_TILE 32
+#define ORA_ZNEAR 0.01f         /* CameraData.hpp:25 */
+#define ORA_ZFAR 1024.0f        /* CameraData.hpp:26 */
+#define ORA_PI 3.14159265358979323846f
+#define ORA_INV_PI 0.31830988618379067154f
+#define ORA_HALF_PI 1.57079632679489661923f
+
+/* struct sizes of the byte model (DESIGN.md §"Algorithmic bytes") */
+#define S_RAY 56u
+#define S_HIT 16u
+#define S_SHADOW 44u
+#define S_NODE 64u
+#define S_TRI 48u
+#define S_SURF 176u
+#define S_FB 16u
+
+typedef struct { float x, y, z; } v3;
+
+static inline v3 V3(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static inline v3 vadd(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 vsub(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 vmul(v3 a, v3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline v3 vscale(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+static inline v3 vneg(v3 a) { return V3(-a.x, -a.y, -a.z); }
+static inline float dot3(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+static inline v3 cross3(v3 a, v3 b) {
+  return V3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+static inline v3 normalize3(v3 a) {
+  float inv = 1.0f / sqrtf(dot3(a, a));
+  return vscale(a, inv);
+}
+/* a*s + b */
+static inline v3 vfma(v3 a, float s, v3 b) { return V3(fmaf(a.x, s, b.x), fmaf(a.y, s, b.y), fmaf(a.z, s, b.z)); }
+static inline float fmin2(float a, float b) { return a < b ? a : b; }
+static inline float fmax2(float a, float b) { return a > b ? a : b; }
+static inline float max3c(v3 a) { return fmax2(fmax2(a.x, a.y), a.z); }
+static inline float luminance(v3 c) { return fmaf(c.z, 0.0722f, fmaf(c.y, 0.7152f, c.x * 0.2126f)); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* RNG: counter-based, keyed (seed, pixel, sample) then (bounce, dim)                           */
+static inline uint32_t pcg(uint32_t v) {
+  uint32_t s = v * 747796405u + 2891336453u;
+  uint32_t w = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u;
+  return (w >> 22) ^ w;
+}
+static inline uint32_t path_key(uint64_t seed, uint32_t pixel, uint32_t sample) {
+  return pcg(pixel + pcg(sample + pcg((uint32_t)seed + pcg((uint32_t)(seed >> 32)))));
+}
+static inline uint32_t rng_u32(uint32_t key, uint32_t bounce, uint32_t dim) {
+  return pcg(pcg(bounce * 8u + dim) ^ key);
+}
+static inline float rng_f(uint32_t key, uint32_t bounce, uint32_t dim) {
+  return (float)(rng_u32(key, bounce, dim) >> 8) * (1.0f / 16777216.0f);
+}
+uint32_t ora_rng_u32(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t dim) {
+  return rng_u32(path_key(seed, pixel, sample), bounce, dim);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* transcendental replacements                                                                 */
+/* sin(2πu), cos(2πu) for u in [0,1): quadrant + octant reduction, Taylor on [0, π/4]. */
+static inline void sincos2pi(float u, float* so, float* co) {
+  float x4 = u * 4.0f;
+  int q = (int)x4;
+  if (q > 3) q = 3;
+  float r = x4 - (float)q;
+  int swap = r > 0.5f;
+  float rr = swap ? 1.0f - r : r;
+  float x = rr * ORA_HALF_PI;
+  float x2 = x * x;
+  float ps = fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 2.7557319e-6f, -1.9841270e-4f), 8.3333333e-3f), -1.6666667e-1f), 1.0f);
+  float s = x * ps;
+  float c = fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 2.4801587e-5f, -1.3888889e-3f), 4.1666667e-2f), -0.5f), 1.0f);
+  if (swap) { float t = s; s = c; c = t; }
+  float S, C;
+  if (q == 0) { S = s; C = c; }
+  else if (q == 1) { S = c; C = -s; }
+  else if (q == 2) { S = -s; C = -c; }
+  else { S = -c; C = s; }
+  *so = S; *co = C;
+}
+void ora_sincos2pi(float u, float* s, float* c) { sincos2pi(u, s, c); }
+
+/* x^y for x > 0 (x <= 0 → 0): exp2(y·log2 x), both by polynomial. */
+static inline float pt_log2(float x) {
+  union { float f; uint32_t u; } b; b.f = x;
+  int e = (int)((b.u >> 23) & 0xffu) - 127;
+  b.u = (b.u & 0x007fffffu) | 0x3f800000u;   /* m in [1,2) */
+  float m = b.f;
+  if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+  float z = (m - 1.0f) / (m + 1.0f);        /* log2 m = 2/ln2 · atanh z */
+  float z2 = z * z;
+  float p = fmaf(z2, fmaf(z2, fmaf(z2, fmaf(z2, 0.3205989f, 0.4121984f), 0.5770780f), 0.9617967f), 2.8853901f);
+  return fmaf(z, p, (float)e);
+}
+static inline float pt_exp2(float x) {
+  if (x < -126.0f) return 0.0f;
+  if (x > 127.0f) x = 127.0f;
+  float fl = floorf(x);
+  float f = x - fl;                           /* [0,1) */
+  float p = fmaf(f, fmaf(f, fmaf(f, fmaf(f, fmaf(f, 1.8775767e-3f, 8.9893397e-3f), 5.5826318e-2f), 2.4015361e-1f), 6.9315308e-1f), 9.9999994e-1f);
+  union { float f; uint32_t u; } b;
+  b.u = (uint32_t)((int)fl + 127) << 23;
+  return p * b.f;
+}
+static inline float pt_pow(float x, float y) {
+  if (!(x > 0.0f)) return 0.0f;
+  return pt_exp2(y * pt_log2(x));
+}
+float ora_powf(float x, float y) { return pt_pow(x, y); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* scene containers                                                                            */
+typedef struct { float position[3], normal[3], tangent[4], texcoord[2]; } vert48; /* R1 */
+
+typedef struct {
+  float base[4]; float metallic, roughness; float emissive[3];
+  int tex_color, tex_normal, tex_mr;
+} material_t;
+
+typedef struct { vert48* v; uint32_t nv; uint32_t* idx; uint32_t ni; int material; } mesh_t;
+typedef struct { int mesh; float t[3], q[4], s[3]; } inst_t;
+typedef struct { uint8_t* px; int w, h; } tex_t;
+
+typedef struct {                 /* 64-byte interior node: both child boxes + child codes */
+  float lo0[3], hi0[3], lo1[3], hi1[3];
+  int32_t c0, c1;                /* >=0 interior index; <0 leaf: ~(first | (count-1)<<28) */
+  int32_t pad0, pad1;
+} node_t;
+
+typedef struct { v3 v0, e1, e2, ng; float area; v3 Le; float pmf; uint32_t prim; } light_t;
+
+struct ora_ctx {
+  char err[256];
+  /* description */
+  material_t* mats; int n_mats;
+  mesh_t* meshes; int n_meshes;
+  inst_t* insts; int n_insts;
+  tex_t* texs; int n_texs;
+  float cam_pos[3], cam_target[3], cam_fov, cam_aspect; int have_cam;
+  /* committed */
+  int committed;
+  vert48* wv; uint32_t n_wv;           /* world-space vertices  */
+  uint32_t* widx; uint32_t n_tris;     /* 3 per triangle        */
+  int32_t* tri_mat;
+  /* BVH (triangles in sorted order) */
+  uint32_t* order;                     /* sorted position → original prim id */
+  v3 *tv0, *te1, *te2;                 /* per sorted position */
+  node_t* nodes; uint32_t n_nodes; uint32_t max_depth;
+  int32_t* prim_light;                 /* original prim id → light index or -1 */
+  light_t* lights; float* cdf; uint32_t n_lights;
+  float scene_lo[3], scene_hi[3]; float ray_eps;
+  ora_stats stats;
+};
+
+static int fail(ora_ctx* c, const char* msg) { snprintf(c->err, sizeof c->err, "%s", msg); return -1; }
+const char* ora_last_error(const ora_ctx* c) { return c ? c->err : "null ctx"; }
+int ora_hw_threads(void) { long n = sysconf(_SC_NPROCESSORS_ONLN); return n > 0 ? (int)n : 1; }
+
+ora_ctx* ora_create(void) {
+  if (!__builtin_cpu_supports("fma")) return NULL;   /* the arithmetic contract needs hardware fma */
+  ora_ctx* c = (ora_ctx*)calloc(1, sizeof *c);
+  return c;
+}
+static void free_committed(ora_ctx* c) {
+  free(c->wv); free(c->widx); free(c->tri_mat); free(c->order); free(c->tv0); free(c->te1); free(c->te2);
+  free(c->nodes); free(c->prim_light); free(c->lights); free(c->cdf);
+  c->wv = NULL; c->widx = NULL; c->tri_mat = NULL; c->order = NULL; c->tv0 = c->te1 = c->te2 = NULL;
+  c->nodes = NULL; c->prim_light = NULL; c->lights = NULL; c->cdf = NULL; c->committed = 0;
+}
+static void free_description(ora_ctx* c) {
+  for (int i = 0; i < c->n_meshes; ++i) { free(c->meshes[i].v); free(c->meshes[i].idx); }
+  for (int i = 0; i < c->n_texs; ++i) free(c->texs[i].px);
+  free(c->meshes); free(c->mats); free(c->insts); free(c->texs);
+  c->meshes = NULL; c->mats = NULL; c->insts = NULL; c->texs = NULL;
+  c->n_meshes = c->n_mats = c->n_insts = c->n_texs = 0;
+}
+void ora_destroy(ora_ctx* c) { if (!c) return; free_committed(c); free_description(c); free(c); }
+
+int ora_scene_begin(ora_ctx* c) { free_committed(c); free_description(c); c->have_cam = 0; return 0; }
+
+int ora_add_material(ora_ctx* c, const float base[4], float metallic, float roughness,
+                     const float emissive[3], int tc, int tn, int tmr) {
+  if (!base || !emissive) return fail(c, "add_material: null pointer");
+  if (tc >= c->n_texs || tn >= c->n_texs || tmr >= c->n_texs) return fail(c, "add_material: texture id out of range");
+  if (tc >= 0 || tn >= 0 || tmr >= 0) return fail(c, "add_material: textures are not implemented in this round");
+  c->mats = (material_t*)realloc(c->mats, sizeof(material_t) * (size_t)(c->n_mats + 1));
+  material_t* m = &c->mats[c->n_mats];
+  memcpy(m->base, base, 16); m->metallic = metallic; m->roughness = roughness;
+  memcpy(m->emissive, emissive, 12); m->tex_color = tc; m->tex_normal = tn; m->tex_mr = tmr;
+  return c->n_mats++;
+}
+int ora_add_texture_rgba8(ora_ctx* c, const uint8_t* px, int w, int h) {
+  if (!px || w <= 0 || h <= 0) return fail(c, "add_texture: bad argument");
+  c->texs = (tex_t*)realloc(c->texs, sizeof(tex_t) * (size_t)(c->n_texs + 1));
+  tex_t* t = &c->texs[c->n_texs];
+  t->px = (uint8_t*)malloc((size_t)w * h * 4); memcpy(t->px, px, (size_t)w * h * 4); t->w = w; t->h = h;
+  return c->n_texs++;
+}
+int ora_add_mesh(ora_ctx* c, const void* verts, uint32_t nv, const uint32_t* idx, uint32_t ni, int material) {
+  if (!verts || !idx || nv == 0 || ni == 0 || ni % 3u) return fail(c, "add_mesh: bad argument");
+  if (material < 0 || material >= c->n_mats) return fail(c, "add_mesh: material out of range");
+  for (uint32_t i = 0; i < ni; ++i) if (idx[i] >= nv) return fail(c, "add_mesh: index out of range");
+  c->meshes = (mesh_t*)realloc(c->meshes, sizeof(mesh_t) * (size_t)(c->n_meshes + 1));
+  mesh_t* m = &c->meshes[c->n_meshes];
+  m->v = (vert48*)malloc(sizeof(vert48) * nv); memcpy(m->v, verts, sizeof(vert48) * nv); m->nv = nv;
+  m->idx = (uint32_t*)malloc(4u * ni); memcpy(m->idx, idx, 4u * ni); m->ni = ni; m->material = material;
+  return c->n_meshes++;
+}
+int ora_add_instance(ora_ctx* c, int mesh, const float t[3], const float q[4], const float s[3]) {
+  if (!t || !q || !s) return fail(c, "add_instance: null pointer");
+  if (mesh < 0 || mesh >= c->n_meshes) return fail(c, "add_instance: mesh out of range");
+  c->insts = (inst_t*)realloc(c->insts, sizeof(inst_t) * (size_t)(c->n_insts + 1));
+  inst_t* in = &c->insts[c->n_insts];
+  in->mesh = mesh; memcpy(in->t, t, 12); memcpy(in->q, q, 16); memcpy(in->s, s, 12);
+  return c->n_insts++;
+}
+int ora_set_camera(ora_ctx* c, const float pos[3], const float target[3], float fov, float aspect) {
+  if (!pos || !target) return fail(c, "set_camera: null pointer");
+  memcpy(c->cam_pos, pos, 12); memcpy(c->cam_target, target, 12); c->cam_fov = fov; c->cam_aspect = aspect;
+  c->have_cam = 1; return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* R3: model = translate(p)·toMat4(q)·scale(s); normalModel = mat3(transpose(inverse(model))).   */
+/* Column-major (glm): m[col*4+row].  Quaternion order (w,x,y,z) — gltf/Asset.cpp:242.           */
+static void make_model(const float t[3], const float q[4], const float s[3], float M[16], float N[9]) {
+  float w = q[0], x = q[1], y = q[2], z = q[3];
+  float qxx = x * x, qyy = y * y, qzz = z * z, qxz = x * z, qxy = x * y, qyz = y * z;
+  float qwx = w * x, qwy = w * y, qwz = w * z;
+  float R[9]; /* R[col*3+row], glm::mat3_cast */
+  R[0] = 1.0f - 2.0f * (qyy + qzz); R[1] = 2.0f * (qxy + qwz);        R[2] = 2.0f * (qxz - qwy);
+  R[3] = 2.0f * (qxy - qwz);        R[4] = 1.0f - 2.0f * (qxx + qzz); R[5] = 2.0f * (qyz + qwx);
+  R[6] = 2.0f * (qxz + qwy);        R[7] = 2.0f * (qyz - qwx);        R[8] = 1.0f - 2.0f * (qxx + qyy);
+  float A[9]; /* upper 3×3 of T·R·S = R·diag(s) */
+  for (int col = 0; col < 3; ++col) for (int row = 0; row < 3; ++row) A[col * 3 + row] = R[col * 3 + row] * s[col];
+  for (int col = 0; col < 3; ++col) { for (int row = 0; row < 3; ++row) M[col * 4 + row] = A[col * 3 + row]; M[col * 4 + 3] = 0.0f; }
+  M[12] = t[0]; M[13] = t[1]; M[14] = t[2]; M[15] = 1.0f;
+  /* inverse-transpose of A = cofactor(A)/det(A); a(r,c) = A[c*3+r] */
+#define a(r, c) A[(c) * 3 + (r)]
+  float c00 = a(1, 1) * a(2, 2) - a(1, 2) * a(2, 1);
+  float c01 = a(1, 2) * a(2, 0) - a(1, 0) * a(2, 2);
+  float c02 = a(1, 0) * a(2, 1) - a(1, 1) * a(2, 0);
+  float c10 = a(0, 2) * a(2, 1) - a(0, 1) * a(2, 2);
+  float c11 = a(0, 0) * a(2, 2) - a(0, 2) * a(2, 0);
+  float c12 = a(0, 1) * a(2, 0) - a(0, 0) * a(2, 1);
+  float c20 = a(0, 1) * a(1, 2) - a(0, 2) * a(1, 1);
+  float c21 = a(0, 2) * a(1, 0) - a(0, 0) * a(1, 2);
+  float c22 = a(0, 0) * a(1, 1) - a(0, 1) * a(1, 0);
+  float det = a(0, 0) * c00 + a(0, 1) * c01 + a(0, 2) * c02;
+#undef a
+  float id = 1.0f / det;
+  /* N(r,c) = cof(r,c)/det, stored column-major N[c*3+r] */
+  N[0] = c00 * id; N[1] = c10 * id; N[2] = c20 * id;
+  N[3] = c01 * id; N[4] = c11 * id; N[5] = c21 * id;
+  N[6] = c02 * id; N[7] = c12 * id; N[8] = c22 * id;
+}
+void ora_make_model(const float t[3], const float q[4], const float s[3], float M[16], float N[9]) { make_model(t, q, s, M, N); }
+
+static inline v3 mat3_mul(const float N[9], v3 v) { /* col0*x + col1*y + col2*z, glm order */
+  return V3(N[0] * v.x + N[3] * v.y + N[6] * v.z, N[1] * v.x + N[4] * v.y + N[7] * v.z, N[2] * v.x + N[5] * v.y + N[8] * v.z);
+}
+static inline v3 mat4_point(const float M[16], v3 p) { /* m[0]*x + m[1]*y + m[2]*z + m[3]*1 */
+  return V3(M[0] * p.x + M[4] * p.y + M[8] * p.z + M[12], M[1] * p.x + M[5] * p.y + M[9] * p.z + M[13],
+            M[2] * p.x + M[6] * p.y + M[10] * p.z + M[14]);
+}
+
+/* R5: camera basis of glm::lookAtRH(pos, target, up=(0,-1,0)): f, s, u.                          */
+typedef struct { v3 pos, f, s, u; float sx, sy; } camera_t;
+static camera_t make_camera_basis(const float pos[3], const float target[3], float fov, float aspect) {
+  camera_t c;
+  c.pos = V3(pos[0], pos[1], pos[2]);
+  c.f = normalize3(vsub(V3(target[0], target[1], target[2]), c.pos));
+  c.s = normalize3(cross3(c.f, V3(0.0f, -1.0f, 0.0f)));
+  c.u = cross3(c.s, c.f);
+  float th = (float)tan((double)fov * 0.5);
+  c.sy = th;
+  c.sx = aspect * th;
+  return c;
+}
+void ora_make_camera(const float pos[3], const float target[3], float fov, float aspect, float V[16], float P[16]) {
+  camera_t c = make_camera_basis(pos, target, fov, aspect);
+  /* glm::lookAtRH result, column-major */
+  V[0] = c.s.x; V[4] = c.s.y; V[8] = c.s.z;  V[12] = -dot3(c.s, c.pos);
+  V[1] = c.u.x; V[5] = c.u.y; V[9] = c.u.z;  V[13] = -dot3(c.u, c.pos);
+  V[2] = -c.f.x; V[6] = -c.f.y; V[10] = -c.f.z; V[14] = dot3(c.f, c.pos);
+  V[3] = 0.0f; V[7] = 0.0f; V[11] = 0.0f; V[15] = 1.0f;
+  /* glm::perspectiveRH_NO(fov, aspect, ZNEAR, ZFAR) */
+  memset(P, 0, 64);
+  float th = (float)tan((double)fov * 0.5);
+  P[0] = 1.0f / (aspect * th);
+  P[5] = 1.0f / th;
+  P[10] = -(ORA_ZFAR + ORA_ZNEAR) / (ORA_ZFAR - ORA_ZNEAR);
+  P[11] = -1.0f;
+  P[14] = -(2.0f * ORA_ZFAR * ORA_ZNEAR) / (ORA_ZFAR - ORA_ZNEAR);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* P2: LBVH.  30-bit Morton of the triangle-AABB centre normalised to the centroid bounds; keys   */
+/* made unique with the primitive id; the binary radix tree over the sorted keys; subtrees of    */
+/* <= ORA_LEAF_MAX triangles collapse into one leaf.                                              */
+static inline uint32_t expand10(uint32_t v) {
+  v &= 0x3ffu;
+  v = (v | (v << 16)) & 0x030000FFu;
+  v = (v | (v << 8)) & 0x0300F00Fu;
+  v = (v | (v << 4)) & 0x030C30C3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+static inline uint32_t quant10(float c, float lo, float ext) {
+  float n = (c - lo) / ext;
+  float q = n * 1024.0f;
+  if (!(q > 0.0f)) q = 0.0f;
+  if (q > 1023.0f) q = 1023.0f;
+  return (uint32_t)q;
+}
+static int cmp_u64(const void* a, const void* b) {
+  uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b;
+  return x < y ? -1 : (x > y ? 1 : 0);
+}
+static inline int32_t leaf_code(uint32_t first, uint32_t count) { return (int32_t)~(first | ((count - 1u) << 28)); }
+
+typedef struct { ora_ctx* c; const uint64_t* keys; const float* tlo; const float* thi; uint32_t next; uint32_t depth_max; } build_t;
+
+static void range_box(build_t* b, uint32_t lo, uint32_t hi, float blo[3], float bhi[3]) {
+  for (int k = 0; k < 3; ++k) { blo[k] = INFINITY; bhi[k] = -INFINITY; }
+  for (uint32_t i = lo; i <= hi; ++i) {
+    uint32_t p = b->c->order[i];
+    for (int k = 0; k < 3; ++k) {
+      blo[k] = fmin2(blo[k], b->tlo[p * 3 + k]);
+      bhi[k] = fmax2(bhi[k], b->thi[p * 3 + k]);
+    }
+  }
+}
+/* Split [lo,hi] at the highest differing key bit: returns last index of the lower half. */
+static uint32_t find_split(const uint64_t* keys, uint32_t lo, uint32_t hi) {
+  uint64_t diff = keys[lo] ^ keys[hi];
+  int bit = 63 - __builtin_clzll(diff);
+  uint64_t mask = 1ull << bit;
+  /* keys sorted: those with bit==0 (given equal higher bits) come first; binary search the boundary */
+  uint32_t a = lo, z = hi; /* keys[a] has bit 0, keys[z] has bit 1 */
+  while (z - a > 1) { uint32_t m = a + (z - a) / 2; if (keys[m] & mask) z = m; else a = m; }
+  return a;
+}
+/* Emit the interior node covering [lo,hi] (count > LEAF_MAX); returns its index. Iterative-safe depth
+ * (<= 64+log) so plain recursion is fine. */
+static int32_t build_node(build_t* b, uint32_t lo, uint32_t hi, uint32_t depth) {
+  uint32_t me = b->next++;
+  if (depth > b->depth_max) b->depth_max = depth;
+  uint32_t split = find_split(b->keys, lo, hi);
+  node_t tmp; memset(&tmp, 0, sizeof tmp);
+  range_box(b, lo, split, tmp.lo0, tmp.hi0);
+  range_box(b, split + 1, hi, tmp.lo1, tmp.hi1);
+  uint32_t n0 = split - lo + 1, n1 = hi - split;
+  tmp.c0 = n0 <= ORA_LEAF_MAX ? leaf_code(lo, n0) : build_node(b, lo, split, depth + 1);
+  tmp.c1 = n1 <= ORA_LEAF_MAX ? leaf_code(split + 1, n1) : build_node(b, split + 1, hi, depth + 1);
+  b->c->nodes[me] = tmp;
+  return (int32_t)me;
+}
+
+int ora_scene_commit(ora_ctx* c) {
+  free_committed(c);
+  if (!c->have_cam) return fail(c, "scene_commit: no camera");
+  if (c->n_insts == 0) return fail(c, "scene_commit: no instances");
+  /* R2/R3/R4 flatten: instances in insertion order, triangles in index order. */
+  uint64_t nv = 0, nt = 0;
+  for (int i = 0; i < c->n_insts; ++i) { nv += c->meshes[c->insts[i].mesh].nv; nt += c->meshes[c->insts[i].mesh].ni / 3; }
+  if (nt >= (1u << 28)) return fail(c, "scene_commit: too many triangles");
+  c->wv = (vert48*)malloc(sizeof(vert48) * nv); c->n_wv = (uint32_t)nv;
+  c->widx = (uint32_t*)malloc(12u * nt); c->tri_mat = (int32_t*)malloc(4u * nt); c->n_tris = (uint32_t)nt;
+  uint32_t vb = 0, tb = 0;
+  for (int i = 0; i < c->n_insts; ++i) {
+    const inst_t* in = &c->insts[i]; const mesh_t* m = &c->meshes[in->mesh];
+    float M[16], N[9]; make_model(in->t, in->q, in->s, M, N);
+    for (uint32_t k = 0; k < m->nv; ++k) {
+      const vert48* s = &m->v[k]; vert48* d = &c->wv[vb + k];
+      v3 p = mat4_point(M, V3(s->position[0], s->position[1], s->position[2]));
+      v3 n0 = V3(s->normal[0], s->normal[1], s->normal[2]);
+      v3 t0 = V3(s->tangent[0], s->tangent[1], s->tangent[2]);
+      v3 n = normalize3(mat3_mul(N, n0));                 /* vertex.glsl:33 */
+      v3 t = normalize3(mat3_mul(N, t0));                 /* vertex.glsl:34 */
+      d->position[0] = p.x; d->position[1] = p.y; d->position[2] = p.z;
+      d->normal[0] = n.x; d->normal[1] = n.y; d->normal[2] = n.z;
+      d->tangent[0] = t.x; d->tangent[1] = t.y; d->tangent[2] = t.z; d->tangent[3] = s->tangent[3];
+      d->texcoord[0] = s->texcoord[0]; d->texcoord[1] = s->texcoord[1];
+    }
+    for (uint32_t k = 0; k < m->ni / 3; ++k) {
+      c->widx[(tb + k) * 3 + 0] = vb + m->idx[k * 3 + 0];
+      c->widx[(tb + k) * 3 + 1] = vb + m->idx[k * 3 + 1];
+      c->widx[(tb + k) * 3 + 2] = vb + m->idx[k * 3 + 2];
+      c->tri_mat[tb + k] = m->material;
+    }
+    vb += m->nv; tb += m->ni / 3;
+  }
+  uint32_t n = c->n_tris;
+  /* triangle boxes, centroid bounds */
+  float* tlo = (float*)malloc(12u * n); float* thi = (float*)malloc(12u * n);
+  float cb_lo[3] = {INFINITY, INFINITY, INFINITY}, cb_hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int k = 0; k < 3; ++k) { c->scene_lo[k] = INFINITY; c->scene_hi[k] = -INFINITY; }
+  for (uint32_t p = 0; p < n; ++p) {
+    for (int k = 0; k < 3; ++k) {
+      float a = c->wv[c->widx[p * 3 + 0]].position[k], b = c->wv[c->widx[p * 3 + 1]].position[k], d = c->wv[c->widx[p * 3 + 2]].position[k];
+      float lo = fmin2(fmin2(a, b), d), hi = fmax2(fmax2(a, b), d);
+      tlo[p * 3 + k] = lo; thi[p * 3 + k] = hi;
+      float ctr = 0.5f * (lo + hi);
+      cb_lo[k] = fmin2(cb_lo[k], ctr); cb_hi[k] = fmax2(cb_hi[k], ctr);
+      c->scene_lo[k] = fmin2(c->scene_lo[k], lo); c->scene_hi[k] = fmax2(c->scene_hi[k], hi);
+    }
+  }
+  float ext[3];
+  for (int k = 0; k < 3; ++k) { ext[k] = cb_hi[k] - cb_lo[k]; if (!(ext[k] > 1e-30f)) ext[k] = 1e-30f; }
+  float diag = fmax2(fmax2(c->scene_hi[0] - c->scene_lo[0], c->scene_hi[1] - c->scene_lo[1]), c->scene_hi[2] - c->scene_lo[2]);
+  c->ray_eps = 1e-4f * fmax2(diag, 1e-6f);
+  uint64_t* keys = (uint64_t*)malloc(8u * n);
+  for (uint32_t p = 0; p < n; ++p) {
+    uint32_t qx = quant10(0.5f * (tlo[p * 3 + 0] + thi[p * 3 + 0]), cb_lo[0], ext[0]);
+    uint32_t qy = quant10(0.5f * (tlo[p * 3 + 1] + thi[p * 3 + 1]), cb_lo[1], ext[1]);
+    uint32_t qz = quant10(0.5f * (tlo[p * 3 + 2] + thi[p * 3 + 2]), cb_lo[2], ext[2]);
+    uint32_t morton = (expand10(qx) << 2) | (expand10(qy) << 1) | expand10(qz);
+    keys[p] = ((uint64_t)morton << 32) | p;
+  }
+  qsort(keys, n, 8, cmp_u64);
+  c->order = (uint32_t*)malloc(4u * n);
+  c->tv0 = (v3*)malloc(sizeof(v3) * n); c->te1 = (v3*)malloc(sizeof(v3) * n); c->te2 = (v3*)malloc(sizeof(v3) * n);
+  for (uint32_t i = 0; i < n; ++i) {
+    uint32_t p = (uint32_t)(keys[i] & 0xffffffffu); c->order[i] = p;
+    const float* a = c->wv[c->widx[p * 3 + 0]].position; const float* b = c->wv[c->widx[p * 3 + 1]].position; const float* d = c->wv[c->widx[p * 3 + 2]].position;
+    c->tv0[i] = V3(a[0], a[1], a[2]);
+    c->te1[i] = V3(b[0] - a[0], b[1] - a[1], b[2] - a[2]);
+    c->te2[i] = V3(d[0] - a[0], d[1] - a[1], d[2] - a[2]);
+  }
+  c->nodes = (node_t*)calloc(n > 1 ? n : 1, sizeof(node_t));
+  build_t b = {c, keys, tlo, thi, 0, 0};
+  if (n == 1) {                 /* a single triangle: both children are that leaf */
+    node_t r; memset(&r, 0, sizeof r);
+    range_box(&b, 0, 0, r.lo0, r.hi0); range_box(&b, 0, 0, r.lo1, r.hi1);
+    r.c0 = leaf_code(0, 1); r.c1 = leaf_code(0, 1);
+    c->nodes[0] = r; b.next = 1;
+  } else {
+    build_node(&b, 0, n - 1, 0);
+  }
+  c->n_nodes = b.next; c->max_depth = b.depth_max;
+  free(keys); free(tlo); free(thi);
+  /* P7: emitter table in original primitive order, power pmf/cdf */
+  c->prim_light = (int32_t*)malloc(4u * n);
+  uint32_t nl = 0;
+  for (uint32_t p = 0; p < n; ++p) {
+    const material_t* m = &c->mats[c->tri_mat[p]];
+    c->prim_light[p] = -1;
+    if (m->emissive[0] > 0.0f || m->emissive[1] > 0.0f || m->emissive[2] > 0.0f) nl++;
+  }
+  c->lights = (light_t*)malloc(sizeof(light_t) * (nl ? nl : 1)); c->cdf = (float*)malloc(4u * (nl ? nl : 1));
+  nl = 0; float total = 0.0f;
+  for (uint32_t p = 0; p < n; ++p) {
+    const material_t* m = &c->mats[c->tri_mat[p]];
+    if (!(m->emissive[0] > 0.0f || m->emissive[1] > 0.0f || m->emissive[2] > 0.0f)) continue;
+    const float* a = c->wv[c->widx[p * 3 + 0]].position; const float* bb = c->wv[c->widx[p * 3 + 1]].position; const float* d = c->wv[c->widx[p * 3 + 2]].position;
+    light_t L; L.v0 = V3(a[0], a[1], a[2]);
+    L.e1 = V3(bb[0] - a[0], bb[1] - a[1], bb[2] - a[2]); L.e2 = V3(d[0] - a[0], d[1] - a[1], d[2] - a[2]);
+    v3 cr = cross3(L.e1, L.e2); float len = sqrtf(dot3(cr, cr));
+    L.area = 0.5f * len; L.Le = V3(m->emissive[0], m->emissive[1], m->emissive[2]);
+    float wgt = L.area * luminance(L.Le);
+    if (!(wgt > 0.0f)) continue;
+    L.ng = vscale(cr, 1.0f / len); L.pmf = wgt; L.prim = p;
+    c->prim_light[p] = (int32_t)nl; c->lights[nl++] = L; total += wgt;
+  }
+  c->n_lights = nl;
+  float run = 0.0f;
+  for (uint32_t i = 0; i < nl; ++i) { run += c->lights[i].pmf; c->cdf[i] = run / total; c->lights[i].pmf = c->lights[i].pmf / total; }
+  if (nl) c->cdf[nl - 1] = 1.0f;
+  memset(&c->stats, 0, sizeof c->stats);
+  c->stats.n_triangles = n; c->stats.n_bvh_nodes = c->n_nodes; c->stats.n_emitters = nl; c->stats.bvh_max_depth = c->max_depth;
+  c->committed = 1;
+  return 0;
+}
+
+int ora_get_flat_scene(ora_ctx* c, uint32_t* nv, uint32_t* nt, void* verts, uint32_t* idx, int32_t* tm) {
+  if (!c->committed) return fail(c, "get_flat_scene: scene not committed");
+  if (nv) *nv = c->n_wv;
+  if (nt) *nt = c->n_tris;
+  if (verts) memcpy(verts, c->wv, sizeof(vert48) * c->n_wv);
+  if (idx) memcpy(idx, c->widx, 12u * c->n_tris);
+  if (tm) memcpy(tm, c->tri_mat, 4u * c->n_tris);
+  return 0;
+}
+
+int ora_get_bvh(ora_ctx* c, uint32_t* nn, uint32_t* nt, float* nodes, float* tris) {
+  if (!c->committed) return fail(c, "get_bvh: scene not committed");
+  if (nn) *nn = c->n_nodes;
+  if (nt) *nt = c->n_tris;
+  if (nodes) memcpy(nodes, c->nodes, sizeof(node_t) * c->n_nodes);
+  if (tris) for (uint32_t i = 0; i < c->n_tris; ++i) {
+    float* o = tris + (size_t)i * 12; uint32_t p = c->order[i];
+    const material_t* m = &c->mats[c->tri_mat[p]];
+    uint32_t cls = (m->metallic == 0.0f && m->roughness >= 1.0f) ? 0u : 1u;
+    o[0] = c->tv0[i].x; o[1] = c->tv0[i].y; o[2] = c->tv0[i].z; memcpy(&o[3], &p, 4);
+    o[4] = c->te1[i].x; o[5] = c->te1[i].y; o[6] = c->te1[i].z; memcpy(&o[7], &cls, 4);
+    o[8] = c->te2[i].x; o[9] = c->te2[i].y; o[10] = c->te2[i].z; o[11] = 0.0f;
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* P3/P4: traversal                                                                             */
+typedef struct { uint64_t nodes, tris; } trav_count;
+
+typedef struct { v3 o, d, inv, ood; } ray_t;
+static inline float safe_dir(float d) { return fabsf(d) < 1e-20f ? copysignf(1e-20f, d) : d; }
+static inline ray_t make_ray(v3 o, v3 d) {
+  ray_t r; r.o = o; r.d = d;
+  r.inv = V3(1.0f / safe_dir(d.x), 1.0f / safe_dir(d.y), 1.0f / safe_dir(d.z));
+  r.ood = V3(o.x * r.inv.x, o.y * r.inv.y, o.z * r.inv.z);
+  return r;
+}
+/* slab test of one child box against [tmin, tlimit]; returns hit, writes entry distance */
+static inline int box_hit(const ray_t* r, const float lo[3], const float hi[3], float tmin, float tlimit, float* tn) {
+  float x0 = fmaf(lo[0], r->inv.x, -r->ood.x), x1 = fmaf(hi[0], r->inv.x, -r->ood.x);
+  float y0 = fmaf(lo[1], r->inv.y, -r->ood.y), y1 = fmaf(hi[1], r->inv.y, -r->ood.y);
+  float z0 = fmaf(lo[2], r->inv.z, -r->ood.z), z1 = fmaf(hi[2], r->inv.z, -r->ood.z);
+  float tnear = fmax2(fmax2(fmin2(x0, x1), fmin2(y0, y1)), fmax2(fmin2(z0, z1), tmin));
+  float tfar = fmin2(fmin2(fmax2(x0, x1), fmax2(y0, y1)), fmin2(fmax2(z0, z1), tlimit));
+  *tn = tnear;
+  return tnear <= tfar;
+}
+/* Möller–Trumbore on (v0,e1,e2).  cull: R6 back-face culling (front = det > 0). */
+static inline int tri_test(const ray_t* r, v3 v0, v3 e1, v3 e2, int cull, float* t, float* u, float* v) {
+  v3 p = cross3(r->d, e2);
+  float det = dot3(e1, p);
+  if (cull ? !(det > 0.0f) : (det == 0.0f)) return 0;
+  float inv = 1.0f / det;
+  v3 tv = vsub(r->o, v0);
+  float uu = dot3(tv, p) * inv;
+  if (!(uu >= 0.0f && uu <= 1.0f)) return 0;
+  v3 q = cross3(tv, e1);
+  float vv = dot3(r->d, q) * inv;
+  if (!(vv >= 0.0f && uu + vv <= 1.0f)) return 0;
+  *t = dot3(e2, q) * inv; *u = uu; *v = vv;
+  return 1;
+}
+
+typedef struct { float t, u, v; int32_t prim; uint32_t pos; } hit_t;
+
+static hit_t trace_closest(const ora_ctx* c, v3 o, v3 d, float tmin, float tmax, int cull, trav_count* cnt) {
+  hit_t best; best.t = tmax; best.prim = 0x7fffffff; best.u = best.v = 0.0f; best.pos = 0; int found = 0;
+  ray_t r = make_ray(o, d);
+  int32_t stack[ORA_STACK]; int sp = 0; int32_t cur = 0;
+  for (;;) {
+    while (cur >= 0) {
+      const node_t* n = &c->nodes[cur]; cnt->nodes++;
+      float t0, t1;
+      int h0 = box_hit(&r, n->lo0, n->hi0, tmin, best.t, &t0);
+      int h1 = box_hit(&r, n->lo1, n->hi1, tmin, best.t, &t1);
+      if (h0 && h1) {
+        int32_t first = n->c0, second = n->c1;
+        if (t1 < t0) { first = n->c1; second = n->c0; }
+        stack[sp++] = second; cur = first;
+      } else if (h0) cur = n->c0;
+      else if (h1) cur = n->c1;
+      else { if (sp == 0) goto done; cur = stack[--sp]; }
+    }
+    {
+      uint32_t code = (uint32_t)~cur; uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
+      for (uint32_t i = first; i < first + count; ++i) {
+        float t, u, v; cnt->tris++;
+        if (!tri_test(&r, c->tv0[i], c->te1[i], c->te2[i], cull, &t, &u, &v)) continue;
+        int32_t pid = (int32_t)c->order[i];
+        if (t > tmin && (t < best.t || (t == best.t && pid < best.prim))) { best.t = t; best.u = u; best.v = v; best.prim = pid; best.pos = i; found = 1; }
+      }
+      if (sp == 0) break;
+      cur = stack[--sp];
+    }
+  }
+done:
+  if (!found) { best.t = -1.0f; best.prim = -1; }
+  return best;
+}
+static int trace_any(const ora_ctx* c, v3 o, v3 d, float tmin, float tmax, trav_count* cnt) {
+  ray_t r = make_ray(o, d);
+  int32_t stack[ORA_STACK]; int sp = 0; int32_t cur = 0;
+  for (;;) {
+    while (cur >= 0) {
+      const node_t* n = &c->nodes[cur]; cnt->nodes++;
+      float t0, t1;
+      int h0 = box_hit(&r, n->lo0, n->hi0, tmin, tmax, &t0);
+      int h1 = box_hit(&r, n->lo1, n->hi1, tmin, tmax, &t1);
+      if (h0 && h1) {
+        int32_t first = n->c0, second = n->c1;
+        if (t1 < t0) { first = n->c1; second = n->c0; }
+        stack[sp++] = second; cur = first;
+      } else if (h0) cur = n->c0;
+      else if (h1) cur = n->c1;
+      else { if (sp == 0) return 0; cur = stack[--sp]; }
+    }
+    uint32_t code = (uint32_t)~cur; uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
+    for (uint32_t i = first; i < first + count; ++i) {
+      float t, u, v; cnt->tris++;
+      if (tri_test(&r, c->tv0[i], c->te1[i], c->te2[i], 0, &t, &u, &v) && t > tmin && t < tmax) return 1;
+    }
+    if (sp == 0) return 0;
+    cur = stack[--sp];
+  }
+}
+
+int ora_trace_closest(ora_ctx* c, const float* o, const float* d, uint32_t n, float* ot, int32_t* op, float* ouv) {
+  if (!c->committed) return fail(c, "trace_closest: scene not committed");
+  trav_count cnt = {0, 0};
+  for (uint32_t i = 0; i < n; ++i) {
+    hit_t h = trace_closest(c, V3(o[i * 3], o[i * 3 + 1], o[i * 3 + 2]), V3(d[i * 3], d[i * 3 + 1], d[i * 3 + 2]), 0.0f, ORA_T_INF, 0, &cnt);
+    ot[i] = h.t; op[i] = h.prim; ouv[i * 2] = h.u; ouv[i * 2 + 1] = h.v;
+  }
+  c->stats.node_visits_closest = cnt.nodes; c->stats.tri_tests_closest = cnt.tris;
+  return 0;
+}
+int ora_trace_any(ora_ctx* c, const float* o, const float* d, const float* tmax, uint32_t n, uint8_t* occ) {
+  if (!c->committed) return fail(c, "trace_any: scene not committed");
+  trav_count cnt = {0, 0};
+  for (uint32_t i = 0; i < n; ++i)
+    occ[i] = (uint8_t)trace_any(c, V3(o[i * 3], o[i * 3 + 1], o[i * 3 + 2]), V3(d[i * 3], d[i * 3 + 1], d[i * 3 + 2]), 0.0f, tmax[i], &cnt);
+  c->stats.node_visits_any = cnt.nodes; c->stats.tri_tests_any = cnt.tris;
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* P6: BSDF in the local frame of the shading normal (z = n).                                    */
+typedef struct { v3 cd, f0; float alpha; int ggx; } bsdf_t;
+
+static inline bsdf_t make_bsdf(const material_t* m) {
+  bsdf_t b;
+  v3 base = V3(m->base[0], m->base[1], m->base[2]);
+  float mt = m->metallic;
+  b.ggx = !(mt == 0.0f && m->roughness >= 1.0f);      /* metallic 0 & roughness 1 → pure Lambert class */
+  b.cd = vscale(base, 1.0f - mt);
+  b.f0 = V3(fmaf(base.x, mt, 0.04f * (1.0f - mt)), fmaf(base.y, mt, 0.04f * (1.0f - mt)), fmaf(base.z, mt, 0.04f * (1.0f - mt)));
+  float a = m->roughness * m->roughness;
+  b.alpha = fmax2(a, ORA_ALPHA_MIN);
+  return b;
+}
+static inline float smith_g1(float x, float a2) { return (2.0f * x) / (x + sqrtf(fmaf(1.0f - a2, x * x, a2))); }
+static inline v3 schlick(v3 f0, float voh) {
+  float m = 1.0f - voh; if (m < 0.0f) m = 0.0f;
+  float m2 = m * m; float m5 = m2 * m2 * m;
+  return V3(fmaf(1.0f - f0.x, m5, f0.x), fmaf(1.0f - f0.y, m5, f0.y), fmaf(1.0f - f0.z, m5, f0.z));
+}
+/* probability of choosing the specular lobe, from wo only */
+static inline float spec_prob(const bsdf_t* b, float nov) {
+  if (!b->ggx) return 0.0f;
+  float ld = luminance(b->cd);
+  if (!(ld > 0.0f)) return 1.0f;
+  float lf = luminance(schlick(b->f0, nov));
+  float p = lf / (lf + ld);
+  return fmin2(fmax2(p, 0.1f), 0.9f);
+}
+/* f (rgb) and pdf (solid angle) for local wo, wi (both z > 0) */
+static inline void bsdf_eval(const bsdf_t* b, v3 wo, v3 wi, float ps, v3* f, float* pdf) {
+  float nol = wi.z;
+  v3 fd = vscale(b->cd, ORA_INV_PI);
+  float pd = nol * ORA_INV_PI;
+  if (!b->ggx) { *f = fd; *pdf = pd; return; }
+  float nov = fmax2(wo.z, 1e-4f);
+  v3 h = normalize3(vadd(wo, wi));
+  float noh = h.z, voh = dot3(wo, h);
+  float a2 = b->alpha * b->alpha;
+  float dd = fmaf(noh * noh, a2 - 1.0f, 1.0f);
+  float D = a2 / (ORA_PI * dd * dd);
+  float gv = smith_g1(nov, a2), gl = smith_g1(nol, a2);
+  v3 F = schlick(b->f0, voh);
+  float sp = (D * gv * gl) / (4.0f * nov * nol);
+  *f = V3(fmaf(F.x, sp, fd.x), fmaf(F.y, sp, fd.y), fmaf(F.z, sp, fd.z));
+  float pspec = (gv * D) / (4.0f * nov);
+  *pdf = fmaf(ps, pspec, (1.0f - ps) * pd);
+}
+/* sample local wi; returns 0 when the sample is unusable */
+static inline int bsdf_sample(const bsdf_t* b, v3 wo, float ps, float ul, float s1, float s2, v3* wi) {
+  float sn, cs; sincos2pi(s2, &sn, &cs);
+  float r = sqrtf(s1);
+  if (ul < ps) {  /* GGX VNDF (Heitz 2018) */
+    float a = b->alpha;
+    v3 vh = normalize3(V3(a * wo.x, a * wo.y, wo.z));
+    float lensq = fmaf(vh.y, vh.y, vh.x * vh.x);
+    v3 t1 = V3(1.0f, 0.0f, 0.0f);
+    if (lensq > 0.0f) { float il = 1.0f / sqrtf(lensq); t1 = V3(-vh.y * il, vh.x * il, 0.0f); }
+    v3 t2 = cross3(vh, t1);
+    float p1 = r * cs, p2 = r * sn;
+    float s = 0.5f * (1.0f + vh.z);
+    p2 = fmaf(1.0f - s, sqrtf(fmax2(0.0f, 1.0f - p1 * p1)), s * p2);
+    float pz = sqrtf(fmax2(0.0f, 1.0f - p1 * p1 - p2 * p2));
+    v3 nh = vfma(t1, p1, vfma(t2, p2, vscale(vh, pz)));
+    v3 h = normalize3(V3(a * nh.x, a * nh.y, fmax2(0.0f, nh.z)));
+    float voh = dot3(wo, h);
+    *wi = V3(fmaf(2.0f * voh, h.x, -wo.x), fmaf(2.0f * voh, h.y, -wo.y), fmaf(2.0f * voh, h.z, -wo.z));
+  } else {        /* cosine hemisphere */
+    *wi = V3(r * cs, r * sn, sqrtf(fmax2(0.0f, 1.0f - s1)));
+  }
+  return wi->z > 0.0f;
+}
+/* branchless orthonormal basis (Duff et al. 2017) */
+static inline void onb(v3 n, v3* t, v3* b) {
+  float sg = copysignf(1.0f, n.z);
+  float a = -1.0f / (sg + n.z);
+  float bb = n.x * n.y * a;
+  *t = V3(fmaf(sg * n.x, n.x * a, 1.0f), sg * bb, -sg * n.x);
+  *b = V3(bb, fmaf(n.y, n.y * a, sg), -n.y);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* tile ownership: 32×32 tiles, Morton walk over the tile grid, tile t → rank t mod n */
+static inline uint32_t compact1by1(uint32_t x) {
+  x &= 0x55555555u; x = (x ^ (x >> 1)) & 0x33333333u; x = (x ^ (x >> 2)) & 0x0f0f0f0fu;
+  x = (x ^ (x >> 4)) & 0x00ff00ffu; x = (x ^ (x >> 8)) & 0x0000ffffu; return x;
+}
+/* rank of tile (tx,ty) in the Morton walk restricted to the tiles_x × tiles_y grid */
+static uint32_t* tile_ranks(int w, int h, uint32_t* n_tiles_out) {
+  uint32_t tx = (uint32_t)(w + ORA_TILE - 1) / ORA_TILE, ty = (uint32_t)(h + ORA_TILE - 1) / ORA_TILE;
+  uint32_t* rank = (uint32_t*)malloc(4u * tx * ty);
+  uint32_t side = 1; while (side < tx || side < ty) side <<= 1;
+  uint32_t t = 0;
+  for (uint32_t m = 0; m < side * side; ++m) {
+    uint32_t x = compact1by1(m), y = compact1by1(m >> 1);
+    if (x < tx && y < ty) rank[y * tx + x] = t++;
+  }
+  *n_tiles_out = t;
+  return rank;
+}
+int ora_tile_owner(int w, int h, int x, int y, int tile_count) {
+  uint32_t nt; uint32_t* rank = tile_ranks(w, h, &nt);
+  uint32_t tx = (uint32_t)(w + ORA_TILE - 1) / ORA_TILE;
+  int o = (int)(rank[(uint32_t)(y / ORA_TILE) * tx + (uint32_t)(x / ORA_TILE)] % (uint32_t)tile_count);
+  free(rank); return o;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* P1 + P5–P10: one camera sample → radiance                                                   */
+typedef struct {
+  uint64_t segments, shadow_rays, hits; trav_count closest, any;
+} path_count;
+
+typedef struct { v3 p, ng, ns; int front; const material_t* mat; } surf_t;
+
+static inline surf_t reconstruct(const ora_ctx* c, v3 d, const hit_t* h) {
+  surf_t s; uint32_t p = (uint32_t)h->prim;
+  const vert48* a = &c->wv[c->widx[p * 3 + 0]]; const vert48* b = &c->wv[c->widx[p * 3 + 1]]; const vert48* e = &c->wv[c->widx[p * 3 + 2]];
+  float u = h->u, v = h->v, w = 1.0f - u - v;
+  s.p = V3(fmaf(e->position[0], v, fmaf(b->position[0], u, a->position[0] * w)),
+           fmaf(e->position[1], v, fmaf(b->position[1], u, a->position[1] * w)),
+           fmaf(e->position[2], v, fmaf(b->position[2], u, a->position[2] * w)));
+  v3 e1 = V3(b->position[0] - a->position[0], b->position[1] - a->position[1], b->position[2] - a->position[2]);
+  v3 e2 = V3(e->position[0] - a->position[0], e->position[1] - a->position[1], e->position[2] - a->position[2]);
+  s.ng = normalize3(cross3(e1, e2));
+  s.ns = normalize3(V3(fmaf(e->normal[0], v, fmaf(b->normal[0], u, a->normal[0] * w)),
+                       fmaf(e->normal[1], v, fmaf(b->normal[1], u, a->normal[1] * w)),
+                       fmaf(e->normal[2], v, fmaf(b->normal[2], u, a->normal[2] * w))));
+  v3 wo = vneg(d);
+  s.front = dot3(s.ng, wo) > 0.0f;
+  if (dot3(s.ns, s.ng) < 0.0f) s.ns = vneg(s.ns);
+  if (!s.front) { s.ng = vneg(s.ng); s.ns = vneg(s.ns); }
+  if (!(dot3(s.ns, wo) > 0.0f)) s.ns = s.ng;
+  s.mat = &c->mats[c->tri_mat[p]];
+  return s;
+}
+
+static v3 trace_path(const ora_ctx* c, const camera_t* cam, int w, int h, uint32_t px, uint32_t py, uint32_t sample,
+                     uint64_t seed, int max_bounces, path_count* pc) {
+  uint32_t key = path_key(seed, py * (uint32_t)w + px, sample);
+  float jx = rng_f(key, 0, 0), jy = rng_f(key, 0, 1);
+  float fx = ((float)px + jx) / (float)w, fy = ((float)py + jy) / (float)h;
+  float dvx = (2.0f * fx - 1.0f) * cam->sx, dvy = (2.0f * fy - 1.0f) * cam->sy;
+  v3 o = cam->pos;
+  v3 d = normalize3(vfma(cam->s, dvx, vfma(cam->u, dvy, cam->f)));
+  v3 T = V3(1.0f, 1.0f, 1.0f), L = V3(0.0f, 0.0f, 0.0f);
+  float prev_pdf = 0.0f;
+  for (int b = 0;; ++b) {
+    pc->segments++;
+    hit_t hit = trace_closest(c, o, d, 0.0f, ORA_T_INF, 0, &pc->closest);
+    if (hit.prim < 0) break;                                  /* background radiance = 0 */
+    pc->hits++;
+    surf_t s = reconstruct(c, d, &hit);
+    v3 wo = vneg(d);
+    const material_t* m = s.mat;
+    int li = c->prim_light[hit.prim];
+    if (li >= 0 && s.front) {                                 /* emission, one-sided, MIS vs NEE */
+      const light_t* lt = &c->lights[li];
+      float wgt = 1.0f;
+      if (b > 0) {
+        float cosl = dot3(s.ng, wo);
+        float pl = (lt->pmf * (hit.t * hit.t)) / (lt->area * cosl);
+        float pb2 = prev_pdf * prev_pdf;
+        wgt = pb2 / fmaf(pl, pl, pb2);
+      }
+      L = V3(fmaf(T.x * lt->Le.x, wgt, L.x), fmaf(T.y * lt->Le.y, wgt, L.y), fmaf(T.z * lt->Le.z, wgt, L.z));
+    }
+    if (b >= max_bounces) break;
+    bsdf_t bs = make_bsdf(m);
+    v3 tx, ty; onb(s.ns, &tx, &ty);
+    v3 wol = V3(dot3(tx, wo), dot3(ty, wo), dot3(s.ns, wo));
+    float ps = spec_prob(&bs, fmax2(wol.z, 1e-4f));
+    v3 porg = vfma(s.ng, c->ray_eps, s.p);
+    uint32_t rb = (uint32_t)b + 1u;
+    /* P7 next-event estimation */
+    if (c->n_lights > 0) {
+      float u0 = rng_f(key, rb, 0), r1 = rng_f(key, rb, 1), r2 = rng_f(key, rb, 2);
+      uint32_t lo = 0, hi = c->n_lights - 1;
+      while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (c->cdf[mid] > u0) hi = mid; else lo = mid + 1; }
+      const light_t* lt = &c->lights[lo];
+      float su = sqrtf(r1); float bu = su * (1.0f - r2), bv = su * r2;
+      v3 y = vfma(lt->e2, bv, vfma(lt->e1, bu, lt->v0));
+      v3 dv = vsub(y, s.p);
+      float dist2 = dot3(dv, dv);
+      if (dist2 > 0.0f) {
+        float dist = sqrtf(dist2);
+        v3 wi = vscale(dv, 1.0f / dist);
+        float cosl = -dot3(lt->ng, wi);
+        v3 wil = V3(dot3(tx, wi), dot3(ty, wi), dot3(s.ns, wi));
+        if (cosl > 0.0f && wil.z > 0.0f && dot3(s.ng, wi) > 0.0f) {
+          float pl = (lt->pmf * dist2) / (lt->area * cosl);
+          v3 f; float pb; bsdf_eval(&bs, wol, wil, ps, &f, &pb);
+          float pl2 = pl * pl;
+          float wgt = pl2 / fmaf(pb, pb, pl2);
+          float k = (wil.z * wgt) / pl;
+          v3 contrib = V3(T.x * f.x * lt->Le.x * k, T.y * f.y * lt->Le.y * k, T.z * f.z * lt->Le.z * k);
+          pc->shadow_rays++;
+          if (!trace_any(c, porg, wi, 0.0f, dist * 0.999f, &pc->any)) L = vadd(L, contrib);
+        }
+      }
+    }
+    /* P6 continuation */
+    float ul = rng_f(key, rb, 3), s1 = rng_f(key, rb, 4), s2 = rng_f(key, rb, 5);
+    v3 wil;
+    if (!bsdf_sample(&bs, wol, ps, ul, s1, s2, &wil)) break;
+    v3 wi = vfma(tx, wil.x, vfma(ty, wil.y, vscale(s.ns, wil.z)));
+    if (!(dot3(s.ng, wi) > 0.0f)) break;
+    v3 f; float pdf; bsdf_eval(&bs, wol, wil, ps, &f, &pdf);
+    if (!(pdf > 0.0f)) break;
+    float k = wil.z / pdf;
+    T = V3(T.x * f.x * k, T.y * f.y * k, T.z * f.z * k);
+    /* P8 Russian roulette */
+    if (rb >= ORA_RR_START) {
+      float q = max3c(T);
+      if (!(q > 0.0f)) break;
+      float pr = fmin2(fmax2(q, ORA_RR_PMIN), 1.0f);
+      float ur = rng_f(key, rb, 6);
+      if (ur >= pr) break;
+      T = V3(T.x / pr, T.y / pr, T.z / pr);
+    }
+    o = porg; d = wi; prev_pdf = pdf;
+  }
+  return L;
+}
+
+/* Raster-compat: the reference's deferred Blinn-Phong result by ray casting the primary hit.    */
+static void raster_compat_pixel(const ora_ctx* c, const camera_t* cam, int w, int h, uint32_t px, uint32_t py, float out[4], path_count* pc) {
+  float fx = ((float)px + 0.5f) / (float)w, fy = ((float)py + 0.5f) / (float)h;
+  float dvx = (2.0f * fx - 1.0f) * cam->sx, dvy = (2.0f * fy - 1.0f) * cam->sy;
+  v3 dn = vfma(cam->s, dvx, vfma(cam->u, dvy, cam->f));
+  float len = sqrtf(fmaf(dvy, dvy, fmaf(dvx, dvx, 1.0f)));
+  v3 d = normalize3(dn);
+  /* Vulkan clips NDC z to [0,1] under a -1..1 projection: near = 2fn/(f+n) */
+  float dnear = (2.0f * ORA_ZFAR * ORA_ZNEAR) / (ORA_ZFAR + ORA_ZNEAR);
+  pc->segments++;
+  hit_t hit = trace_closest(c, cam->pos, d, dnear * len, ORA_ZFAR * len, 1, &pc->closest);
+  out[0] = out[1] = out[2] = out[3] = 0.0f;                  /* G-buffer clear → colour 0 */
+  if (hit.prim < 0) return;
+  pc->hits++;
+  uint32_t p = (uint32_t)hit.prim;
+  const vert48* a = &c->wv[c->widx[p * 3 + 0]]; const vert48* b = &c->wv[c->widx[p * 3 + 1]]; const vert48* e = &c->wv[c->widx[p * 3 + 2]];
+  float u = hit.u, v = hit.v, ww = 1.0f - u - v;
+  v3 P = V3(fmaf(e->position[0], v, fmaf(b->position[0], u, a->position[0] * ww)),
+            fmaf(e->position[1], v, fmaf(b->position[1], u, a->position[1] * ww)),
+            fmaf(e->position[2], v, fmaf(b->position[2], u, a->position[2] * ww)));
+  /* fragment.glsl:24-27 with the default flat normal texel (0.5,0.5,1): TBN·(0,0,1) = N */
+  v3 N = normalize3(V3(fmaf(e->normal[0], v, fmaf(b->normal[0], u, a->normal[0] * ww)),
+                       fmaf(e->normal[1], v, fmaf(b->normal[1], u, a->normal[1] * ww)),
+                       fmaf(e->normal[2], v, fmaf(b->normal[2], u, a->normal[2] * ww))));
+  const material_t* m = &c->mats[c->tri_mat[p]];
+  v3 V = normalize3(vsub(cam->pos, P));                      /* lighting.glsl:25 */
+  v3 H = normalize3(vadd(V, V));                             /* L = V; BlinnPhong.lib.glsl:6 */
+  float ndv = fmax2(dot3(N, V), 0.0f), ndh = fmax2(dot3(N, H), 0.0f);
+  float s2 = ndh * ndh, s4 = s2 * s2, s8 = s4 * s4, s16 = s8 * s8, s32 = s16 * s16, spec = s32 * s32; /* pow(.,64) */
+  for (int k = 0; k < 4; ++k) out[k] = fmaf(m->base[k], ndv, spec);
+}
+
+typedef struct {
+  const ora_ctx* c; camera_t cam; int w, h, spp, max_bounces, integrator, tile_rank, tile_count;
+  uint64_t seed; float* out; const uint32_t* trank; uint32_t tiles_x;
+  volatile int next_row; path_count pc; pthread_mutex_t* mu; path_count* total;
+} job_t;
+
+static void* worker(void* arg) {
+  job_t* j = (job_t*)arg;
+  path_count pc; memset(&pc, 0, sizeof pc);
+  for (;;) {
+    int y = __sync_fetch_and_add(&j->next_row, 1);
+    if (y >= j->h) break;
+    for (int x = 0; x < j->w; ++x) {
+      float* o = j->out + ((size_t)y * j->w + x) * 4;
+      if (j->tile_count > 1) {
+        uint32_t t = j->trank[(uint32_t)(y / ORA_TILE) * j->tiles_x + (uint32_t)(x / ORA_TILE)];
+        if ((int)(t % (uint32_t)j->tile_count) != j->tile_rank) { o[0] = o[1] = o[2] = o[3] = 0.0f; continue; }
+      }
+      if (j->integrator == 1) { raster_compat_pixel(j->c, &j->cam, j->w, j->h, (uint32_t)x, (uint32_t)y, o, &pc); continue; }
+      v3 sum = V3(0.0f, 0.0f, 0.0f);
+      for (int s = 0; s < j->spp; ++s) {                       /* P10: sample-index order */
+        v3 L = trace_path(j->c, &j->cam, j->w, j->h, (uint32_t)x, (uint32_t)y, (uint32_t)s, j->seed, j->max_bounces, &pc);
+        sum = vadd(sum, L);
+      }
+      float fs = (float)j->spp;
+      o[0] = sum.x / fs; o[1] = sum.y / fs; o[2] = sum.z / fs; o[3] = 1.0f;
+    }
+  }
+  pthread_mutex_lock(j->mu);
+  j->total->segments += pc.segments; j->total->shadow_rays += pc.shadow_rays; j->total->hits += pc.hits;
+  j->total->closest.nodes += pc.closest.nodes; j->total->closest.tris += pc.closest.tris;
+  j->total->any.nodes += pc.any.nodes; j->total->any.tris += pc.any.tris;
+  pthread_mutex_unlock(j->mu);
+  return NULL;
+}
+
+int ora_render(ora_ctx* c, int w, int h, int spp, uint64_t seed, int max_bounces, int integrator,
+               int tile_rank, int tile_count, int n_threads, float* out) {
+  if (!c->committed) return fail(c, "render: scene not committed");
+  if (w <= 0 || h <= 0 || spp <= 0 || max_bounces < 0 || !out) return fail(c, "render: bad argument");
+  if (integrator != 0 && integrator != 1) return fail(c, "render: unknown integrator");
+  if (tile_count < 1 || tile_rank < 0 || tile_rank >= tile_count) return fail(c, "render: bad tile rank/count");
+  if (n_threads <= 0) n_threads = ora_hw_threads();
+  if (n_threads > 256) n_threads = 256;
+  uint32_t nt; uint32_t* trank = tile_ranks(w, h, &nt);
+  pthread_mutex_t mu; pthread_mutex_init(&mu, NULL);
+  path_count total; memset(&total, 0, sizeof total);
+  job_t j; memset(&j, 0, sizeof j);
+  j.c = c; j.cam = make_camera_basis(c->cam_pos, c->cam_target, c->cam_fov, c->cam_aspect);
+  j.w = w; j.h = h; j.spp = spp; j.max_bounces = max_bounces; j.integrator = integrator;
+  j.tile_rank = tile_rank; j.tile_count = tile_count; j.seed = seed; j.out = out; j.trank = trank;
+  j.tiles_x = (uint32_t)(w + ORA_TILE - 1) / ORA_TILE; j.next_row = 0; j.mu = &mu; j.total = &total;
+  struct timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
+  pthread_t th[256];
+  for (int i = 0; i < n_threads; ++i) pthread_create(&th[i], NULL, worker, &j);
+  for (int i = 0; i < n_threads; ++i) pthread_join(th[i], NULL);
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  pthread_mutex_destroy(&mu); free(trank);
+  ora_stats* s = &c->stats;
+  uint64_t owned = 0;
+  {
+    uint32_t nt2; uint32_t* tr = tile_ranks(w, h, &nt2); uint32_t tx = (uint32_t)(w + ORA_TILE - 1) / ORA_TILE;
+    for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x)
+      owned += ((int)(tr[(uint32_t)(y / ORA_TILE) * tx + (uint32_t)(x / ORA_TILE)] % (uint32_t)tile_count) == tile_rank);
+    free(tr);
+  }
+  s->paths = owned * (uint64_t)(integrator == 1 ? 1 : spp);
+  s->segments = total.segments; s->shadow_rays = total.shadow_rays; s->hits = total.hits;
+  s->node_visits_closest = total.closest.nodes; s->tri_tests_closest = total.closest.tris;
+  s->node_visits_any = total.any.nodes; s->tri_tests_any = total.any.tris;
+  s->algorithmic_bytes = s->segments * (2u * S_RAY + 2u * S_HIT) + s->node_visits_closest * S_NODE + s->tri_tests_closest * S_TRI
+                       + s->hits * S_SURF + s->shadow_rays * (2u * S_SHADOW) + s->node_visits_any * S_NODE + s->tri_tests_any * S_TRI
+                       + s->paths * (2u * S_FB);
+  s->seconds_render = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+  return 0;
+}
+int ora_get_stats(ora_ctx* c, ora_stats* out) { if (!out) return fail(c, "get_stats: null"); *out = c->stats; return 0; }
+
+/* ------------------------------------------------------------------------------------------ */
+/* R9: ACES fit + gamma 2.2 + clamp → RGBA8.  GLSL mat3x3(a,b,c, d,e,f, g,h,i) is column-major,   */
+/* so the matrices written row-wise in aces+gamma.glsl:10-19 act as their transposes. */
+static inline float rrt_odt(float c) {
+  float num = c * (c + 0.0245786f) - 0.000090537f;
+  float den = c * (0.983729f * c + 0.4329510f) + 0.238081f;
+  return num / den;
+}
+void ora_tonemap_rgba8(const float* rgba, uint32_t n, uint8_t* out) {
+  for (uint32_t i = 0; i < n; ++i) {
+    float r = rgba[i * 4], g = rgba[i * 4 + 1], b = rgba[i * 4 + 2], a = rgba[i * 4 + 3];
+    float ir = 0.59719f * r + 0.07600f * g + 0.02840f * b;
+    float ig = 0.35458f * r + 0.90834f * g + 0.13383f * b;
+    float ib = 0.04823f * r + 0.01566f * g + 0.83777f * b;
+    float fr = rrt_odt(ir), fg = rrt_odt(ig), fb = rrt_odt(ib);
+    float orr = 1.60475f * fr + -0.10208f * fg + -0.00327f * fb;
+    float og = -0.53108f * fr + 1.10813f * fg + -0.07276f * fb;
+    float ob = -0.07367f * fr + -0.00605f * fg + 1.07602f * fb;
+    float c4[4] = {orr, og, ob, a};
+    for (int k = 0; k < 4; ++k) {
+      float v = c4[k];
+      if (k < 3) v = pt_pow(fmax2(v, 0.0f), 1.0f / 2.2f);      /* clamp before pow: documented deviation */
+      v = fmin2(fmax2(v, 0.0f), 1.0f);
+      out[i * 4 + k] = (uint8_t)(int)(v * 255.0f + 0.5f);      /* UNORM8 round-to-nearest */
+    }
+  }
+}

@@ -1,0 +1,98 @@
+// ptc_internal.h — structures shared by the host side (ptc_api.cpp, ptc_scene.cpp) and the
+// kernels (pt_kernels.hip).  Nothing here crosses the C-ABI (include/ptc.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+// ---- HBM layout of the committed scene (DESIGN.md §"Data layout in HBM") -----------------------
+struct DevScene {
+  const float4* nodes;        // 4 × float4 per interior node (64 B): both child boxes + child codes
+  const float4* tris;         // 3 × float4 per triangle in Morton order (48 B): (v0,prim) (e1,class) (e2,-)
+  const float* wverts;        // world-space ptc_vertex records, 12 floats each (R1 layout)
+  const uint32_t* widx;       // 3 per original primitive id
+  const int32_t* tri_mat;     // material per original primitive id
+  const int32_t* prim_light;  // emitter index per original primitive id, or -1
+  const float4* mats;         // 3 × float4 per material: (base.rgb, metallic) (emissive.rgb, roughness) (base.a,-,-,-)
+  const float4* lights;       // 5 × float4 per emitter: (v0,area) (e1,pmf) (e2,-) (ng,-) (Le,-)
+  const float* cdf;           // emitter power cdf
+  uint32_t n_lights;
+  uint32_t n_nodelets;        // leading nodes (BFS order) that the trace kernels stage in LDS
+  float ray_eps;
+};
+
+struct DevCamera { float pos[3], f[3], s[3], u[3], sx, sy; };  // R5 basis, see ptc_scene.cpp
+
+struct DevFrame {
+  int w, h;
+  uint32_t seed_hash;          // pcg(seed_lo + pcg(seed_hi))
+  int max_bounces;
+  uint32_t n_owned;            // pixels this context owns
+  const uint32_t* owned;       // their indices y*w+x, tile-Morton order
+};
+
+// ---- wavefront queues (SoA of 16-byte lanes) ------------------------------------------------------
+// ray record   : A=(o.xyz,d.x) B=(d.y,d.z,T.x,T.y) C=(T.z,prev_pdf,path_id,key) D=bounce   (52 B)
+//   raster/debug rays reuse B.zw as (tmin,tmax)
+// hit record   : H=(t,prim,u,v)                                                            (16 B)
+// shadow record: A=(o.xyz,d.x) B=(d.y,d.z,tmax,path_id) C=(contrib.rgb,-)                  (48 B)
+struct RayQ { float4* A; float4* B; float4* C; uint32_t* D; };
+struct SortQ { float4* A; float4* B; float4* C; uint32_t* D; float4* H; };
+struct ShadowQ { float4* A; float4* B; float4* C; };
+
+struct DevQueues {
+  RayQ ray;        // compact [0, cnt[CNT_RAYS])
+  SortQ sorted;    // class 0 at [0, cnt[CNT_SORT0]), class 1 at (cap-1 ... cap-cnt[CNT_SORT1]]
+  ShadowQ shadow;  // compact [0, cnt[CNT_SHADOW])
+  float4* hit;     // in-place hit records (raster / debug mode)
+  float4* lpath;   // per-path radiance (rgb,-), single owner
+  uint32_t* cnt;   // device counters, see CNT_*
+  unsigned long long* stats;  // device statistics, see ST_*
+  uint32_t cap;    // queue capacity (paths per batch)
+};
+
+enum { CNT_RAYS = 0, CNT_SORT0, CNT_SORT1, CNT_NEXT, CNT_SHADOW, CNT_WORK_TRACE, CNT_WORK_SHADE, CNT_WORK_SHADOW, CNT_N };
+enum { ST_SEGMENTS = 0, ST_SHADOW, ST_HITS, ST_NODES_C, ST_TRIS_C, ST_NODES_A, ST_TRIS_A, ST_N };
+
+struct LaunchCfg { int n_cu; int trace_blocks_per_cu; bool lds_stack; };
+
+// ---- kernel launchers (pt_kernels.hip) ------------------------------------------------------------
+void pt_launch_set_counts(hipStream_t, const DevQueues&, uint32_t n_rays, uint32_t n_shadow);
+void pt_launch_advance(hipStream_t, const DevQueues&);
+void pt_launch_raygen(hipStream_t, const DevCamera&, const DevFrame&, const DevQueues&, uint32_t first_sample, uint32_t n_samples, bool raster);
+void pt_launch_trace_closest(hipStream_t, const LaunchCfg&, const DevScene&, const DevQueues&, int mode /*0 sort,1 in-place,2 in-place+cull*/);
+void pt_launch_shade(hipStream_t, const LaunchCfg&, const DevScene&, const DevFrame&, const DevQueues&);
+void pt_launch_trace_any(hipStream_t, const LaunchCfg&, const DevScene&, const DevQueues&, uint8_t* debug_out /*or null*/);
+void pt_launch_accumulate(hipStream_t, const DevFrame&, const DevQueues&, float4* accum, uint32_t n_samples);
+void pt_launch_shade_raster(hipStream_t, const DevScene&, const DevCamera&, const DevFrame&, const DevQueues&, float4* accum);
+void pt_launch_resolve(hipStream_t, const DevFrame&, const float4* accum, float4* radiance, float inv_spp_divisor, bool raster);
+void pt_launch_tonemap(hipStream_t, const float4* radiance, uint32_t* rgba8, int w, int h);
+
+// ---- host-side scene build (ptc_scene.cpp) ----------------------------------------------------------
+struct HostMaterial { float base[4]; float metallic, roughness; float emissive[3]; int tex_color, tex_normal, tex_mr; };
+struct HostVertex { float position[3], normal[3], tangent[4], texcoord[2]; };
+struct HostMesh { std::vector<HostVertex> v; std::vector<uint32_t> idx; int material; };
+struct HostInstance { int mesh; float t[3], q[4], s[3]; };
+
+struct HostBuilt {
+  std::vector<HostVertex> wverts;
+  std::vector<uint32_t> widx;
+  std::vector<int32_t> tri_mat;
+  std::vector<int32_t> prim_light;
+  std::vector<float> nodes;      // 16 floats per node
+  std::vector<float> tris;       // 12 floats per sorted triangle
+  std::vector<float> mats;       // 12 floats per material
+  std::vector<float> lights;     // 20 floats per emitter
+  std::vector<float> cdf;
+  uint32_t n_nodes = 0, n_tris = 0, n_lights = 0, max_depth = 0, n_nodelets = 0;
+  float ray_eps = 0.0f;
+};
+
+// returns empty string on success, else the error text
+std::string ptc_build_scene(const std::vector<HostMaterial>&, const std::vector<HostMesh>&, const std::vector<HostInstance>&,
+                            uint32_t nodelet_budget, HostBuilt& out);
+void ptc_make_camera(const float pos[3], const float target[3], float fov, float aspect, DevCamera& cam);
+// pixels owned by (rank,count) in tile-Morton order
+void ptc_owned_pixels(int w, int h, int tile_rank, int tile_count, std::vector<uint32_t>& out);

@@ -1,0 +1,401 @@
+// ptc_scene.cpp — host side of ptc_scene_commit: flatten instances to world space, build the LBVH,
+// lay it out for the trace kernels, build the emitter table.
+//
+// Reference conventions implemented here (file:line under the reference checkout):
+//   R2  primitive concatenation        src/pbr_engine/engine/pbr/MeshBuilder.cpp:16-55
+//   R3  model = T·R·S, normal matrix   src/pbr_engine/engine/pbr/ModelPushConstant.hpp:33-46
+//   R4  world-space N/T                assets/shaders/geometry_pass/vertex.glsl:25-36
+//   R5  camera basis                   src/pbr_engine/engine/pbr/CameraData.hpp:22-32
+// Everything is plain IEEE binary32 without contraction (this file is compiled -ffp-contract=off),
+// so the flattened scene is reproducible bit for bit.
+#include "ptc_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace {
+
+constexpr int kLeafMax = 4;
+constexpr int kTile = 32;
+
+struct Mat34 { float m[16]; float n[9]; };  // column-major model (glm layout) + normal matrix
+
+// translate(t) * toMat4(q) * scale(s), then mat3(transpose(inverse(model))) via cofactors.
+Mat34 make_model(const float t[3], const float q[4], const float s[3]) {
+  Mat34 r;
+  const float w = q[0], x = q[1], y = q[2], z = q[3];
+  const float xx = x * x, yy = y * y, zz = z * z, xz = x * z, xy = x * y, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+  float R[9];
+  R[0] = 1.0f - 2.0f * (yy + zz); R[1] = 2.0f * (xy + wz);        R[2] = 2.0f * (xz - wy);
+  R[3] = 2.0f * (xy - wz);        R[4] = 1.0f - 2.0f * (xx + zz); R[5] = 2.0f * (yz + wx);
+  R[6] = 2.0f * (xz + wy);        R[7] = 2.0f * (yz - wx);        R[8] = 1.0f - 2.0f * (xx + yy);
+  float A[9];
+  for (int c = 0; c < 3; ++c)
+    for (int k = 0; k < 3; ++k) A[c * 3 + k] = R[c * 3 + k] * s[c];
+  for (int c = 0; c < 3; ++c) {
+    for (int k = 0; k < 3; ++k) r.m[c * 4 + k] = A[c * 3 + k];
+    r.m[c * 4 + 3] = 0.0f;
+  }
+  r.m[12] = t[0]; r.m[13] = t[1]; r.m[14] = t[2]; r.m[15] = 1.0f;
+  auto a = [&](int row, int col) { return A[col * 3 + row]; };
+  const float c00 = a(1, 1) * a(2, 2) - a(1, 2) * a(2, 1);
+  const float c01 = a(1, 2) * a(2, 0) - a(1, 0) * a(2, 2);
+  const float c02 = a(1, 0) * a(2, 1) - a(1, 1) * a(2, 0);
+  const float c10 = a(0, 2) * a(2, 1) - a(0, 1) * a(2, 2);
+  const float c11 = a(0, 0) * a(2, 2) - a(0, 2) * a(2, 0);
+  const float c12 = a(0, 1) * a(2, 0) - a(0, 0) * a(2, 1);
+  const float c20 = a(0, 1) * a(1, 2) - a(0, 2) * a(1, 1);
+  const float c21 = a(0, 2) * a(1, 0) - a(0, 0) * a(1, 2);
+  const float c22 = a(0, 0) * a(1, 1) - a(0, 1) * a(1, 0);
+  const float det = a(0, 0) * c00 + a(0, 1) * c01 + a(0, 2) * c02;
+  const float id = 1.0f / det;
+  r.n[0] = c00 * id; r.n[1] = c10 * id; r.n[2] = c20 * id;
+  r.n[3] = c01 * id; r.n[4] = c11 * id; r.n[5] = c21 * id;
+  r.n[6] = c02 * id; r.n[7] = c12 * id; r.n[8] = c22 * id;
+  return r;
+}
+
+inline float fdot(const float a[3], const float b[3]) { return fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0])); }
+inline void fcross(const float a[3], const float b[3], float o[3]) {
+  o[0] = fmaf(a[1], b[2], -(a[2] * b[1]));
+  o[1] = fmaf(a[2], b[0], -(a[0] * b[2]));
+  o[2] = fmaf(a[0], b[1], -(a[1] * b[0]));
+}
+inline void fnormalize(float v[3]) {
+  const float inv = 1.0f / sqrtf(fdot(v, v));
+  v[0] *= inv; v[1] *= inv; v[2] *= inv;
+}
+inline void mul_n(const float N[9], const float v[3], float o[3]) {
+  o[0] = N[0] * v[0] + N[3] * v[1] + N[6] * v[2];
+  o[1] = N[1] * v[0] + N[4] * v[1] + N[7] * v[2];
+  o[2] = N[2] * v[0] + N[5] * v[1] + N[8] * v[2];
+}
+
+inline uint32_t spread10(uint32_t v) {
+  v &= 0x3ffu;
+  v = (v | (v << 16)) & 0x030000FFu;
+  v = (v | (v << 8)) & 0x0300F00Fu;
+  v = (v | (v << 4)) & 0x030C30C3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+inline uint32_t quantize10(float c, float lo, float ext) {
+  float q = ((c - lo) / ext) * 1024.0f;
+  if (!(q > 0.0f)) q = 0.0f;
+  if (q > 1023.0f) q = 1023.0f;
+  return (uint32_t)q;
+}
+
+// ---- binary radix tree over sorted unique 64-bit keys (Karras 2012) ------------------------------
+struct RadixNode { uint32_t lo, hi; int32_t left, right; };  // child >= 0: internal index; < 0: ~leaf position
+
+inline int delta(const std::vector<uint64_t>& k, int64_t i, int64_t j) {
+  if (j < 0 || j >= (int64_t)k.size()) return -1;
+  return __builtin_clzll(k[(size_t)i] ^ k[(size_t)j]);
+}
+
+void build_radix_tree(const std::vector<uint64_t>& k, std::vector<RadixNode>& out) {
+  const int64_t n = (int64_t)k.size();
+  out.resize((size_t)(n - 1));
+  for (int64_t i = 0; i < n - 1; ++i) {   // every internal node is independent (GPU-ready formulation)
+    const int d = delta(k, i, i + 1) - delta(k, i, i - 1) >= 0 ? 1 : -1;
+    const int dmin = delta(k, i, i - d);
+    int64_t lmax = 2;
+    while (delta(k, i, i + lmax * d) > dmin) lmax *= 2;
+    int64_t l = 0;
+    for (int64_t t = lmax / 2; t >= 1; t /= 2)
+      if (delta(k, i, i + (l + t) * d) > dmin) l += t;
+    const int64_t j = i + l * d;
+    const int dnode = delta(k, i, j);
+    int64_t s = 0;
+    for (int64_t t = (l + 1) / 2;; t = (t + 1) / 2) {
+      if (delta(k, i, i + (s + t) * d) > dnode) s += t;
+      if (t == 1) break;
+    }
+    const int64_t gamma = i + s * d + std::min(d, 0);
+    RadixNode r;
+    r.lo = (uint32_t)std::min(i, j);
+    r.hi = (uint32_t)std::max(i, j);
+    r.left = (r.lo == (uint32_t)gamma) ? ~(int32_t)gamma : (int32_t)gamma;
+    r.right = (r.hi == (uint32_t)gamma + 1u) ? ~(int32_t)(gamma + 1) : (int32_t)(gamma + 1);
+    out[(size_t)i] = r;
+  }
+}
+
+struct Box { float lo[3], hi[3]; };
+inline Box empty_box() {
+  Box b;
+  for (int k = 0; k < 3; ++k) { b.lo[k] = std::numeric_limits<float>::infinity(); b.hi[k] = -std::numeric_limits<float>::infinity(); }
+  return b;
+}
+inline void grow(Box& b, const Box& o) {
+  for (int k = 0; k < 3; ++k) { b.lo[k] = o.lo[k] < b.lo[k] ? o.lo[k] : b.lo[k]; b.hi[k] = o.hi[k] > b.hi[k] ? o.hi[k] : b.hi[k]; }
+}
+inline int32_t leaf_code(uint32_t first, uint32_t count) { return (int32_t) ~(first | ((count - 1u) << 28)); }
+
+}  // namespace
+
+// =================================================================================================
+void ptc_make_camera(const float pos[3], const float target[3], float fov, float aspect, DevCamera& cam) {
+  // glm::lookAtRH(pos, target, up = (0,-1,0)): f = normalize(target-pos), s = normalize(f × up), u = s × f
+  float f[3] = {target[0] - pos[0], target[1] - pos[1], target[2] - pos[2]};
+  fnormalize(f);
+  const float up[3] = {0.0f, -1.0f, 0.0f};
+  float s[3], u[3];
+  fcross(f, up, s);
+  fnormalize(s);
+  fcross(s, f, u);
+  for (int k = 0; k < 3; ++k) { cam.pos[k] = pos[k]; cam.f[k] = f[k]; cam.s[k] = s[k]; cam.u[k] = u[k]; }
+  const float th = (float)std::tan((double)fov * 0.5);   // 1/proj[1][1] of glm::perspectiveRH_NO
+  cam.sy = th;
+  cam.sx = aspect * th;
+}
+
+void ptc_owned_pixels(int w, int h, int tile_rank, int tile_count, std::vector<uint32_t>& out) {
+  auto compact = [](uint32_t x) {
+    x &= 0x55555555u; x = (x ^ (x >> 1)) & 0x33333333u; x = (x ^ (x >> 2)) & 0x0f0f0f0fu;
+    x = (x ^ (x >> 4)) & 0x00ff00ffu; x = (x ^ (x >> 8)) & 0x0000ffffu; return x;
+  };
+  const uint32_t tx = (uint32_t)(w + kTile - 1) / kTile, ty = (uint32_t)(h + kTile - 1) / kTile;
+  uint32_t side = 1;
+  while (side < tx || side < ty) side <<= 1;
+  out.clear();
+  uint32_t t = 0;
+  for (uint32_t m = 0; m < side * side; ++m) {       // Morton walk over the tile grid
+    const uint32_t cx = compact(m), cy = compact(m >> 1);
+    if (cx >= tx || cy >= ty) continue;
+    const bool mine = (t % (uint32_t)tile_count) == (uint32_t)tile_rank;
+    ++t;
+    if (!mine) continue;
+    for (uint32_t p = 0; p < (uint32_t)(kTile * kTile); ++p) {   // Morton inside the tile: 64 consecutive = 8×8 block
+      const uint32_t x = cx * kTile + compact(p), y = cy * kTile + compact(p >> 1);
+      if (x < (uint32_t)w && y < (uint32_t)h) out.push_back(y * (uint32_t)w + x);
+    }
+  }
+}
+
+std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::vector<HostMesh>& meshes,
+                            const std::vector<HostInstance>& insts, uint32_t nodelet_budget, HostBuilt& B) {
+  if (insts.empty()) return "scene_commit: no instances";
+  uint64_t nv = 0, nt = 0;
+  for (const auto& in : insts) { nv += meshes[(size_t)in.mesh].v.size(); nt += meshes[(size_t)in.mesh].idx.size() / 3; }
+  if (nt >= (1u << 28)) return "scene_commit: too many triangles";
+  B = HostBuilt();
+  B.wverts.resize(nv);
+  B.widx.resize(nt * 3);
+  B.tri_mat.resize(nt);
+  // ---- flatten ----------------------------------------------------------------------------------
+  uint32_t vb = 0, tb = 0;
+  for (const auto& in : insts) {
+    const HostMesh& m = meshes[(size_t)in.mesh];
+    const Mat34 M = make_model(in.t, in.q, in.s);
+    for (size_t k = 0; k < m.v.size(); ++k) {
+      const HostVertex& s = m.v[k];
+      HostVertex& d = B.wverts[vb + k];
+      for (int r = 0; r < 3; ++r)   // m[0]*x + m[1]*y + m[2]*z + m[3]
+        d.position[r] = M.m[0 + r] * s.position[0] + M.m[4 + r] * s.position[1] + M.m[8 + r] * s.position[2] + M.m[12 + r];
+      mul_n(M.n, s.normal, d.normal);
+      fnormalize(d.normal);
+      mul_n(M.n, s.tangent, d.tangent);
+      fnormalize(d.tangent);
+      d.tangent[3] = s.tangent[3];
+      d.texcoord[0] = s.texcoord[0];
+      d.texcoord[1] = s.texcoord[1];
+    }
+    const size_t ntm = m.idx.size() / 3;
+    for (size_t k = 0; k < ntm; ++k) {
+      for (int c = 0; c < 3; ++c) B.widx[(tb + k) * 3 + c] = vb + m.idx[k * 3 + c];
+      B.tri_mat[tb + k] = m.material;
+    }
+    vb += (uint32_t)m.v.size();
+    tb += (uint32_t)ntm;
+  }
+  const uint32_t n = (uint32_t)nt;
+  B.n_tris = n;
+  // ---- triangle boxes, Morton keys ----------------------------------------------------------------
+  std::vector<Box> tbox(n);
+  Box cb = empty_box(), sb = empty_box();
+  for (uint32_t p = 0; p < n; ++p) {
+    Box b = empty_box();
+    for (int c = 0; c < 3; ++c) {
+      const float* P = B.wverts[B.widx[p * 3 + c]].position;
+      for (int k = 0; k < 3; ++k) { b.lo[k] = P[k] < b.lo[k] ? P[k] : b.lo[k]; b.hi[k] = P[k] > b.hi[k] ? P[k] : b.hi[k]; }
+    }
+    tbox[p] = b;
+    grow(sb, b);
+    Box c1;
+    for (int k = 0; k < 3; ++k) c1.lo[k] = c1.hi[k] = 0.5f * (b.lo[k] + b.hi[k]);
+    grow(cb, c1);
+  }
+  float ext[3];
+  for (int k = 0; k < 3; ++k) { ext[k] = cb.hi[k] - cb.lo[k]; if (!(ext[k] > 1e-30f)) ext[k] = 1e-30f; }
+  float diag = sb.hi[0] - sb.lo[0];
+  if (sb.hi[1] - sb.lo[1] > diag) diag = sb.hi[1] - sb.lo[1];
+  if (sb.hi[2] - sb.lo[2] > diag) diag = sb.hi[2] - sb.lo[2];
+  B.ray_eps = 1e-4f * (diag > 1e-6f ? diag : 1e-6f);
+  std::vector<uint64_t> keys(n);
+  for (uint32_t p = 0; p < n; ++p) {
+    const Box& b = tbox[p];
+    const uint32_t qx = quantize10(0.5f * (b.lo[0] + b.hi[0]), cb.lo[0], ext[0]);
+    const uint32_t qy = quantize10(0.5f * (b.lo[1] + b.hi[1]), cb.lo[1], ext[1]);
+    const uint32_t qz = quantize10(0.5f * (b.lo[2] + b.hi[2]), cb.lo[2], ext[2]);
+    const uint32_t morton = (spread10(qx) << 2) | (spread10(qy) << 1) | spread10(qz);
+    keys[p] = ((uint64_t)morton << 32) | p;
+  }
+  std::sort(keys.begin(), keys.end());
+  // sorted triangle records: (v0, prim id) (e1, class) (e2, 0)
+  B.tris.resize((size_t)n * 12);
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t p = (uint32_t)(keys[i] & 0xffffffffu);
+    const float* a = B.wverts[B.widx[p * 3 + 0]].position;
+    const float* b = B.wverts[B.widx[p * 3 + 1]].position;
+    const float* c = B.wverts[B.widx[p * 3 + 2]].position;
+    float* o = &B.tris[(size_t)i * 12];
+    const HostMaterial& hm = mats[(size_t)B.tri_mat[p]];
+    const uint32_t cls = (hm.metallic == 0.0f && hm.roughness >= 1.0f) ? 0u : 1u;
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; std::memcpy(&o[3], &p, 4);
+    o[4] = b[0] - a[0]; o[5] = b[1] - a[1]; o[6] = b[2] - a[2]; std::memcpy(&o[7], &cls, 4);
+    o[8] = c[0] - a[0]; o[9] = c[1] - a[1]; o[10] = c[2] - a[2]; o[11] = 0.0f;
+  }
+  // ---- hierarchy --------------------------------------------------------------------------------------
+  // Output node = 16 floats: lo0 hi0 lo1 hi1 (12) + c0 c1 pad pad.  Subtrees of <= kLeafMax triangles
+  // collapse into leaves.  Layout: the first `nodelet_budget` nodes in breadth-first order (they are
+  // staged in LDS by the trace kernels), the remainder depth-first under each frontier node.
+  auto range_box = [&](uint32_t lo, uint32_t hi) {
+    Box b = empty_box();
+    for (uint32_t i = lo; i <= hi; ++i) grow(b, tbox[(uint32_t)(keys[i] & 0xffffffffu)]);
+    return b;
+  };
+  struct Child { bool leaf; uint32_t lo, hi; int32_t radix; };
+  std::vector<RadixNode> radix;
+  auto child_of = [&](int32_t link) {
+    Child c;
+    if (link < 0) { c.leaf = true; c.lo = c.hi = (uint32_t)~link; c.radix = -1; return c; }
+    const RadixNode& r = radix[(size_t)link];
+    c.lo = r.lo; c.hi = r.hi; c.radix = link;
+    c.leaf = (r.hi - r.lo + 1u) <= (uint32_t)kLeafMax;
+    return c;
+  };
+  auto put_node = [&](uint32_t idx, const Box& b0, const Box& b1, int32_t c0, int32_t c1) {
+    if (B.nodes.size() < (size_t)(idx + 1) * 16) B.nodes.resize((size_t)(idx + 1) * 16);
+    float* o = &B.nodes[(size_t)idx * 16];
+    o[0] = b0.lo[0]; o[1] = b0.lo[1]; o[2] = b0.lo[2]; o[3] = b0.hi[0]; o[4] = b0.hi[1]; o[5] = b0.hi[2];
+    o[6] = b1.lo[0]; o[7] = b1.lo[1]; o[8] = b1.lo[2]; o[9] = b1.hi[0]; o[10] = b1.hi[1]; o[11] = b1.hi[2];
+    std::memcpy(&o[12], &c0, 4); std::memcpy(&o[13], &c1, 4); o[14] = 0.0f; o[15] = 0.0f;
+  };
+  if (n == 1) {   // both children are the one leaf
+    const Box b = range_box(0, 0);
+    put_node(0, b, b, leaf_code(0, 1), leaf_code(0, 1));
+    B.n_nodes = 1; B.max_depth = 0;
+  } else {
+    build_radix_tree(keys, radix);
+    // pass 1: assign output indices (BFS for the first nodelet_budget, DFS below), remember depth
+    struct Slot { int32_t radix; uint32_t depth; };
+    std::vector<int32_t> out_index(radix.size(), -1);
+    std::vector<Slot> order;   // output index → radix node
+    size_t head = 0;
+    out_index[0] = 0; order.push_back({0, 0});
+    // breadth-first part
+    std::vector<Slot> bfs{{0, 0}};
+    while (head < bfs.size() && order.size() < nodelet_budget) {
+      const Slot s = bfs[head++];
+      const RadixNode& r = radix[(size_t)s.radix];
+      for (int32_t link : {r.left, r.right}) {
+        const Child c = child_of(link);
+        if (c.leaf) continue;
+        if (order.size() >= nodelet_budget) break;
+        out_index[(size_t)c.radix] = (int32_t)order.size();
+        order.push_back({c.radix, s.depth + 1});
+        bfs.push_back({c.radix, s.depth + 1});
+      }
+    }
+    // depth-first part: subtrees hanging below the breadth-first top, numbered in preorder
+    {
+      std::vector<Slot> stack;
+      const size_t n_top = order.size();
+      for (size_t i = 0; i < n_top; ++i) {
+        const Slot top = order[i];
+        const RadixNode& r = radix[(size_t)top.radix];
+        for (int32_t link : {r.left, r.right}) {
+          const Child c = child_of(link);
+          if (c.leaf || out_index[(size_t)c.radix] >= 0) continue;
+          stack.push_back({c.radix, top.depth + 1});
+          while (!stack.empty()) {
+            const Slot s = stack.back();
+            stack.pop_back();
+            out_index[(size_t)s.radix] = (int32_t)order.size();
+            order.push_back(s);
+            const RadixNode& rr = radix[(size_t)s.radix];
+            const Child cl = child_of(rr.left), cr = child_of(rr.right);
+            if (!cr.leaf) stack.push_back({cr.radix, s.depth + 1});   // right first: left follows its parent
+            if (!cl.leaf) stack.push_back({cl.radix, s.depth + 1});
+          }
+        }
+      }
+    }
+    // pass 2: emit
+    B.n_nodes = (uint32_t)order.size();
+    B.nodes.assign((size_t)B.n_nodes * 16, 0.0f);
+    uint32_t maxd = 0;
+    for (uint32_t idx = 0; idx < B.n_nodes; ++idx) {
+      const Slot s = order[idx];
+      if (s.depth > maxd) maxd = s.depth;
+      const RadixNode& r = radix[(size_t)s.radix];
+      const Child cl = child_of(r.left), cr = child_of(r.right);
+      const int32_t c0 = cl.leaf ? leaf_code(cl.lo, cl.hi - cl.lo + 1u) : out_index[(size_t)cl.radix];
+      const int32_t c1 = cr.leaf ? leaf_code(cr.lo, cr.hi - cr.lo + 1u) : out_index[(size_t)cr.radix];
+      put_node(idx, range_box(cl.lo, cl.hi), range_box(cr.lo, cr.hi), c0, c1);
+    }
+    B.max_depth = maxd;
+  }
+  B.n_nodelets = B.n_nodes < nodelet_budget ? B.n_nodes : nodelet_budget;
+  // ---- materials --------------------------------------------------------------------------------------
+  B.mats.resize(mats.size() * 12);
+  for (size_t i = 0; i < mats.size(); ++i) {
+    float* o = &B.mats[i * 12];
+    const HostMaterial& m = mats[i];
+    o[0] = m.base[0]; o[1] = m.base[1]; o[2] = m.base[2]; o[3] = m.metallic;
+    o[4] = m.emissive[0]; o[5] = m.emissive[1]; o[6] = m.emissive[2]; o[7] = m.roughness;
+    o[8] = m.base[3]; o[9] = 0.0f; o[10] = 0.0f; o[11] = 0.0f;
+  }
+  // ---- emitters (original primitive order), power pmf / cdf ----------------------------------------------
+  B.prim_light.assign(n, -1);
+  std::vector<float> weight;
+  for (uint32_t p = 0; p < n; ++p) {
+    const HostMaterial& m = mats[(size_t)B.tri_mat[p]];
+    if (!(m.emissive[0] > 0.0f || m.emissive[1] > 0.0f || m.emissive[2] > 0.0f)) continue;
+    const float* a = B.wverts[B.widx[p * 3 + 0]].position;
+    const float* b = B.wverts[B.widx[p * 3 + 1]].position;
+    const float* c = B.wverts[B.widx[p * 3 + 2]].position;
+    const float e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+    float cr[3];
+    fcross(e1, e2, cr);
+    const float len = sqrtf(fdot(cr, cr));
+    const float area = 0.5f * len;
+    const float lum = fmaf(m.emissive[2], 0.0722f, fmaf(m.emissive[1], 0.7152f, m.emissive[0] * 0.2126f));
+    const float wgt = area * lum;
+    if (!(wgt > 0.0f)) continue;
+    const float il = 1.0f / len;
+    B.prim_light[p] = (int32_t)weight.size();
+    weight.push_back(wgt);
+    const float rec[20] = {a[0], a[1], a[2], area, e1[0], e1[1], e1[2], 0.0f /*pmf*/, e2[0], e2[1], e2[2], 0.0f,
+                           cr[0] * il, cr[1] * il, cr[2] * il, 0.0f, m.emissive[0], m.emissive[1], m.emissive[2], 0.0f};
+    B.lights.insert(B.lights.end(), rec, rec + 20);
+  }
+  B.n_lights = (uint32_t)weight.size();
+  float total = 0.0f;
+  for (float wv : weight) total += wv;
+  float run = 0.0f;
+  B.cdf.resize(weight.size());
+  for (size_t i = 0; i < weight.size(); ++i) {
+    run += weight[i];
+    B.cdf[i] = run / total;
+    B.lights[i * 20 + 7] = weight[i] / total;
+  }
+  if (!B.cdf.empty()) B.cdf.back() = 1.0f;
+  if (B.cdf.empty()) B.cdf.push_back(1.0f);
+  if (B.lights.empty()) B.lights.assign(20, 0.0f);
+  return std::string();
+}

@@ -1,0 +1,231 @@
+"""ctypes binding of the C-ABI in include/ptc.h (physically-based-renderer_amd/lib/libptc.so).
+
+`PathTracer` is the drop-in for the reference's render seam: where the reference calls
+`PbrRenderSystem::render(cmd, scene, gBuffer, renderTarget, extent)`
+(src/pbr_engine/engine/pbr/PbrRenderSystem.hpp:46-47, called at src/gltf_viewer/App.cpp:387-388) after
+`gltf::Asset::loadScene` (src/pbr_engine/gltf/pbr/gltf/Asset.hpp:76-78), a caller here does
+`PathTracer(device).load_scene(desc).render(w, h, spp, ...)`.
+
+HIP only.  There is no CPU fallback: if libptc.so is missing or no gfx950 device is usable this
+module raises — loudly — instead of computing anything on the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libptc.so")
+
+DEVICE_NONE = -1  # PTC_DEVICE_NONE: description-only context (host flatten + LBVH; renders nothing)
+INTEGRATOR_PATH = 0
+INTEGRATOR_RASTER_COMPAT = 1
+
+# every symbol include/ptc.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "ptc_create", "ptc_destroy", "ptc_last_error", "ptc_abi_version", "ptc_scene_begin", "ptc_add_material",
+    "ptc_add_texture_rgba8", "ptc_add_mesh", "ptc_add_instance", "ptc_set_camera", "ptc_scene_commit", "ptc_render",
+    "ptc_frame_begin", "ptc_frame_add_samples", "ptc_frame_resolve", "ptc_sync", "ptc_read_radiance_rgba32f",
+    "ptc_radiance_device_ptr", "ptc_write_radiance_rgba32f", "ptc_tonemap_rgba8", "ptc_get_stats",
+    "ptc_debug_trace_closest", "ptc_debug_trace_any", "ptc_debug_get_flat_scene", "ptc_debug_get_bvh",
+]
+
+
+class PtcStats(C.Structure):
+    _fields_ = [
+        ("paths", C.c_uint64), ("segments", C.c_uint64), ("shadow_rays", C.c_uint64), ("hits", C.c_uint64),
+        ("node_visits_closest", C.c_uint64), ("tri_tests_closest", C.c_uint64),
+        ("node_visits_any", C.c_uint64), ("tri_tests_any", C.c_uint64), ("algorithmic_bytes", C.c_uint64),
+        ("seconds_render", C.c_double), ("seconds_trace_closest", C.c_double), ("seconds_trace_any", C.c_double),
+        ("seconds_shade", C.c_double), ("seconds_commit", C.c_double),
+        ("launches_trace_closest", C.c_uint32), ("launches_trace_any", C.c_uint32),
+        ("n_triangles", C.c_uint32), ("n_bvh_nodes", C.c_uint32), ("n_emitters", C.c_uint32), ("bvh_max_depth", C.c_uint32),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class PtcError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library():
+    """Load libptc.so and declare the prototypes.  Raises PtcError when the HIP library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PtcError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, fp = C.c_void_p, C.POINTER(C.c_float)
+    u32p, i32p, u8p = C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+    L.ptc_create.restype = vp
+    L.ptc_create.argtypes = [C.c_int]
+    L.ptc_destroy.argtypes = [vp]
+    L.ptc_destroy.restype = None
+    L.ptc_last_error.restype = C.c_char_p
+    L.ptc_last_error.argtypes = [vp]
+    L.ptc_abi_version.restype = C.c_int
+    L.ptc_scene_begin.argtypes = [vp]
+    L.ptc_add_material.argtypes = [vp, fp, C.c_float, C.c_float, fp, C.c_int, C.c_int, C.c_int]
+    L.ptc_add_texture_rgba8.argtypes = [vp, u8p, C.c_int, C.c_int]
+    L.ptc_add_mesh.argtypes = [vp, vp, C.c_uint32, u32p, C.c_uint32, C.c_int]
+    L.ptc_add_instance.argtypes = [vp, C.c_int, fp, fp, fp]
+    L.ptc_set_camera.argtypes = [vp, fp, fp, C.c_float, C.c_float]
+    L.ptc_scene_commit.argtypes = [vp]
+    L.ptc_render.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int]
+    L.ptc_frame_begin.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.ptc_frame_add_samples.argtypes = [vp, C.c_int]
+    L.ptc_frame_resolve.argtypes = [vp]
+    L.ptc_sync.argtypes = [vp]
+    L.ptc_read_radiance_rgba32f.argtypes = [vp, fp]
+    L.ptc_radiance_device_ptr.argtypes = [vp]
+    L.ptc_radiance_device_ptr.restype = vp
+    L.ptc_write_radiance_rgba32f.argtypes = [vp, fp]
+    L.ptc_tonemap_rgba8.argtypes = [vp, u8p]
+    L.ptc_get_stats.argtypes = [vp, C.POINTER(PtcStats)]
+    L.ptc_debug_trace_closest.argtypes = [vp, fp, fp, C.c_uint32, fp, i32p, fp]
+    L.ptc_debug_trace_any.argtypes = [vp, fp, fp, fp, C.c_uint32, u8p]
+    L.ptc_debug_get_flat_scene.argtypes = [vp, u32p, u32p, vp, u32p, i32p]
+    L.ptc_debug_get_bvh.argtypes = [vp, u32p, u32p, fp, fp]
+    _lib = L
+    return L
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, np.float32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class PathTracer:
+    def __init__(self, device: int = 0):
+        self._L = load_library()
+        self._h = self._L.ptc_create(int(device))
+        if not self._h:
+            raise PtcError(self._L.ptc_last_error(None).decode())
+        self.device = int(device)
+        self._w = self._h_px = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ptc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc < 0:
+            raise PtcError(f"ptc error {rc}: {self._L.ptc_last_error(self._h).decode()}")
+        return rc
+
+    # ---- scene ------------------------------------------------------------------------------------
+    def load_scene(self, desc):
+        L, h = self._L, self._h
+        self._ck(L.ptc_scene_begin(h))
+        for m in desc.materials:
+            self._ck(L.ptc_add_material(h, _f(m.base_color)[1], m.metallic, m.roughness, _f(m.emissive)[1], m.tex_color, m.tex_normal, m.tex_mr))
+        for me in desc.meshes:
+            v = np.ascontiguousarray(me.vertices)
+            i = np.ascontiguousarray(me.indices, np.uint32)
+            self._ck(L.ptc_add_mesh(h, v.ctypes.data, v.size, i.ctypes.data_as(C.POINTER(C.c_uint32)), i.size, me.material))
+        for it in desc.instances:
+            self._ck(L.ptc_add_instance(h, it.mesh, _f(it.t)[1], _f(it.q_wxyz)[1], _f(it.s)[1]))
+        c = desc.camera
+        self._ck(L.ptc_set_camera(h, _f(c.position)[1], _f(c.target)[1], c.fov_y, c.aspect))
+        self._ck(L.ptc_scene_commit(h))
+        return self
+
+    def set_camera(self, position, target, fov_y, aspect):
+        self._ck(self._L.ptc_set_camera(self._h, _f(position)[1], _f(target)[1], fov_y, aspect))
+
+    # ---- rendering --------------------------------------------------------------------------------
+    def render(self, w, h, spp, seed=1, max_bounces=8, integrator=INTEGRATOR_PATH):
+        self._ck(self._L.ptc_render(self._h, w, h, spp, seed, max_bounces, integrator))
+        self._w, self._h_px = w, h
+        return self.read_radiance()
+
+    def frame_begin(self, w, h, spp_total, seed=1, max_bounces=8, integrator=INTEGRATOR_PATH, tile_rank=0, tile_count=1):
+        self._ck(self._L.ptc_frame_begin(self._h, w, h, spp_total, seed, max_bounces, integrator, tile_rank, tile_count))
+        self._w, self._h_px = w, h
+
+    def frame_add_samples(self, n):
+        self._ck(self._L.ptc_frame_add_samples(self._h, n))
+
+    def frame_resolve(self):
+        self._ck(self._L.ptc_frame_resolve(self._h))
+
+    def sync(self):
+        self._ck(self._L.ptc_sync(self._h))
+
+    def read_radiance(self):
+        out = np.empty((self._h_px, self._w, 4), np.float32)
+        self._ck(self._L.ptc_read_radiance_rgba32f(self._h, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def write_radiance(self, img):
+        a, p = _f(img)
+        assert a.size == self._w * self._h_px * 4
+        self._ck(self._L.ptc_write_radiance_rgba32f(self._h, p))
+
+    def radiance_device_ptr(self) -> int:
+        return int(self._L.ptc_radiance_device_ptr(self._h) or 0)
+
+    def tonemap(self):
+        out = np.empty((self._h_px, self._w, 4), np.uint8)
+        self._ck(self._L.ptc_tonemap_rgba8(self._h, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    def stats(self):
+        s = PtcStats()
+        self._ck(self._L.ptc_get_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+    # ---- test hooks -------------------------------------------------------------------------------
+    def trace_closest(self, origins, dirs):
+        o, op = _f(origins)
+        d, dp = _f(dirs)
+        n = o.shape[0]
+        t = np.zeros(n, np.float32)
+        prim = np.zeros(n, np.int32)
+        uv = np.zeros((n, 2), np.float32)
+        self._ck(self._L.ptc_debug_trace_closest(self._h, op, dp, n, t.ctypes.data_as(C.POINTER(C.c_float)),
+                                                 prim.ctypes.data_as(C.POINTER(C.c_int32)), uv.ctypes.data_as(C.POINTER(C.c_float))))
+        return t, prim, uv
+
+    def trace_any(self, origins, dirs, tmax):
+        o, op = _f(origins)
+        d, dp = _f(dirs)
+        tm, tp = _f(tmax)
+        n = o.shape[0]
+        occ = np.zeros(n, np.uint8)
+        self._ck(self._L.ptc_debug_trace_any(self._h, op, dp, tp, n, occ.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return occ
+
+    def flat_scene(self):
+        nv, nt = C.c_uint32(), C.c_uint32()
+        self._ck(self._L.ptc_debug_get_flat_scene(self._h, C.byref(nv), C.byref(nt), None, None, None))
+        verts = np.zeros((nv.value, 12), np.float32)
+        idx = np.zeros((nt.value, 3), np.uint32)
+        tm = np.zeros(nt.value, np.int32)
+        self._ck(self._L.ptc_debug_get_flat_scene(self._h, None, None, verts.ctypes.data, idx.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                  tm.ctypes.data_as(C.POINTER(C.c_int32))))
+        return verts, idx, tm
+
+    def bvh(self):
+        nn, nt = C.c_uint32(), C.c_uint32()
+        self._ck(self._L.ptc_debug_get_bvh(self._h, C.byref(nn), C.byref(nt), None, None))
+        nodes = np.zeros((nn.value, 16), np.float32)
+        tris = np.zeros((nt.value, 12), np.float32)
+        self._ck(self._L.ptc_debug_get_bvh(self._h, None, None, nodes.ctypes.data_as(C.POINTER(C.c_float)), tris.ctypes.data_as(C.POINTER(C.c_float))))
+        return nodes, tris
