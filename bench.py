@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py — Mpaths/s of the wavefront path tracer on BASELINE.json's headline configuration.
+
+Workload (config.workload): the Sponza-class procedural atrium (249,936 triangles, SURVEY §8d row 3 —
+the reference's assets are stripped, so the scene is generated) at 1920×1080.  One STEP = one
+wavefront batch of `--spp-per-step` samples of every pixel this rank owns; the default
+64 steps × 16 spp = the 1024 spp of BASELINE.json's metric.  Inputs (scene, BVH, queues) are
+resident in HBM before the timed region.
+
+Contract: W untimed warm-up steps, then exactly K timed steps bracketed by barrier +
+torch.cuda.synchronize() on both sides, MAX over ranks, rank 0 prints ONE JSON line.
+N > 1: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`; one process per
+GPU, 32×32-pixel tiles interleaved over ranks (strong scaling: the frame is fixed), and the single
+collective of the path — the RCCL fp32 sum of the framebuffer onto rank 0 — is inside the timed
+region.
+
+Extra objects on the JSON line:
+  roofline     dominant kernel k_trace_closest: algorithmic bytes (counted node visits × 64 B +
+               triangle tests × 48 B + ray/hit records) ÷ its HIP-event time, against 8 TB/s HBM.
+  cpu_baseline the oracle (scalar C restatement, kind "port") timed on this box's host cores on a
+               bounded sample of the same workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "physically-based-renderer_amd"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--spp-per-step", type=int, default=16)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--max-bounces", type=int, default=8)
+    ap.add_argument("--seed", type=int, default=3)
+    ap.add_argument("--scene-scale", type=float, default=1.0, help="atrium tessellation scale (1.0 = 249,936 triangles)")
+    ap.add_argument("--cpu-spp", type=int, default=2, help="samples per pixel of the bounded CPU-baseline render")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import pbr_amd
+    from pbr_amd import dist as pdist
+    from pbr_amd import scenes
+
+    rank, world, local_rank = pdist.env_rank_world()
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run); got {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the path tracer is HIP-only (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    desc = scenes.atrium(args.scene_scale)
+    desc.camera.aspect = args.width / args.height
+    pt = pbr_amd.PathTracer(local_rank).load_scene(desc)
+    K, W, S = args.steps, args.warmup, args.spp_per_step
+    spp_total = (K + W) * S
+    pt.frame_begin(args.width, args.height, spp_total, args.seed, args.max_bounces, pbr_amd.INTEGRATOR_PATH, tile_rank=rank, tile_count=world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(W):
+        pt.frame_add_samples(S)
+    pt.sync()
+    s0 = pt.stats()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        pt.frame_add_samples(S)
+    pt.frame_resolve()
+    pt.sync()
+    if world > 1:
+        fb = pdist.radiance_tensor(pt, args.width, args.height)
+        pdist.reduce_framebuffer(fb, 0)
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    s1 = pt.stats()
+    dt = t1 - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    d = {k: s1[k] - s0[k] for k in s1 if isinstance(s1[k], (int, float))}
+    # per-rank counters → whole-job sums (strong scaling: ranks own disjoint pixels)
+    keys = ["paths", "segments", "shadow_rays", "hits", "node_visits_closest", "tri_tests_closest", "node_visits_any", "tri_tests_any", "algorithmic_bytes"]
+    tot = {k: float(d[k]) for k in keys}
+    if world > 1:
+        v = torch.tensor([tot[k] for k in keys], dtype=torch.float64, device="cuda")
+        dist.all_reduce(v, op=dist.ReduceOp.SUM)
+        tot = {k: float(x) for k, x in zip(keys, v.tolist())}
+
+    if rank == 0:
+        paths = args.width * args.height * S * K
+        assert abs(tot["paths"] - paths) < 0.5, (tot["paths"], paths)
+        # dominant kernel on this rank: k_trace_closest.  Algorithmic bytes per launch = counted units
+        # × record sizes (DESIGN.md §Algorithmic bytes) ÷ launches; duration = HIP events on the
+        # kernel's own stream, summed by the library, ÷ launches.
+        n_launch = max(1, d["launches_trace_closest"])
+        tc_bytes = d["segments"] * (56 + 16) + d["node_visits_closest"] * 64 + d["tri_tests_closest"] * 48
+        tc_sec = d["seconds_trace_closest"]
+        achieved = tc_bytes / tc_sec / 1e9 if tc_sec > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_trace_closest_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mpaths/s + HBM GB/s (% of peak), 1920x1080x1024 spp glTF scene",
+            "value": paths / dt / 1e6,
+            "unit": "Mpaths/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": dt / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"procedural atrium {desc.n_triangles} tris (BASELINE configs[2]/[3]), {args.width}x{args.height}, {S * K} spp = {K} steps x {S} spp, max_bounces {args.max_bounces}, seed {args.seed}",
+                "paths": paths,
+                "sharding": f"32x32 tiles over {world} rank(s), RCCL reduce to rank 0" if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_trace_closest",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "bytes_per_launch": tc_bytes / n_launch,
+                "avg_launch_ms": tc_sec / n_launch * 1e3,
+                "launches": n_launch,
+            },
+            "whole_path_algorithmic_GBs": tot["algorithmic_bytes"] / dt / 1e9,
+            "seconds": {"wall": dt, "trace_closest": d["seconds_trace_closest"], "trace_any": d["seconds_trace_any"], "shade": d["seconds_shade"]},
+            "per_path": {"segments": tot["segments"] / paths, "shadow_rays": tot["shadow_rays"] / paths,
+                         "node_visits": (tot["node_visits_closest"] + tot["node_visits_any"]) / paths,
+                         "algorithmic_bytes": tot["algorithmic_bytes"] / paths},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import ora  # the checker, timed as the CPU baseline; never on the product path
+
+            o = ora.Oracle().load_scene(desc)
+            cores = ora.hw_threads()
+            tc0 = time.perf_counter()
+            o.render(args.width, args.height, args.cpu_spp, args.seed, args.max_bounces, 0, 0, 1, cores)
+            tc = time.perf_counter() - tc0
+            out["cpu_baseline"] = {
+                "value": args.width * args.height * args.cpu_spp / tc / 1e6,
+                "unit": "Mpaths/s",
+                "cores": cores,
+                "kind": "port",
+                "sample": f"same scene and camera, {args.width}x{args.height} x {args.cpu_spp} spp ({tc:.1f} s of CPU work), oracle/ptc_oracle.c -O2 -ffp-contract=off, pthreads over rows",
+            }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures FROM THE ORACLE (oracle/ptc_oracle.c).
+
+PARITY UNPINNED against the reference: it holds no path tracer, no CPU render path and no numerical
+fixture for any of this, and it cannot be built or run here.  These vectors pin the
+oracle against itself over time (a change of the specification shows up as a fixture diff) and are the
+common yard-stick the HIP path is held to on the GPU box.
+
+  cornell_256x256x64_seed1.npy     config 1 golden: RGBA32F radiance, 1 MiB          (SURVEY §8c fixture 4)
+  raster_two_tris_sphere_64.npy    raster-compat image, 64×64 RGBA32F                (fixture 3)
+  sphere10k_rays4096.npz           4096 fixed rays → (t, prim, u, v) + any-hit flags (fixture 5)
+  digests.json                     SHA-256 + 32×32 box-downsample of larger configs  (fixture 6)
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "physically-based-renderer_amd"))
+from oracle import ora  # noqa: E402
+from pbr_amd import scenes  # noqa: E402
+
+
+def fixed_rays(desc, n=4096, seed=7):
+    rng = np.random.default_rng(seed)
+    cam = np.asarray(desc.camera.position, np.float32)
+    org = (np.repeat(cam[None, :], n, 0) + rng.normal(0, 0.01, (n, 3))).astype(np.float32)
+    d = rng.normal(0, 1, (n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    tmax = rng.uniform(0.5, 30.0, n).astype(np.float32)
+    return org, d, tmax
+
+
+def box32(img):
+    h, w = img.shape[:2]
+    ys = np.linspace(0, h, 33).astype(int)
+    xs = np.linspace(0, w, 33).astype(int)
+    out = np.zeros((32, 32, 3), np.float64)
+    for j in range(32):
+        for i in range(32):
+            out[j, i] = img[ys[j]:ys[j + 1], xs[i]:xs[i + 1], :3].astype(np.float64).mean(axis=(0, 1))
+    return out.astype(np.float32)
+
+
+DIGEST_CASES = {
+    # name: (scene, kwargs, w, h, spp, seed, max_bounces)
+    "sphere10k_192x192x8_seed2": ("sphere10k", {}, 192, 192, 8, 2, 8),
+    "atrium_small_160x90x4_seed3": ("atrium", {"scale": 0.05}, 160, 90, 4, 3, 8),
+    "atrium_full_240x135x2_seed3": ("atrium", {}, 240, 135, 2, 3, 8),
+}
+
+
+def main():
+    o = ora.Oracle().load_scene(scenes.cornell_box())
+    np.save(os.path.join(HERE, "cornell_256x256x64_seed1.npy"), o.render(256, 256, 64, seed=1, max_bounces=8))
+    o = ora.Oracle().load_scene(scenes.two_triangles_and_sphere())
+    np.save(os.path.join(HERE, "raster_two_tris_sphere_64.npy"), o.render(64, 64, 1, integrator=1))
+    d = scenes.sphere_scene()
+    o = ora.Oracle().load_scene(d)
+    org, dirs, tmax = fixed_rays(d)
+    t, prim, uv = o.trace_closest(org, dirs)
+    occ = o.trace_any(org, dirs, tmax)
+    np.savez_compressed(os.path.join(HERE, "sphere10k_rays4096.npz"), t=t, prim=prim, uv=uv, occ=occ)
+    dig = {}
+    for name, (scene, kw, w, h, spp, seed, mb) in DIGEST_CASES.items():
+        o = ora.Oracle().load_scene(scenes.by_name(scene, **kw))
+        img = o.render(w, h, spp, seed=seed, max_bounces=mb)
+        st = o.stats()
+        dig[name] = {
+            "sha256": hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest(),
+            "box32": [[round(float(x), 6) for x in row] for row in box32(img).reshape(-1, 3)],
+            "stats": {k: int(st[k]) for k in ("paths", "segments", "shadow_rays", "hits", "node_visits_closest", "tri_tests_closest", "node_visits_any", "tri_tests_any")},
+        }
+    json.dump(dig, open(os.path.join(HERE, "digests.json"), "w"), indent=0)
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,71 @@
+"""The C-ABI shared library: loads, exports every symbol include/ptc.h declares, reports errors as
+codes + text, and has no CPU path (no compute call is made here; rendering needs the GPU tests)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(pbr):
+    header = open(os.path.join(ROOT, "include", "ptc.h")).read()
+    declared = sorted(set(re.findall(r"\b(ptc_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 24
+    L = pbr.load_library()
+    for sym in declared:
+        assert hasattr(L, sym), f"libptc.so does not export {sym}"
+    assert sorted(pbr.ptc.ABI_SYMBOLS) == declared
+    assert L.ptc_abi_version() == 1
+    assert C.sizeof(pbr.ptc.PtcStats) == 9 * 8 + 5 * 8 + 6 * 4
+
+
+def test_no_cpu_fallback(pbr):
+    import torch
+
+    L = pbr.load_library()
+    if not torch.cuda.is_available():
+        h = L.ptc_create(0)
+        assert not h, "ptc_create must fail without a GPU"
+        assert b"no HIP device" in L.ptc_last_error(None) or b"hip" in L.ptc_last_error(None).lower()
+        with pytest.raises(pbr.PtcError):
+            pbr.PathTracer(0)
+    pt = pbr.PathTracer(pbr.DEVICE_NONE).load_scene(pbr.scenes.cornell_box())
+    for call in (lambda: pt.render(8, 8, 1), lambda: pt.frame_begin(8, 8, 1), lambda: pt.sync(), lambda: pt.tonemap(),
+                 lambda: pt.trace_closest(np.zeros((1, 3)), np.array([[0, 0, -1.0]]))):
+        with pytest.raises(pbr.PtcError, match="no device|needs a gfx950"):
+            call()
+    assert pt.radiance_device_ptr() == 0
+
+
+def test_argument_errors_are_codes_and_text(pbr):
+    L = pbr.load_library()
+    h = L.ptc_create(pbr.DEVICE_NONE)
+    assert h
+    f4 = (C.c_float * 4)(1, 1, 1, 1)
+    f3 = (C.c_float * 3)(0, 0, 0)
+    assert L.ptc_scene_commit(h) == -2 and b"camera" in L.ptc_last_error(h)            # PTC_E_STATE
+    assert L.ptc_scene_begin(h) == 0
+    assert L.ptc_add_material(h, None, 0.0, 1.0, f3, -1, -1, -1) == -1                   # PTC_E_ARG
+    assert L.ptc_add_material(h, f4, 0.0, 1.0, f3, 0, -1, -1) == -1 and b"texture" in L.ptc_last_error(h)
+    m = L.ptc_add_material(h, f4, 0.0, 1.0, f3, -1, -1, -1)
+    assert m == 0
+    v = np.zeros(3, pbr.scene.MESH_VERTEX)
+    idx = np.array([0, 1, 5], np.uint32)
+    ip = idx.ctypes.data_as(C.POINTER(C.c_uint32))
+    assert L.ptc_add_mesh(h, v.ctypes.data, 3, ip, 3, 0) == -1 and b"index out of range" in L.ptc_last_error(h)
+    assert L.ptc_add_mesh(h, v.ctypes.data, 3, ip, 2, 0) == -1
+    assert L.ptc_add_mesh(h, v.ctypes.data, 3, ip, 3, 7) == -1 and b"material" in L.ptc_last_error(h)
+    idx[2] = 2
+    assert L.ptc_add_mesh(h, v.ctypes.data, 3, ip, 3, 0) == 0
+    assert L.ptc_add_instance(h, 3, f3, f4, f3) == -1
+    assert L.ptc_set_camera(h, f3, None, 1.0, 1.0) == -1
+    assert L.ptc_set_camera(h, f3, (C.c_float * 3)(0, 0, -1), 1.0, 1.0) == 0
+    assert L.ptc_scene_commit(h) == -2 and b"no instances" in L.ptc_last_error(h)
+    assert L.ptc_get_stats(h, None) == -1
+    assert L.ptc_frame_begin(h, 8, 8, 1, 0, 1, 0, 0, 1) == -3                            # PTC_E_DEVICE on a description-only context
+    assert L.ptc_scene_begin(None) == -1
+    L.ptc_destroy(h)
+    L.ptc_destroy(None)

@@ -1,0 +1,240 @@
+"""Parity of the HIP path (through the C-ABI) against the oracle on a real MI355X.
+
+Bar (BASELINE.json north_star): relative L2 <= 1e-4 on the HDR radiance buffer with identical scene +
+seed.  Because both sides follow one arithmetic contract the tests demand more: identical
+bits for hit records, counters, images and RGBA8 output; the 1e-4 bound is asserted as well so that a
+future relaxation of bit-equality still has the contractual gate.
+
+Sizes: oracle-checked cases finish in seconds on the host; BASELINE's full sizes are covered through
+size-independent properties (tile-sharded sum == whole frame, batch split invariance, run-to-run
+determinism, counter identities)."""
+import hashlib
+import json
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from conftest import GOLDEN, rel_l2  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # north_star tolerance on the fp32 radiance buffer
+COUNTERS = ("paths", "segments", "shadow_rays", "hits", "node_visits_closest", "tri_tests_closest", "node_visits_any", "tri_tests_any", "algorithmic_bytes")
+
+
+@pytest.fixture(scope="module")
+def gpu(pbr):
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return pbr
+
+
+def _bits_equal(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+def _pair(gpu, ora, desc):
+    return gpu.PathTracer(0).load_scene(desc), ora.Oracle().load_scene(desc)
+
+
+CASES = [
+    ("cornell", {}, 96, 96, 16, 1, 8),            # config 1 geometry (12 tris, Lambert + emitter)
+    ("sphere10k", {}, 128, 128, 8, 2, 8),         # config 2 geometry (10 k tris, GGX metal, instanced non-uniform scale)
+    ("atrium", {"scale": 0.05}, 160, 90, 4, 3, 8),  # config 3 at reduced tessellation
+    ("atrium", {}, 240, 135, 2, 3, 8),            # config 3 geometry, 249,936 tris
+    ("two_tris_sphere", {}, 64, 64, 2, 5, 3),     # no emitters: NEE disabled, background 0
+]
+
+
+@pytest.mark.parametrize("name,kw,w,h,spp,seed,mb", CASES)
+def test_path_tracer_image_and_counters(gpu, ora, name, kw, w, h, spp, seed, mb):
+    pt, o = _pair(gpu, ora, gpu.scenes.by_name(name, **kw))
+    g = pt.render(w, h, spp, seed=seed, max_bounces=mb)
+    c = o.render(w, h, spp, seed=seed, max_bounces=mb)
+    assert np.isfinite(g).all()
+    assert rel_l2(g, c) <= TOL
+    assert _bits_equal(g, c), f"{int((g != c).any(-1).sum())} pixels differ"
+    sg, so = pt.stats(), o.stats()
+    for k in COUNTERS:                                  # counted, and the two sides must agree exactly
+        assert sg[k] == so[k], k
+    assert sg["seconds_trace_closest"] > 0 and sg["launches_trace_closest"] == mb + 1
+
+
+@pytest.mark.parametrize("name,kw,w,h", [("two_tris_sphere", {}, 64, 64), ("atrium", {"scale": 0.05}, 160, 90), ("sphere10k", {}, 101, 67)])
+def test_raster_compat(gpu, ora, name, kw, w, h):
+    pt, o = _pair(gpu, ora, gpu.scenes.by_name(name, **kw))
+    g = pt.render(w, h, 1, integrator=gpu.INTEGRATOR_RASTER_COMPAT)
+    c = o.render(w, h, 1, integrator=1)
+    assert _bits_equal(g, c)
+    assert pt.stats()["node_visits_closest"] == o.stats()["node_visits_closest"]
+    assert np.array_equal(pt.tonemap(), ora.tonemap_rgba8(c))          # R9, byte-exact
+
+
+@pytest.mark.parametrize("name,kw", [("cornell", {}), ("sphere10k", {}), ("atrium", {})])
+def test_hit_records(gpu, ora, name, kw):
+    from golden.make_golden import fixed_rays
+
+    d = gpu.scenes.by_name(name, **kw)
+    pt, o = _pair(gpu, ora, d)
+    org, dirs, tmax = fixed_rays(d, n=8192 + 37, seed=11)              # ragged: not a multiple of 64
+    t1, p1, uv1 = pt.trace_closest(org, dirs)
+    s1 = pt.stats()
+    t2, p2, uv2 = o.trace_closest(org, dirs)
+    s2 = o.stats()
+    assert _bits_equal(t1, t2) and np.array_equal(p1, p2) and _bits_equal(uv1, uv2)
+    assert (s1["node_visits_closest"], s1["tri_tests_closest"]) == (s2["node_visits_closest"], s2["tri_tests_closest"])
+    assert np.array_equal(pt.trace_any(org, dirs, tmax), o.trace_any(org, dirs, tmax))
+    assert pt.stats()["node_visits_any"] == o.stats()["node_visits_any"]
+
+
+def test_golden_fixtures(gpu):
+    from golden.make_golden import DIGEST_CASES, fixed_rays
+
+    pt = gpu.PathTracer(0).load_scene(gpu.scenes.cornell_box())
+    gold = np.load(os.path.join(GOLDEN, "cornell_256x256x64_seed1.npy"))      # BASELINE config 1 in full
+    img = pt.render(256, 256, 64, seed=1, max_bounces=8)
+    assert rel_l2(img, gold) <= TOL and _bits_equal(img, gold)
+    pt.load_scene(gpu.scenes.two_triangles_and_sphere())
+    assert _bits_equal(pt.render(64, 64, 1, integrator=1), np.load(os.path.join(GOLDEN, "raster_two_tris_sphere_64.npy")))
+    d = gpu.scenes.sphere_scene()
+    pt.load_scene(d)
+    org, dirs, tmax = fixed_rays(d)
+    g = np.load(os.path.join(GOLDEN, "sphere10k_rays4096.npz"))
+    t, prim, uv = pt.trace_closest(org, dirs)
+    assert _bits_equal(t, g["t"]) and np.array_equal(prim, g["prim"]) and _bits_equal(uv, g["uv"])
+    assert np.array_equal(pt.trace_any(org, dirs, tmax), g["occ"])
+    dig = json.load(open(os.path.join(GOLDEN, "digests.json")))
+    for name, (scene, kw, w, h, spp, seed, mb) in DIGEST_CASES.items():
+        pt.load_scene(gpu.scenes.by_name(scene, **kw))
+        img = pt.render(w, h, spp, seed=seed, max_bounces=mb)
+        assert hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest() == dig[name]["sha256"], name
+        st = pt.stats()
+        assert {k: int(st[k]) for k in dig[name]["stats"]} == dig[name]["stats"]
+
+
+def test_tonemap_bytes(gpu, ora):
+    pt = gpu.PathTracer(0).load_scene(gpu.scenes.cornell_box())
+    img = pt.render(64, 48, 4, seed=2)
+    assert np.array_equal(pt.tonemap(), ora.tonemap_rgba8(img))
+    rnd = np.random.default_rng(1).uniform(-0.1, 20.0, (48, 64, 4)).astype(np.float32)   # write → tonemap round trip
+    pt.write_radiance(rnd)
+    assert _bits_equal(pt.read_radiance(), rnd)
+    assert np.array_equal(pt.tonemap(), ora.tonemap_rgba8(rnd))
+
+
+def test_edge_cases(gpu, ora):
+    sc = gpu.scene
+    v, i = gpu.scenes._quad((-1, -1, -3), (1, -1, -3), (1, 1, -3), (-1, 1, -3))
+    cam = sc.CameraDesc((0, 0, 0), (0, 0, -1), math.pi / 2, 1.0)
+    emis = sc.Material((0.5, 0.5, 0.5, 1), 0.0, 1.0, (2.0, 3.0, 4.0))
+    # 1 triangle (single-node BVH), an emitter seen directly, odd sizes, max_bounces 0, 1x1 frame
+    for ntri, w, h, spp, mb in [(1, 33, 17, 2, 0), (2, 1, 1, 3, 2), (2, 65, 31, 1, 1)]:
+        d = sc.SceneDesc([emis], [sc.MeshDesc(v, i[: 3 * ntri], 0)], [sc.InstanceDesc(0, (0, 0, 0), (1, 0, 0, 0), (1, 1, 1))], cam)
+        pt, o = _pair(gpu, ora, d)
+        assert _bits_equal(pt.render(w, h, spp, seed=4, max_bounces=mb), o.render(w, h, spp, seed=4, max_bounces=mb))
+        assert _bits_equal(pt.render(w, h, 1, integrator=1), o.render(w, h, 1, integrator=1))
+    # degenerate (zero-area) triangles and a ray-parallel triangle are never hit, on either side
+    vv = v.copy()
+    vv["position"][2] = vv["position"][1]
+    d = sc.SceneDesc([emis, sc.Material()], [sc.MeshDesc(vv, i, 0), sc.MeshDesc(v, i, 1)],
+                     [sc.InstanceDesc(0, (0, 0, 0.5), (1, 0, 0, 0), (1, 1, 1)), sc.InstanceDesc(1, (0, 0, 0), (1, 0, 0, 0), (1, 1, 1)),
+                      sc.InstanceDesc(1, (0, 0, -1), (math.cos(math.pi / 4), 0, math.sin(math.pi / 4), 0), (1, 1, 1))], cam)
+    pt, o = _pair(gpu, ora, d)
+    g, c = pt.render(40, 40, 4, seed=1, max_bounces=3), o.render(40, 40, 4, seed=1, max_bounces=3)
+    assert np.isfinite(g).all() and _bits_equal(g, c)
+    # API misuse on a live context
+    with pytest.raises(gpu.PtcError):
+        pt.render(0, 8, 1)
+    with pytest.raises(gpu.PtcError):
+        pt.frame_begin(8, 8, 1, tile_rank=2, tile_count=2)
+    with pytest.raises(gpu.PtcError):
+        gpu.PathTracer(0).render(8, 8, 1)                                   # no scene
+
+
+def test_deep_tree_uses_scratch_stack(gpu, ora):
+    """An LBVH deeper than the 32-entry LDS stack (one far triangle per Morton bit + 6000 coincident
+    triangles whose keys differ only in the primitive id: depth 40) must switch the trace kernels to their
+    scratch-stack variant — still bit-exact, path tracer and raster-compat alike."""
+    sc = gpu.scene
+    cents = [(1024.0, 1024.0, 1024.0)]
+    for k in range(10):
+        x = float(2 ** (9 - k))
+        cents += [(x, 0, 0), (0, x, 0), (0, 0, x)]
+    cents += [(0.0, 0.0, 0.0)] * 6000
+    c = np.asarray(cents, np.float64)
+    n, e = len(c), 0.05
+    pos = np.zeros((3 * n, 3), np.float32)
+    pos[0::3], pos[1::3], pos[2::3] = c + (-e, -e, 0), c + (e, -e, 0), c + (0, e, 0)
+    v = np.zeros(3 * n, sc.MESH_VERTEX)
+    v["position"], v["normal"], v["tangent"] = pos, (0, 0, 1), (1, 0, 0, 1)
+    emis = sc.Material((0.6, 0.6, 0.6, 1), 0.0, 1.0, (1.0, 1.0, 1.0))
+    d = sc.SceneDesc([emis], [sc.MeshDesc(v, np.arange(3 * n, dtype=np.uint32), 0)], [sc.InstanceDesc(0, (0, 0, 0), (1, 0, 0, 0), (1, 1, 1))],
+                     sc.CameraDesc((0.0, 0.0, 3.0), (0, 0, 0), 0.2, 1.0))
+    pt, o = _pair(gpu, ora, d)
+    assert pt.stats()["bvh_max_depth"] + 1 > 32
+    for integ, spp in ((1, 1), (0, 2)):
+        g, c2 = pt.render(64, 64, spp, seed=2, max_bounces=2, integrator=integ), o.render(64, 64, spp, seed=2, max_bounces=2, integrator=integ)
+        assert _bits_equal(g, c2)
+        assert pt.stats()["node_visits_closest"] == o.stats()["node_visits_closest"] and pt.stats()["node_visits_any"] == o.stats()["node_visits_any"]
+
+
+def test_sharding_and_batching_do_not_change_bits(gpu):
+    """tile-sharded partial frames sum to the undivided frame bit for bit; splitting the
+    samples into different wavefront batches (and a smaller queue) changes nothing either."""
+    pt = gpu.PathTracer(0).load_scene(gpu.scenes.atrium(0.05))
+    w, h, spp = 200, 120, 6
+    full = pt.render(w, h, spp, seed=7)
+    acc = np.zeros_like(full)
+    for n in (2, 3):
+        acc[:] = 0
+        for r in range(n):
+            pt.frame_begin(w, h, spp, 7, 8, 0, tile_rank=r, tile_count=n)
+            pt.frame_add_samples(spp)
+            pt.frame_resolve()
+            part = pt.read_radiance()
+            assert (part[~gpu.dist.owned_mask(w, h, r, n)] == 0).all()
+            acc += part
+        assert _bits_equal(acc, full)
+    for split in ([1, 2, 3], [5, 1], [2, 2, 2]):
+        pt.frame_begin(w, h, spp, 7, 8, 0)
+        for k in split:
+            pt.frame_add_samples(k)
+        pt.frame_resolve()
+        assert _bits_equal(pt.read_radiance(), full)
+    os.environ["PTC_BATCH_PATHS"] = "30000"                                       # forces ~5 internal batches of 1 spp
+    try:
+        small = gpu.PathTracer(0).load_scene(gpu.scenes.atrium(0.05))
+        assert _bits_equal(small.render(w, h, spp, seed=7), full)
+    finally:
+        del os.environ["PTC_BATCH_PATHS"]
+
+
+def test_full_size_properties(gpu):
+    """BASELINE's full size (1920x1080, 249,936 triangles) at 2 spp: determinism, counter identities,
+    tile-shard sum == whole frame, radiance-buffer device pointer usable by torch (the RCCL reduce's input)."""
+    import torch
+
+    pt = gpu.PathTracer(0).load_scene(gpu.scenes.atrium())
+    w, h, spp = 1920, 1080, 2
+    a = pt.render(w, h, spp, seed=3)
+    sa = pt.stats()
+    assert np.isfinite(a).all() and (a[..., 3] == 1).all() and a[..., :3].min() >= 0
+    assert sa["paths"] == w * h * spp and sa["hits"] <= sa["segments"] and sa["shadow_rays"] <= sa["hits"]
+    assert sa["segments"] >= sa["paths"] and sa["node_visits_closest"] >= sa["segments"]
+    t = gpu.dist.radiance_tensor(pt, w, h)
+    assert t.is_cuda and np.array_equal(t.cpu().numpy(), a)
+    b = pt.render(w, h, spp, seed=3)
+    assert _bits_equal(a, b) and all(pt.stats()[k] == sa[k] for k in COUNTERS)    # scheduling-independent
+    acc = torch.zeros_like(t)
+    for r in range(4):
+        pt.frame_begin(w, h, spp, 3, 8, 0, tile_rank=r, tile_count=4)
+        pt.frame_add_samples(spp)
+        pt.frame_resolve()
+        pt.sync()
+        acc += gpu.dist.radiance_tensor(pt, w, h)
+    assert np.array_equal(acc.cpu().numpy(), a)

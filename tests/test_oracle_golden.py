@@ -1,0 +1,124 @@
+"""The oracle against the committed golden fixtures (tests/golden/make_golden.py generated them from the
+oracle itself — "parity unpinned" against the reference, which holds no fixture for this path)
+plus size-independent properties of the oracle."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from conftest import GOLDEN, rel_l2
+
+
+def test_cornell_golden_bit_exact(ora, pbr):
+    gold = np.load(os.path.join(GOLDEN, "cornell_256x256x64_seed1.npy"))
+    img = ora.Oracle().load_scene(pbr.scenes.cornell_box()).render(256, 256, 64, seed=1, max_bounces=8)
+    assert np.array_equal(img.view(np.uint32), gold.view(np.uint32))
+    # physical sanity of the golden itself: light visible, red/green walls on the expected (mirrored) sides
+    assert gold[..., 3].min() == 1.0 and np.isfinite(gold).all()
+    assert gold[30:38, 108:148, :3].mean() > 14.0                       # emitter (radiance 15) seen directly
+    left, right = gold[128, 10, :3], gold[128, 245, :3]
+    assert left[1] > left[0] and right[0] > right[1]                   # reference camera mirrors x: green left, red right
+
+
+def test_raster_compat_golden(ora, pbr):
+    gold = np.load(os.path.join(GOLDEN, "raster_two_tris_sphere_64.npy"))
+    img = ora.Oracle().load_scene(pbr.scenes.two_triangles_and_sphere()).render(64, 64, 1, integrator=1)
+    assert np.array_equal(img.view(np.uint32), gold.view(np.uint32))
+    assert (gold[0, 0] == 0).all()                                     # background: G-buffer clear → 0
+    # centre pixel: sphere (material 1, base alpha 0.5): alpha = 0.5*NdotV + spec, colour = base*NdotV + spec
+    c = gold[32, 32]
+    assert c[2] > c[0] and 0.0 < c[3] <= 1.5
+
+
+def test_hit_records_golden(ora, pbr):
+    from golden.make_golden import fixed_rays
+
+    d = pbr.scenes.sphere_scene()
+    o = ora.Oracle().load_scene(d)
+    org, dirs, tmax = fixed_rays(d)
+    g = np.load(os.path.join(GOLDEN, "sphere10k_rays4096.npz"))
+    t, prim, uv = o.trace_closest(org, dirs)
+    assert np.array_equal(t.view(np.uint32), g["t"].view(np.uint32)) and np.array_equal(prim, g["prim"])
+    assert np.array_equal(uv.view(np.uint32), g["uv"].view(np.uint32))
+    assert np.array_equal(o.trace_any(org, dirs, tmax), g["occ"])
+    # brute force over all triangles agrees with the BVH answer (closest t, lowest prim id on ties)
+    verts, idx, _ = o.flat_scene()
+    P = verts[:, :3].astype(np.float64)
+    a, b, c = P[idx[:, 0]], P[idx[:, 1]], P[idx[:, 2]]
+    for k in range(0, 4096, 97):
+        oo, dd = org[k].astype(np.float64), dirs[k].astype(np.float64)
+        e1, e2 = b - a, c - a
+        pv = np.cross(dd, e2)
+        det = (e1 * pv).sum(1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            inv = 1.0 / det
+            tv = oo - a
+            u = (tv * pv).sum(1) * inv
+            qv = np.cross(tv, e1)
+            v = (qv * dd).sum(1) * inv
+            tt = (e2 * qv).sum(1) * inv
+        ok = (det != 0) & (u >= 0) & (u <= 1) & (v >= 0) & (u + v <= 1) & (tt > 0)
+        if not ok.any():
+            assert prim[k] == -1
+        else:
+            tmin = tt[ok].min()
+            assert prim[k] >= 0 and abs(t[k] - tmin) <= 1e-4 * max(1.0, tmin)
+
+
+def test_digests(ora, pbr):
+    from golden.make_golden import DIGEST_CASES, box32
+
+    dig = json.load(open(os.path.join(GOLDEN, "digests.json")))
+    for name, (scene, kw, w, h, spp, seed, mb) in DIGEST_CASES.items():
+        o = ora.Oracle().load_scene(pbr.scenes.by_name(scene, **kw))
+        img = o.render(w, h, spp, seed=seed, max_bounces=mb)
+        assert hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest() == dig[name]["sha256"], name
+        st = o.stats()
+        assert {k: int(st[k]) for k in dig[name]["stats"]} == dig[name]["stats"]
+        assert np.allclose(box32(img).reshape(-1, 3), np.asarray(dig[name]["box32"], np.float32), rtol=1e-5, atol=1e-6)
+
+
+def test_threads_and_tiles_do_not_change_bits(ora, pbr):
+    d = pbr.scenes.sphere_scene(24, 13)
+    o = ora.Oracle().load_scene(d)
+    full = o.render(75, 50, 3, seed=5, max_bounces=4, n_threads=1)
+    assert np.array_equal(full, o.render(75, 50, 3, seed=5, max_bounces=4, n_threads=7))
+    parts = [o.render(75, 50, 3, seed=5, max_bounces=4, tile_rank=r, tile_count=3) for r in range(3)]
+    assert np.array_equal(parts[0] + parts[1] + parts[2], full)
+    for r in range(3):
+        m = pbr.dist.owned_mask(75, 50, r, 3)
+        assert (parts[r][~m] == 0).all()
+
+
+def test_seed_and_sample_count_matter(ora, pbr):
+    o = ora.Oracle().load_scene(pbr.scenes.cornell_box())
+    a = o.render(32, 32, 4, seed=1)
+    assert not np.array_equal(a, o.render(32, 32, 4, seed=2))
+    assert np.array_equal(a, o.render(32, 32, 4, seed=1))
+    # more samples converge: 256 spp is closer to 1024 spp than 16 spp is
+    ref = o.render(24, 24, 1024, seed=9)
+    assert rel_l2(o.render(24, 24, 256, seed=4), ref) < rel_l2(o.render(24, 24, 16, seed=4), ref)
+
+
+def test_energy_furnace(ora, pbr):
+    """White-furnace style check of the estimator: a closed Lambert box of albedo ρ lit by an emitter
+    converges to L = Le·(emitted-flux share) / (1-ρ) in the mean; here only the weaker, robust statement
+    is asserted: max_bounces=0 shows emission only, and radiance grows monotonically with bounce depth."""
+    o = ora.Oracle().load_scene(pbr.scenes.cornell_box())
+    means = [float(o.render(32, 32, 64, seed=1, max_bounces=b)[..., :3].mean()) for b in (0, 1, 2, 4, 8)]
+    assert means[0] > 0 and all(m2 >= m1 for m1, m2 in zip(means, means[1:]))
+    assert means[-1] < 3.0 * means[1]
+
+
+def test_oracle_argument_errors(ora, pbr):
+    o = ora.Oracle()
+    with pytest.raises(RuntimeError):
+        o.render(8, 8, 1)                                      # not committed
+    o.load_scene(pbr.scenes.cornell_box())
+    for bad in [dict(w=0, h=8, spp=1), dict(w=8, h=8, spp=0), dict(w=8, h=8, spp=1, integrator=7), dict(w=8, h=8, spp=1, tile_rank=2, tile_count=2)]:
+        with pytest.raises(RuntimeError):
+            o.render(**bad)
