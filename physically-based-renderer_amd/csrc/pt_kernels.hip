@@ -1,31 +1,33 @@
 // pt_kernels.hip — the wavefront path tracer's kernels for gfx950 (wave64).
 //
-// Stages:  P1 k_raygen · P3 k_trace_closest · P9 per-wave class sort (epilogue of
-// k_trace_closest) · P5–P8 k_shade · P4 k_trace_any · P10 k_accumulate / k_resolve · R8 k_shade_raster
-// · R9 k_tonemap.  All queue traffic is SoA of 16-byte lanes (one dwordx4 per lane, 1 KiB per
-// wave-instruction); compaction is ballot + mbcnt prefix + ONE atomic per wave and class; no float
-// atomics anywhere (every per-path / per-pixel word has a single owner), so results do not depend on
-// scheduling.  MFMA is unused: there is no dense contraction on this path.
+// Stages:  P1 k_raygen · P3 k_trace_closest · P9 material sort + compaction (front and
+// back end of k_shade) · P5–P8 k_shade · P4 k_trace_any · P10 k_accumulate / k_resolve ·
+// R8 k_shade_raster · R9 k_tonemap.
+//
+// Design rules that came out of the first profile (profiles/r01_v1_*):
+//  * a single device word takes ≈88 atomics/µs, so NOTHING does one atomic per wave-iteration: trace
+//    waves pull 512-ray chunks (one atomic per chunk) and refill idle lanes from their private chunk;
+//    the shade kernel sorts and compacts per 512-thread block through LDS and does ONE atomic per
+//    block and output queue;
+//  * traversal is latency-bound with poor lane utilisation when a wave waits for its slowest ray, so
+//    finished lanes are refilled in place (persistent while-while with dynamic fetch);
+//  * every queue access is a 16-byte lane (dwordx4); no float atomics anywhere — each per-path /
+//    per-pixel word has one owner, so results do not depend on scheduling.  MFMA is unused: there is
+//    no dense contraction on this path.
 #include "pt_device.h"
 #include "ptc_internal.h"
 
 #define TRACE_BLOCK 256
 #define TRACE_WAVES (TRACE_BLOCK / 64)
-#define LDS_STACK_DEPTH 32
+#define TRACE_CHUNK 512u          // rays per work-fetch atomic
+#define TRACE_REFILL_IDLE 16      // refill as soon as this many lanes are idle
 #define SCRATCH_STACK_DEPTH 64
+#define SHADE_BLOCK 512
+#define SHADE_WAVES (SHADE_BLOCK / 64)
 #define CUR_DONE ((int)0x80000000)
+#define HIT_CLASS_SHIFT 28
 
 // ---- small helpers --------------------------------------------------------------------------------
-PT_DEV float4 ld4(const float4* p) { return *p; }
-
-// One wave-wide allocation of popc(mask) consecutive slots; lanes in `mask` get base+rank.
-PT_DEV uint32_t wave_alloc(uint32_t* ctr, uint64_t mask, uint32_t lane) {
-  uint32_t base = 0;
-  const int leader = __ffsll((unsigned long long)mask) - 1;
-  if ((int)lane == leader) base = atomicAdd(ctr, (uint32_t)__popcll(mask));
-  base = __shfl((int)base, leader);
-  return base + mbcnt64(mask);
-}
 PT_DEV uint32_t wave_fetch(uint32_t* ctr, uint32_t amount, uint32_t lane) {
   uint32_t base = 0;
   if (lane == 0) base = atomicAdd(ctr, amount);
@@ -44,7 +46,7 @@ __global__ void k_set_counts(uint32_t* cnt, uint32_t n_rays, uint32_t n_shadow) 
 __global__ void k_advance(uint32_t* cnt) {
   if (threadIdx.x == 0) {
     const uint32_t next = cnt[CNT_NEXT];
-    cnt[CNT_RAYS] = next; cnt[CNT_SORT0] = 0; cnt[CNT_SORT1] = 0; cnt[CNT_NEXT] = 0; cnt[CNT_SHADOW] = 0;
+    cnt[CNT_RAYS] = next; cnt[CNT_NEXT] = 0; cnt[CNT_SHADOW] = 0;
     cnt[CNT_WORK_TRACE] = 0; cnt[CNT_WORK_SHADE] = 0; cnt[CNT_WORK_SHADOW] = 0;
   }
 }
@@ -74,39 +76,29 @@ __global__ __launch_bounds__(256) void k_raygen(DevCamera cam, DevFrame fr, DevQ
     const float dnear = (2.0f * PT_ZFAR * PT_ZNEAR) / (PT_ZFAR + PT_ZNEAR);
     bz = dnear * len; bw = PT_ZFAR * len;
   }
-  q.ray.A[p] = make_float4(cam.pos[0], cam.pos[1], cam.pos[2], d.x);
-  q.ray.B[p] = make_float4(d.y, d.z, bz, bw);
-  q.ray.C[p] = make_float4(1.0f, 0.0f, __uint_as_float(p), __uint_as_float(key));
-  q.ray.D[p] = 0u;
+  const RayQ& r = q.ray[0];
+  r.A[p] = make_float4(cam.pos[0], cam.pos[1], cam.pos[2], d.x);
+  r.B[p] = make_float4(d.y, d.z, bz, bw);
+  r.C[p] = make_float4(1.0f, 0.0f, __uint_as_float(p), __uint_as_float(key));
+  r.D[p] = 0u;
   q.lpath[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
 // =================================================================================================
-// P3 closest-hit traversal + triangle intersection, persistent waves.
-//
-// Each wave pulls 64 consecutive rays with one atomic, every lane walks the 64-byte-node LBVH with
-// its own stack (LDS, stride 64 dwords: bank = lane for every depth, so no conflicts; or scratch when
-// the tree is deeper than the LDS stack), near child first, ties to child 0.  Closest hit is the
-// lexicographic minimum of (t, original primitive id).  The first `n_nodelets` nodes (breadth-first
-// top of the tree) are read from an LDS copy ("nodelets") instead of L1/L2.
-// MODE 0: epilogue sorts surviving paths by material class into the two-ended queue (P9).
-// MODE 1: epilogue writes (t, prim, u, v) in place (debug / raster).  CULL: R6 back-face culling +
-//         per-ray [tmin,tmax] from B.zw.
-struct TravStack {
-  int* lds;           // &stack[wave][0][lane]
-};
-
+// traversal machinery shared by the closest-hit and any-hit kernels
 template <bool LDS_STACK> struct Stack;
-template <> struct Stack<true> {
+template <> struct Stack<true> {    // per-lane stack in LDS, stride 64 dwords: bank = lane at every depth
   int* base; int sp;
   PT_DEV void init(int* lds_base) { base = lds_base; sp = 0; }
+  PT_DEV void reset() { sp = 0; }
   PT_DEV void push(int v) { base[sp * 64] = v; ++sp; }
   PT_DEV int pop() { --sp; return base[sp * 64]; }
   PT_DEV bool empty() const { return sp == 0; }
 };
-template <> struct Stack<false> {
+template <> struct Stack<false> {   // deep trees: private (scratch) stack
   int st[SCRATCH_STACK_DEPTH]; int sp;
   PT_DEV void init(int*) { sp = 0; }
+  PT_DEV void reset() { sp = 0; }
   PT_DEV void push(int v) { st[sp] = v; ++sp; }
   PT_DEV int pop() { --sp; return st[sp]; }
   PT_DEV bool empty() const { return sp == 0; }
@@ -127,37 +119,74 @@ PT_DEV Node16 load_node(const DevScene& sc, const float4* lds_nodes, int cur) {
   return n;
 }
 
-template <int MODE, bool CULL, bool LDS_STACK, bool NODELETS>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DevScene sc, DevQueues q) {
+// Wave-private reservoir of input slots: one atomic fetches TRACE_CHUNK consecutive rays, idle lanes are
+// refilled from it (ballot + mbcnt).  Returns, per lane, whether it received slot `ri`.
+struct Reservoir {
+  uint32_t next, end; bool exhausted;
+  PT_DEV void init() { next = 0; end = 0; exhausted = false; }
+  PT_DEV bool refill(uint32_t* ctr, uint32_t n, bool idle, uint32_t lane, uint32_t& ri) {
+    const uint64_t mi = __ballot(idle);
+    if (!mi) return false;
+    if (next >= end && !exhausted) {
+      const uint32_t base = wave_fetch(ctr, TRACE_CHUNK, lane);
+      if (base >= n) exhausted = true;
+      else { next = base; end = (base + TRACE_CHUNK < n) ? base + TRACE_CHUNK : n; }
+    }
+    const uint32_t avail = end - next;
+    if (avail == 0) return false;
+    const uint32_t rank = mbcnt64(mi), need = (uint32_t)__popcll(mi);
+    const bool take = idle && rank < avail;
+    if (take) ri = next + rank;
+    next += need < avail ? need : avail;
+    return take;
+  }
+};
+
+// =================================================================================================
+// P3 closest-hit traversal + triangle intersection: persistent waves, dynamic lane refill.
+// Near child first, ties to child 0; closest hit = lexicographic minimum of (t, original primitive id).
+// The hit record (t, prim | class<<28, u, v) is written IN PLACE at the ray's slot (miss: prim = -1).
+// CULL: R6 back-face culling + per-ray [tmin,tmax] from B.zw (raster-compat primary rays).
+template <bool CULL, bool LDS_STACK, bool NODELETS>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DevScene sc, DevQueues q, int qi, uint32_t stack_depth) {
   extern __shared__ float4 lds_raw[];
-  // LDS carve: [nodelets: n_nodelets × 64 B][stacks: TRACE_WAVES × DEPTH × 64 × 4 B]
-  float4* lds_nodes = lds_raw;
-  int* lds_stack = reinterpret_cast<int*>(lds_raw + (NODELETS ? (size_t)sc.n_nodelets * 4 : 0));
+  float4* lds_nodes = lds_raw;                                       // [n_nodelets × 64 B]
+  int* lds_stack = reinterpret_cast<int*>(lds_raw + (NODELETS ? (size_t)sc.n_nodelets * 4 : 0));   // [waves][depth][64]
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
   if (NODELETS) {
     for (uint32_t i = threadIdx.x; i < sc.n_nodelets * 4u; i += TRACE_BLOCK) lds_nodes[i] = sc.nodes[i];
     __syncthreads();
   }
+  const RayQ rq = q.ray[qi];
   const uint32_t n = q.cnt[CNT_RAYS];
-  unsigned long long c_nodes = 0, c_tris = 0, c_rays = 0, c_hits = 0;
+  uint32_t nv = 0, nt = 0, nr = 0, nh = 0;
+  Reservoir res; res.init();
+  Stack<LDS_STACK> st;
+  st.init(lds_stack + wave * (stack_depth * 64u) + lane);
+  int cur = CUR_DONE;
+  uint32_t ri = 0;
+  ray_t r = make_ray(V3(0, 0, 0), V3(0, 0, 1));
+  float tmin = 0.0f, best_t = PT_T_INF, best_u = 0.0f, best_v = 0.0f;
+  int best_prim = 0x7fffffff, best_cls = 0;
+  bool found = false;
   for (;;) {
-    const uint32_t base = wave_fetch(&q.cnt[CNT_WORK_TRACE], 64u, lane);
-    if (base >= n) break;
-    const uint32_t i = base + lane;
-    const bool active = i < n;
-    float4 A = make_float4(0, 0, 0, 0), Bq = make_float4(0, 0, 0, 0);
-    if (active) { A = q.ray.A[i]; Bq = q.ray.B[i]; }
-    const ray_t r = make_ray(V3(A.x, A.y, A.z), V3(A.w, Bq.x, Bq.y));
-    const float tmin = CULL ? Bq.z : 0.0f;
-    float best_t = CULL ? Bq.w : PT_T_INF, best_u = 0.0f, best_v = 0.0f;
-    int best_prim = 0x7fffffff, best_cls = 0;
-    bool found = false;
-    uint32_t nv = 0, nt = 0;
-    Stack<LDS_STACK> st;
-    st.init(lds_stack + wave * (LDS_STACK_DEPTH * 64) + lane);
-    int cur = active ? 0 : CUR_DONE;
-    while (cur != CUR_DONE) {
+    // ---- refill idle lanes from the wave's reservoir ----
+    if (res.refill(&q.cnt[CNT_WORK_TRACE], n, cur == CUR_DONE, lane, ri)) {
+      const float4 A = rq.A[ri], Bq = rq.B[ri];
+      r = make_ray(V3(A.x, A.y, A.z), V3(A.w, Bq.x, Bq.y));
+      tmin = CULL ? Bq.z : 0.0f;
+      best_t = CULL ? Bq.w : PT_T_INF; best_u = 0.0f; best_v = 0.0f; best_prim = 0x7fffffff; best_cls = 0; found = false;
+      st.reset();
+      cur = 0;
+      ++nr;
+    }
+    if (!__ballot(cur != CUR_DONE)) {
+      if (res.exhausted) break;
+      continue;
+    }
+    // ---- traverse until enough lanes have finished to make a refill worthwhile ----
+    do {
       while (cur >= 0) {
         const Node16 nd = load_node<NODELETS>(sc, lds_nodes, cur);
         ++nv;
@@ -172,9 +201,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DevScene sc, DevQ
           cur = first;
         } else if (h0) cur = c0;
         else if (h1) cur = c1;
-        else cur = st.empty() ? CUR_DONE : st.pop();
+        else cur = st.empty() ? CUR_DONE + 1 : st.pop();
       }
-      if (cur != CUR_DONE) {
+      if (cur > CUR_DONE + 1) {                                        // a leaf
         const uint32_t code = (uint32_t)~cur;
         const uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
         for (uint32_t k = first; k < first + count; ++k) {
@@ -187,30 +216,16 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DevScene sc, DevQ
             best_t = t; best_u = u; best_v = v; best_prim = pid; best_cls = __float_as_int(b.w); found = true;
           }
         }
-        cur = st.empty() ? CUR_DONE : st.pop();
+        cur = st.empty() ? CUR_DONE + 1 : st.pop();
       }
-    }
-    c_nodes += nv; c_tris += nt; c_rays += active ? 1u : 0u; c_hits += found ? 1u : 0u;
-    // ---- epilogue ------------------------------------------------------------------------------
-    if (MODE == 1) {
-      if (active) q.hit[i] = make_float4(found ? best_t : -1.0f, __int_as_float(found ? best_prim : -1), best_u, best_v);
-    } else {
-      // P9: per-wave material-class sort.  Class 0 (Lambert) grows up from slot 0, class 1 (GGX) grows
-      // down from slot cap-1; misses leave the wavefront here (background radiance is 0).
-      float4 Cq = make_float4(0, 0, 0, 0); uint32_t Dq = 0;
-      if (found) { Cq = q.ray.C[i]; Dq = q.ray.D[i]; }
-      const uint64_t m0 = __ballot(found && best_cls == 0);
-      const uint64_t m1 = __ballot(found && best_cls != 0);
-      uint32_t pos = 0;
-      if (m0) { const uint32_t s = wave_alloc(&q.cnt[CNT_SORT0], m0, lane); if (found && best_cls == 0) pos = s; }
-      if (m1) { const uint32_t s = wave_alloc(&q.cnt[CNT_SORT1], m1, lane); if (found && best_cls != 0) pos = q.cap - 1u - s; }
-      if (found) {
-        q.sorted.A[pos] = A; q.sorted.B[pos] = Bq; q.sorted.C[pos] = Cq; q.sorted.D[pos] = Dq;
-        q.sorted.H[pos] = make_float4(best_t, __int_as_float(best_prim), best_u, best_v);
+      if (cur == CUR_DONE + 1) {                                       // this lane's ray is finished: publish in place
+        q.hit[ri] = make_float4(found ? best_t : -1.0f, __int_as_float(found ? (best_prim | (best_cls << HIT_CLASS_SHIFT)) : -1), best_u, best_v);
+        nh += found ? 1u : 0u;
+        cur = CUR_DONE;
       }
-    }
+    } while (__popcll(__ballot(cur == CUR_DONE)) < TRACE_REFILL_IDLE || (res.exhausted && res.next >= res.end && __ballot(cur != CUR_DONE)));
   }
-  c_nodes = wave_sum(c_nodes); c_tris = wave_sum(c_tris); c_rays = wave_sum(c_rays); c_hits = wave_sum(c_hits);
+  unsigned long long c_nodes = wave_sum(nv), c_tris = wave_sum(nt), c_rays = wave_sum(nr), c_hits = wave_sum(nh);
   if (lane == 0 && c_rays) {
     atomicAdd(&q.stats[ST_NODES_C], c_nodes); atomicAdd(&q.stats[ST_TRIS_C], c_tris);
     atomicAdd(&q.stats[ST_SEGMENTS], c_rays); atomicAdd(&q.stats[ST_HITS], c_hits);
@@ -218,10 +233,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DevScene sc, DevQ
 }
 
 // =================================================================================================
-// P4 any-hit traversal for the NEE shadow rays; unoccluded rays add their contribution to the
-// path's radiance word (single owner: one shadow ray per path per bounce).
+// P4 any-hit traversal for the NEE shadow rays (same machinery); an unoccluded ray adds its contribution
+// to the path's radiance word (single owner: one shadow ray per path per bounce).
 template <bool LDS_STACK, bool NODELETS, bool DEBUG_OUT>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_any(DevScene sc, DevQueues q, uint8_t* debug_out) {
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_any(DevScene sc, DevQueues q, uint32_t stack_depth, uint8_t* debug_out) {
   extern __shared__ float4 lds_raw[];
   float4* lds_nodes = lds_raw;
   int* lds_stack = reinterpret_cast<int*>(lds_raw + (NODELETS ? (size_t)sc.n_nodelets * 4 : 0));
@@ -232,22 +247,30 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_any(DevScene sc, DevQueue
     __syncthreads();
   }
   const uint32_t n = q.cnt[CNT_SHADOW];
-  unsigned long long c_nodes = 0, c_tris = 0, c_rays = 0;
+  uint32_t nv = 0, nt = 0, nr = 0;
+  Reservoir res; res.init();
+  Stack<LDS_STACK> st;
+  st.init(lds_stack + wave * (stack_depth * 64u) + lane);
+  int cur = CUR_DONE;
+  uint32_t ri = 0, path = 0;
+  ray_t r = make_ray(V3(0, 0, 0), V3(0, 0, 1));
+  float tmax = 0.0f;
+  bool occluded = false;
   for (;;) {
-    const uint32_t base = wave_fetch(&q.cnt[CNT_WORK_SHADOW], 64u, lane);
-    if (base >= n) break;
-    const uint32_t i = base + lane;
-    const bool active = i < n;
-    float4 A = make_float4(0, 0, 0, 0), Bq = make_float4(0, 0, 0, 0);
-    if (active) { A = q.shadow.A[i]; Bq = q.shadow.B[i]; }
-    const ray_t r = make_ray(V3(A.x, A.y, A.z), V3(A.w, Bq.x, Bq.y));
-    const float tmax = Bq.z;
-    bool occluded = false;
-    uint32_t nv = 0, nt = 0;
-    Stack<LDS_STACK> st;
-    st.init(lds_stack + wave * (LDS_STACK_DEPTH * 64) + lane);
-    int cur = active ? 0 : CUR_DONE;
-    while (cur != CUR_DONE) {
+    if (res.refill(&q.cnt[CNT_WORK_SHADOW], n, cur == CUR_DONE, lane, ri)) {
+      const float4 A = q.shadow.A[ri], Bq = q.shadow.B[ri];
+      r = make_ray(V3(A.x, A.y, A.z), V3(A.w, Bq.x, Bq.y));
+      tmax = Bq.z; path = __float_as_uint(Bq.w);
+      occluded = false;
+      st.reset();
+      cur = 0;
+      ++nr;
+    }
+    if (!__ballot(cur != CUR_DONE)) {
+      if (res.exhausted) break;
+      continue;
+    }
+    do {
       while (cur >= 0) {
         const Node16 nd = load_node<NODELETS>(sc, lds_nodes, cur);
         ++nv;
@@ -262,9 +285,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_any(DevScene sc, DevQueue
           cur = first;
         } else if (h0) cur = c0;
         else if (h1) cur = c1;
-        else cur = st.empty() ? CUR_DONE : st.pop();
+        else cur = st.empty() ? CUR_DONE + 1 : st.pop();
       }
-      if (cur != CUR_DONE) {
+      if (cur > CUR_DONE + 1) {
         const uint32_t code = (uint32_t)~cur;
         const uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
         for (uint32_t k = first; k < first + count; ++k) {
@@ -276,53 +299,94 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_any(DevScene sc, DevQueue
             break;
           }
         }
-        cur = (occluded || st.empty()) ? CUR_DONE : st.pop();
+        cur = (occluded || st.empty()) ? CUR_DONE + 1 : st.pop();
       }
-    }
-    c_nodes += nv; c_tris += nt; c_rays += active ? 1u : 0u;
-    if (DEBUG_OUT) {
-      if (active) debug_out[i] = occluded ? 1 : 0;
-    } else if (active && !occluded) {
-      const float4 Cq = q.shadow.C[i];
-      const uint32_t path = __float_as_uint(Bq.w);
-      float4 L = q.lpath[path];
-      L.x = L.x + Cq.x; L.y = L.y + Cq.y; L.z = L.z + Cq.z;
-      q.lpath[path] = L;
-    }
+      if (cur == CUR_DONE + 1) {
+        if (DEBUG_OUT) debug_out[ri] = occluded ? 1 : 0;
+        else if (!occluded) {
+          const float4 Cq = q.shadow.C[ri];
+          float4 L = q.lpath[path];
+          L.x = L.x + Cq.x; L.y = L.y + Cq.y; L.z = L.z + Cq.z;
+          q.lpath[path] = L;
+        }
+        cur = CUR_DONE;
+      }
+    } while (__popcll(__ballot(cur == CUR_DONE)) < TRACE_REFILL_IDLE || (res.exhausted && res.next >= res.end && __ballot(cur != CUR_DONE)));
   }
-  c_nodes = wave_sum(c_nodes); c_tris = wave_sum(c_tris); c_rays = wave_sum(c_rays);
+  unsigned long long c_nodes = wave_sum(nv), c_tris = wave_sum(nt), c_rays = wave_sum(nr);
   if (lane == 0 && c_rays) {
     atomicAdd(&q.stats[ST_NODES_A], c_nodes); atomicAdd(&q.stats[ST_TRIS_A], c_tris); atomicAdd(&q.stats[ST_SHADOW], c_rays);
   }
 }
 
 // =================================================================================================
-// P5–P8 shading: surface reconstruction, emission with MIS, next-event estimation, BSDF sampling,
-// Russian roulette.  Input is the class-sorted queue, so a wave is (boundary waves aside) uniform
-// in material class and the GGX / Lambert branches below do not diverge.
-__global__ __launch_bounds__(256) void k_shade(DevScene sc, DevFrame fr, DevQueues q) {
+// P9 + P5–P8 shading.
+// Front end (P9): a 512-thread block takes a window of 512 consecutive (ray, hit) slots and sorts the
+// surviving paths by material class through LDS — per-wave ballot + mbcnt prefix, per-block prefix over
+// the 8 wave counts — so that waves are uniform in class (Lambert first, GGX after, class boundary
+// rounded up to a wave) and misses are dropped.
+// Middle (P5–P8): surface reconstruction, emission with MIS, next-event estimation, BSDF sampling,
+// Russian roulette.
+// Back end (P9): continuation and shadow rays are compacted into the output queues with the same
+// ballot/prefix scheme and ONE atomic per block and queue.
+__global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DevScene sc, DevFrame fr, DevQueues q, int qi) {
+  __shared__ uint32_t s_cnt[4][SHADE_WAVES];     // per-wave counts: class0, class1, shadow, next
+  __shared__ uint32_t s_base[2];                 // block's base slots in the shadow / next queues
+  __shared__ uint16_t s_idx[SHADE_BLOCK];        // sorted local slot of each work item (0xffff = none)
   const uint32_t lane = lane_id();
-  const uint32_t n0 = q.cnt[CNT_SORT0], n1 = q.cnt[CNT_SORT1];
-  const uint32_t w0 = (n0 + 63u) >> 6, w1 = (n1 + 63u) >> 6;
-  for (;;) {
-    const uint32_t wv = wave_fetch(&q.cnt[CNT_WORK_SHADE], 1u, lane);
-    if (wv >= w0 + w1) break;
-    bool valid; uint32_t slot;
-    if (wv < w0) { const uint32_t k = wv * 64u + lane; valid = k < n0; slot = k; }
-    else { const uint32_t k = (wv - w0) * 64u + lane; valid = k < n1; slot = q.cap - 1u - k; }
+  const uint32_t wave = threadIdx.x >> 6;
+  const RayQ rin = q.ray[qi], rout = q.ray[qi ^ 1];
+  const uint32_t n = q.cnt[CNT_RAYS];
+  const uint32_t n_windows = (n + SHADE_BLOCK - 1u) / SHADE_BLOCK;
+  for (uint32_t win = blockIdx.x; win < n_windows; win += gridDim.x) {
+    const uint32_t wbase = win * SHADE_BLOCK;
+    // ---- front end: class sort of the window ----
+    int cls = -1;
+    {
+      const uint32_t i = wbase + threadIdx.x;
+      if (i < n) {
+        const int pc = __float_as_int(q.hit[i].y);
+        if (pc >= 0) cls = (pc >> HIT_CLASS_SHIFT) & 1;
+      }
+    }
+    const uint64_t m0 = __ballot(cls == 0), m1 = __ballot(cls == 1);
+    if (lane == 0) { s_cnt[0][wave] = (uint32_t)__popcll(m0); s_cnt[1][wave] = (uint32_t)__popcll(m1); }
+    s_idx[threadIdx.x] = 0xffffu;
+    __syncthreads();
+    uint32_t off0 = 0, off1 = 0, tot0 = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < SHADE_WAVES; ++w) {
+      const uint32_t a = s_cnt[0][w], b = s_cnt[1][w];
+      if (w < wave) { off0 += a; off1 += b; }
+      tot0 += a;
+    }
+    const uint32_t start1 = (tot0 + 63u) & ~63u;                       // GGX group starts on a wave boundary
+    if (cls == 0) s_idx[off0 + mbcnt64(m0)] = (uint16_t)threadIdx.x;
+    else if (cls == 1) {
+      // the padding may push the tail of the GGX group past the block: those (< 64) items fold back into
+      // the padding gap behind the Lambert group (only that one wave is then mixed)
+      uint32_t p = start1 + off1 + mbcnt64(m1);
+      if (p >= SHADE_BLOCK) p = tot0 + (p - SHADE_BLOCK);
+      s_idx[p] = (uint16_t)threadIdx.x;
+    }
+    __syncthreads();
+    const uint32_t item = s_idx[threadIdx.x];
+    const bool valid = item != 0xffffu;
+    const uint32_t slot = wbase + (valid ? item : 0u);
+
     bool alive = false, has_shadow = false;
     float4 oA, oB, oC; uint32_t oD = 0;              // continuation ray
     float4 sA, sB, sC;                               // shadow ray
     oA = oB = oC = sA = sB = sC = make_float4(0, 0, 0, 0);
     if (valid) {
-      const float4 A = q.sorted.A[slot], Bq = q.sorted.B[slot], Cq = q.sorted.C[slot], H = q.sorted.H[slot];
-      const uint32_t b = q.sorted.D[slot];
+      const float4 A = rin.A[slot], Bq = rin.B[slot], Cq = rin.C[slot], H = q.hit[slot];
+      const uint32_t b = rin.D[slot];
       const v3 d = V3(A.w, Bq.x, Bq.y);
       v3 T = V3(Bq.z, Bq.w, Cq.x);
       const float prev_pdf = Cq.y;
       const uint32_t path = __float_as_uint(Cq.z), key = __float_as_uint(Cq.w);
       const float ht = H.x, hu = H.z, hv = H.w;
-      const uint32_t prim = (uint32_t)__float_as_int(H.y);
+      const uint32_t prim = (uint32_t)__float_as_int(H.y) & ((1u << HIT_CLASS_SHIFT) - 1u);
       // ---- P5 surface reconstruction: gather the three R1 vertex records ----
       const uint32_t i0 = sc.widx[prim * 3 + 0], i1 = sc.widx[prim * 3 + 1], i2 = sc.widx[prim * 3 + 2];
       const float* va = sc.wverts + (size_t)i0 * 12; const float* vb = sc.wverts + (size_t)i1 * 12; const float* vc = sc.wverts + (size_t)i2 * 12;
@@ -339,8 +403,6 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, DevFrame fr, DevQueu
       if (!(dot3(ns, wo) > 0.0f)) ns = ng;
       const int mat = sc.tri_mat[prim];
       const float4 M0 = sc.mats[mat * 3 + 0], M1 = sc.mats[mat * 3 + 1];
-      float4 L = q.lpath[path];
-      bool Ldirty = false;
       // ---- emission (one-sided), MIS against next-event estimation ----
       const int li = sc.prim_light[prim];
       if (li >= 0 && front) {
@@ -352,10 +414,10 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, DevFrame fr, DevQueu
           const float pb2 = prev_pdf * prev_pdf;
           wgt = pb2 / pt_fma(pl, pl, pb2);
         }
+        float4 L = q.lpath[path];
         L.x = pt_fma(T.x * l4.x, wgt, L.x); L.y = pt_fma(T.y * l4.y, wgt, L.y); L.z = pt_fma(T.z * l4.z, wgt, L.z);
-        Ldirty = true;
+        q.lpath[path] = L;
       }
-      if (Ldirty) q.lpath[path] = L;
       if ((int)b < fr.max_bounces) {
         const bsdf_t bs = make_bsdf(V3(M0.x, M0.y, M0.z), M0.w, M1.w);
         v3 tx, ty; onb(ns, tx, ty);
@@ -428,17 +490,25 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, DevFrame fr, DevQueu
         }
       }
     }
-    // ---- compaction: ballot + mbcnt prefix + one atomic per wave and queue ----
-    const uint64_t ms = __ballot(has_shadow);
-    if (ms) {
-      const uint32_t s = wave_alloc(&q.cnt[CNT_SHADOW], ms, lane);
-      if (has_shadow) { q.shadow.A[s] = sA; q.shadow.B[s] = sB; q.shadow.C[s] = sC; }
+    // ---- back end: compaction, ballot + mbcnt prefix per wave, LDS prefix per block, one atomic per queue ----
+    const uint64_t ms = __ballot(has_shadow), ma = __ballot(alive);
+    if (lane == 0) { s_cnt[2][wave] = (uint32_t)__popcll(ms); s_cnt[3][wave] = (uint32_t)__popcll(ma); }
+    __syncthreads();
+    uint32_t offs = 0, offa = 0, tots = 0, tota = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < SHADE_WAVES; ++w) {
+      const uint32_t a = s_cnt[2][w], b = s_cnt[3][w];
+      if (w < wave) { offs += a; offa += b; }
+      tots += a; tota += b;
     }
-    const uint64_t ma = __ballot(alive);
-    if (ma) {
-      const uint32_t s = wave_alloc(&q.cnt[CNT_NEXT], ma, lane);
-      if (alive) { q.ray.A[s] = oA; q.ray.B[s] = oB; q.ray.C[s] = oC; q.ray.D[s] = oD; }
+    if (threadIdx.x == 0) {
+      s_base[0] = tots ? atomicAdd(&q.cnt[CNT_SHADOW], tots) : 0u;
+      s_base[1] = tota ? atomicAdd(&q.cnt[CNT_NEXT], tota) : 0u;
     }
+    __syncthreads();
+    if (has_shadow) { const uint32_t s = s_base[0] + offs + mbcnt64(ms); q.shadow.A[s] = sA; q.shadow.B[s] = sB; q.shadow.C[s] = sC; }
+    if (alive) { const uint32_t s = s_base[1] + offa + mbcnt64(ma); rout.A[s] = oA; rout.B[s] = oB; rout.C[s] = oC; rout.D[s] = oD; }
+    __syncthreads();   // s_cnt / s_idx are rewritten by the next window
   }
 }
 
@@ -475,8 +545,9 @@ __global__ __launch_bounds__(256) void k_shade_raster(DevScene sc, DevCamera cam
   if (j >= fr.n_owned) return;
   const float4 H = q.hit[j];
   float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // G-buffer clear → colour 0
-  const int prim = __float_as_int(H.y);
-  if (prim >= 0) {
+  const int pc = __float_as_int(H.y);
+  if (pc >= 0) {
+    const int prim = pc & ((1 << HIT_CLASS_SHIFT) - 1);
     const float hu = H.z, hv = H.w, hw = 1.0f - hu - hv;
     const uint32_t i0 = sc.widx[prim * 3 + 0], i1 = sc.widx[prim * 3 + 1], i2 = sc.widx[prim * 3 + 2];
     const float* va = sc.wverts + (size_t)i0 * 12; const float* vb = sc.wverts + (size_t)i1 * 12; const float* vc = sc.wverts + (size_t)i2 * 12;
@@ -528,7 +599,7 @@ __global__ __launch_bounds__(256) void k_tonemap(const float4* radiance, uint32_
 // launchers
 static size_t trace_lds_bytes(const LaunchCfg& cfg, const DevScene& sc, bool nodelets) {
   size_t b = nodelets ? (size_t)sc.n_nodelets * 64 : 0;
-  if (cfg.lds_stack) b += (size_t)TRACE_WAVES * LDS_STACK_DEPTH * 64 * 4;
+  if (cfg.lds_stack) b += (size_t)TRACE_WAVES * cfg.stack_depth * 64 * 4;
   return b;
 }
 
@@ -542,30 +613,28 @@ void pt_launch_raygen(hipStream_t s, const DevCamera& cam, const DevFrame& fr, c
   else hipLaunchKernelGGL(k_raygen<false>, grid, dim3(256), 0, s, cam, fr, q, first_sample, n_paths);
 }
 
-template <int MODE, bool CULL>
-static void launch_tc(hipStream_t s, const LaunchCfg& cfg, const DevScene& sc, const DevQueues& q) {
+void pt_launch_trace_closest(hipStream_t s, const LaunchCfg& cfg, const DevScene& sc, const DevQueues& q, int qi, bool cull) {
   const bool nodelets = sc.n_nodelets > 0;
   const dim3 grid((unsigned)(cfg.n_cu * cfg.trace_blocks_per_cu));
   const size_t lds = trace_lds_bytes(cfg, sc, nodelets);
-  if (cfg.lds_stack) {
-    if (nodelets) hipLaunchKernelGGL((k_trace_closest<MODE, CULL, true, true>), grid, dim3(TRACE_BLOCK), lds, s, sc, q);
-    else hipLaunchKernelGGL((k_trace_closest<MODE, CULL, true, false>), grid, dim3(TRACE_BLOCK), lds, s, sc, q);
+  const uint32_t sd = (uint32_t)cfg.stack_depth;
+#define TC(C, L, N) hipLaunchKernelGGL((k_trace_closest<C, L, N>), grid, dim3(TRACE_BLOCK), lds, s, sc, q, qi, sd)
+  if (cull) {
+    if (cfg.lds_stack) { if (nodelets) TC(true, true, true); else TC(true, true, false); }
+    else { if (nodelets) TC(true, false, true); else TC(true, false, false); }
   } else {
-    if (nodelets) hipLaunchKernelGGL((k_trace_closest<MODE, CULL, false, true>), grid, dim3(TRACE_BLOCK), lds, s, sc, q);
-    else hipLaunchKernelGGL((k_trace_closest<MODE, CULL, false, false>), grid, dim3(TRACE_BLOCK), lds, s, sc, q);
+    if (cfg.lds_stack) { if (nodelets) TC(false, true, true); else TC(false, true, false); }
+    else { if (nodelets) TC(false, false, true); else TC(false, false, false); }
   }
-}
-void pt_launch_trace_closest(hipStream_t s, const LaunchCfg& cfg, const DevScene& sc, const DevQueues& q, int mode) {
-  if (mode == 0) launch_tc<0, false>(s, cfg, sc, q);
-  else if (mode == 1) launch_tc<1, false>(s, cfg, sc, q);
-  else launch_tc<1, true>(s, cfg, sc, q);
+#undef TC
 }
 
 void pt_launch_trace_any(hipStream_t s, const LaunchCfg& cfg, const DevScene& sc, const DevQueues& q, uint8_t* debug_out) {
   const bool nodelets = sc.n_nodelets > 0;
   const dim3 grid((unsigned)(cfg.n_cu * cfg.trace_blocks_per_cu));
   const size_t lds = trace_lds_bytes(cfg, sc, nodelets);
-#define TA(L, N, D) hipLaunchKernelGGL((k_trace_any<L, N, D>), grid, dim3(TRACE_BLOCK), lds, s, sc, q, debug_out)
+  const uint32_t sd = (uint32_t)cfg.stack_depth;
+#define TA(L, N, D) hipLaunchKernelGGL((k_trace_any<L, N, D>), grid, dim3(TRACE_BLOCK), lds, s, sc, q, sd, debug_out)
   if (debug_out) {
     if (cfg.lds_stack) { if (nodelets) TA(true, true, true); else TA(true, false, true); }
     else { if (nodelets) TA(false, true, true); else TA(false, false, true); }
@@ -576,8 +645,8 @@ void pt_launch_trace_any(hipStream_t s, const LaunchCfg& cfg, const DevScene& sc
 #undef TA
 }
 
-void pt_launch_shade(hipStream_t s, const LaunchCfg& cfg, const DevScene& sc, const DevFrame& fr, const DevQueues& q) {
-  hipLaunchKernelGGL(k_shade, dim3((unsigned)(cfg.n_cu * 8)), dim3(256), 0, s, sc, fr, q);
+void pt_launch_shade(hipStream_t s, const LaunchCfg& cfg, const DevScene& sc, const DevFrame& fr, const DevQueues& q, int qi) {
+  hipLaunchKernelGGL(k_shade, dim3((unsigned)(cfg.n_cu * 3)), dim3(SHADE_BLOCK), 0, s, sc, fr, q, qi);
 }
 void pt_launch_accumulate(hipStream_t s, const DevFrame& fr, const DevQueues& q, float4* accum, uint32_t n_samples) {
   hipLaunchKernelGGL(k_accumulate, dim3((fr.n_owned + 255u) / 256u), dim3(256), 0, s, fr, (const float4*)q.lpath, accum, n_samples);

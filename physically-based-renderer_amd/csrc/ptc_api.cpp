@@ -113,11 +113,10 @@ int ensure_queues(ptc_ctx* c, uint32_t cap) {
   free_all(c->queue_allocs);
   DevQueues q{};
   int rc = 0;
-  rc |= dev_alloc(c, c->queue_allocs, &q.ray.A, cap); rc |= dev_alloc(c, c->queue_allocs, &q.ray.B, cap);
-  rc |= dev_alloc(c, c->queue_allocs, &q.ray.C, cap); rc |= dev_alloc(c, c->queue_allocs, &q.ray.D, cap);
-  rc |= dev_alloc(c, c->queue_allocs, &q.sorted.A, cap); rc |= dev_alloc(c, c->queue_allocs, &q.sorted.B, cap);
-  rc |= dev_alloc(c, c->queue_allocs, &q.sorted.C, cap); rc |= dev_alloc(c, c->queue_allocs, &q.sorted.D, cap);
-  rc |= dev_alloc(c, c->queue_allocs, &q.sorted.H, cap);
+  for (int k = 0; k < 2; ++k) {
+    rc |= dev_alloc(c, c->queue_allocs, &q.ray[k].A, cap); rc |= dev_alloc(c, c->queue_allocs, &q.ray[k].B, cap);
+    rc |= dev_alloc(c, c->queue_allocs, &q.ray[k].C, cap); rc |= dev_alloc(c, c->queue_allocs, &q.ray[k].D, cap);
+  }
   rc |= dev_alloc(c, c->queue_allocs, &q.shadow.A, cap); rc |= dev_alloc(c, c->queue_allocs, &q.shadow.B, cap);
   rc |= dev_alloc(c, c->queue_allocs, &q.shadow.C, cap);
   rc |= dev_alloc(c, c->queue_allocs, &q.hit, cap); rc |= dev_alloc(c, c->queue_allocs, &q.lpath, cap);
@@ -152,8 +151,10 @@ struct ScopedSpan {   // records a start/stop event pair around launches on the 
 
 void configure_launch(ptc_ctx* c) {
   // LDS budget per trace block: nodelets + per-wave stacks.  160 KiB per CU, at most 8 blocks of 4 waves.
-  c->cfg.lds_stack = (c->built.max_depth + 1u) <= 32u;
-  size_t lds = (size_t)c->built.n_nodelets * 64 + (c->cfg.lds_stack ? (size_t)4 * 32 * 64 * 4 : 0);
+  // The per-lane traversal stack needs max_depth+1 entries (one deferred sibling per interior level).
+  c->cfg.stack_depth = (int)c->built.max_depth + 1;
+  c->cfg.lds_stack = c->cfg.stack_depth <= 40;
+  size_t lds = (size_t)c->built.n_nodelets * 64 + (c->cfg.lds_stack ? (size_t)4 * c->cfg.stack_depth * 64 * 4 : 0);
   int per_cu = 8;
   if (lds > 0) { per_cu = (int)((160u * 1024u) / lds); if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1; }
   if (const char* e = std::getenv("PTC_TRACE_BLOCKS_PER_CU")) { int v = std::atoi(e); if (v >= 1 && v <= 8) per_cu = v; }
@@ -167,13 +168,13 @@ int run_batch(ptc_ctx* c, uint32_t n_samples) {
   pt_launch_set_counts(c->stream, c->q, n_paths, 0);
   if (c->integrator == PTC_INTEGRATOR_RASTER_COMPAT) {
     pt_launch_raygen(c->stream, c->cam, c->fr, c->q, 0, 1, true);
-    { ScopedSpan t(c, 0); pt_launch_trace_closest(c->stream, c->cfg, c->dsc, c->q, 2); c->stats.launches_trace_closest++; }
+    { ScopedSpan t(c, 0); pt_launch_trace_closest(c->stream, c->cfg, c->dsc, c->q, 0, true); c->stats.launches_trace_closest++; }
     pt_launch_shade_raster(c->stream, c->dsc, c->cam, c->fr, c->q, c->accum.p);
   } else {
     pt_launch_raygen(c->stream, c->cam, c->fr, c->q, c->samples_done, n_samples, false);
     for (int b = 0; b <= c->fr.max_bounces; ++b) {
-      { ScopedSpan t(c, 0); pt_launch_trace_closest(c->stream, c->cfg, c->dsc, c->q, 0); c->stats.launches_trace_closest++; }
-      { ScopedSpan t(c, 2); pt_launch_shade(c->stream, c->cfg, c->dsc, c->fr, c->q); }
+      { ScopedSpan t(c, 0); pt_launch_trace_closest(c->stream, c->cfg, c->dsc, c->q, b & 1, false); c->stats.launches_trace_closest++; }
+      { ScopedSpan t(c, 2); pt_launch_shade(c->stream, c->cfg, c->dsc, c->fr, c->q, b & 1); }
       if (b < c->fr.max_bounces && c->dsc.n_lights > 0) {
         ScopedSpan t(c, 1); pt_launch_trace_any(c->stream, c->cfg, c->dsc, c->q, nullptr); c->stats.launches_trace_any++;
       }
@@ -529,17 +530,18 @@ int ptc_debug_trace_closest(ptc_ctx* c, const float* origins, const float* dirs,
     A[i] = make_float4(origins[i * 3], origins[i * 3 + 1], origins[i * 3 + 2], dirs[i * 3]);
     B[i] = make_float4(dirs[i * 3 + 1], dirs[i * 3 + 2], 0.0f, 0.0f);
   }
-  HIP_TRY(c, hipMemcpy(c->q.ray.A, A.data(), n * sizeof(float4), hipMemcpyHostToDevice));
-  HIP_TRY(c, hipMemcpy(c->q.ray.B, B.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->q.ray[0].A, A.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->q.ray[0].B, B.data(), n * sizeof(float4), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemsetAsync(c->q.stats, 0, ST_N * sizeof(unsigned long long), c->stream));
   pt_launch_set_counts(c->stream, c->q, n, 0);
-  pt_launch_trace_closest(c->stream, c->cfg, c->dsc, c->q, 1);
+  pt_launch_trace_closest(c->stream, c->cfg, c->dsc, c->q, 0, false);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   std::vector<float4> H(n);
   HIP_TRY(c, hipMemcpy(H.data(), c->q.hit, n * sizeof(float4), hipMemcpyDeviceToHost));
   for (uint32_t i = 0; i < n; ++i) {
-    out_t[i] = H[i].x; std::memcpy(&out_prim[i], &H[i].y, 4); out_uv[i * 2] = H[i].z; out_uv[i * 2 + 1] = H[i].w;
+    int32_t pc; std::memcpy(&pc, &H[i].y, 4);   // prim | class<<28, or -1
+    out_t[i] = H[i].x; out_prim[i] = pc < 0 ? -1 : (pc & 0x0fffffff); out_uv[i * 2] = H[i].z; out_uv[i * 2 + 1] = H[i].w;
   }
   return PTC_OK;
 }

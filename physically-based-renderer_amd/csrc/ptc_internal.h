@@ -39,31 +39,29 @@ struct DevFrame {
 // hit record   : H=(t,prim,u,v)                                                            (16 B)
 // shadow record: A=(o.xyz,d.x) B=(d.y,d.z,tmax,path_id) C=(contrib.rgb,-)                  (48 B)
 struct RayQ { float4* A; float4* B; float4* C; uint32_t* D; };
-struct SortQ { float4* A; float4* B; float4* C; uint32_t* D; float4* H; };
 struct ShadowQ { float4* A; float4* B; float4* C; };
 
 struct DevQueues {
-  RayQ ray;        // compact [0, cnt[CNT_RAYS])
-  SortQ sorted;    // class 0 at [0, cnt[CNT_SORT0]), class 1 at (cap-1 ... cap-cnt[CNT_SORT1]]
+  RayQ ray[2];     // ping-pong: bounce b reads ray[b&1] (compact [0, cnt[CNT_RAYS])), shade writes ray[(b+1)&1]
   ShadowQ shadow;  // compact [0, cnt[CNT_SHADOW])
-  float4* hit;     // in-place hit records (raster / debug mode)
+  float4* hit;     // hit record of ray slot i, written in place by k_trace_closest: (t, prim | class<<28, u, v)
   float4* lpath;   // per-path radiance (rgb,-), single owner
   uint32_t* cnt;   // device counters, see CNT_*
   unsigned long long* stats;  // device statistics, see ST_*
   uint32_t cap;    // queue capacity (paths per batch)
 };
 
-enum { CNT_RAYS = 0, CNT_SORT0, CNT_SORT1, CNT_NEXT, CNT_SHADOW, CNT_WORK_TRACE, CNT_WORK_SHADE, CNT_WORK_SHADOW, CNT_N };
+enum { CNT_RAYS = 0, CNT_NEXT, CNT_SHADOW, CNT_WORK_TRACE, CNT_WORK_SHADE, CNT_WORK_SHADOW, CNT_N };
 enum { ST_SEGMENTS = 0, ST_SHADOW, ST_HITS, ST_NODES_C, ST_TRIS_C, ST_NODES_A, ST_TRIS_A, ST_N };
 
-struct LaunchCfg { int n_cu; int trace_blocks_per_cu; bool lds_stack; };
+struct LaunchCfg { int n_cu; int trace_blocks_per_cu; bool lds_stack; int stack_depth; };
 
 // ---- kernel launchers (pt_kernels.hip) ------------------------------------------------------------
 void pt_launch_set_counts(hipStream_t, const DevQueues&, uint32_t n_rays, uint32_t n_shadow);
 void pt_launch_advance(hipStream_t, const DevQueues&);
 void pt_launch_raygen(hipStream_t, const DevCamera&, const DevFrame&, const DevQueues&, uint32_t first_sample, uint32_t n_samples, bool raster);
-void pt_launch_trace_closest(hipStream_t, const LaunchCfg&, const DevScene&, const DevQueues&, int mode /*0 sort,1 in-place,2 in-place+cull*/);
-void pt_launch_shade(hipStream_t, const LaunchCfg&, const DevScene&, const DevFrame&, const DevQueues&);
+void pt_launch_trace_closest(hipStream_t, const LaunchCfg&, const DevScene&, const DevQueues&, int qi, bool cull);
+void pt_launch_shade(hipStream_t, const LaunchCfg&, const DevScene&, const DevFrame&, const DevQueues&, int qi);
 void pt_launch_trace_any(hipStream_t, const LaunchCfg&, const DevScene&, const DevQueues&, uint8_t* debug_out /*or null*/);
 void pt_launch_accumulate(hipStream_t, const DevFrame&, const DevQueues&, float4* accum, uint32_t n_samples);
 void pt_launch_shade_raster(hipStream_t, const DevScene&, const DevCamera&, const DevFrame&, const DevQueues&, float4* accum);
