@@ -181,9 +181,13 @@ int ptc_debug_trace_any(ptc_ctx*, const float* origins, const float* dirs, const
 int ptc_debug_get_flat_scene(ptc_ctx*, uint32_t* n_verts, uint32_t* n_tris, ptc_vertex* verts,
                              uint32_t* indices, int32_t* tri_material);
 
-/* The flattened LBVH as committed: nodes (n_nodes*16 floats: lo0 hi0 lo1 hi1, then child codes c0 c1
- * as int32 bits and 2 pads) and Morton-ordered triangle records (n_tris*12 floats: v0,prim | e1,class |
- * e2,0).  Pass NULL to query sizes only. */
+/* Raw device counter array of the current frame (segments, shadow rays, hits, node/triangle counts, then the
+ * loop-iteration diagnostics a -DPT_DIAG build fills).  Returns the number of counters the library keeps. */
+int ptc_debug_get_counters(ptc_ctx*, uint64_t* out, int n);
+
+/* The flattened 4-wide LBVH as committed: nodes (n_nodes*32 floats, SoA: lo.x[4] lo.y[4] lo.z[4] hi.x[4]
+ * hi.y[4] hi.z[4], child codes[4] as int32 bits, 4 pads) and Morton-ordered triangle records (n_tris*12
+ * floats: v0,prim | e1,class | e2,0).  Pass NULL to query sizes only. */
 int ptc_debug_get_bvh(ptc_ctx*, uint32_t* n_nodes, uint32_t* n_tris, float* nodes, float* tris);
 
 #ifdef __cplusplus

@@ -36,7 +36,8 @@
 /* ------------------------------------------------------------------------------------------ */
 /* constants of the specification                                                              */
 #define ORA_LEAF_MAX 4          /* triangles per BVH leaf                                      */
-#define ORA_STACK 64            /* traversal stack entries                                     */
+#define ORA_STACK 256           /* traversal stack entries (3 per wide level, worst case)      */
+#define ORA_EMPTY ((int32_t)0x80000000)  /* unused child slot of a wide node                    */
 #define ORA_RR_START 3          /* Russian roulette from this bounce index on                  */
 #define ORA_RR_PMIN 0.05f
 #define ORA_ALPHA_MIN 0.001f
@@ -52,7 +53,7 @@
 #define S_RAY 56u
 #define S_HIT 16u
 #define S_SHADOW 44u
-#define S_NODE 64u
+#define S_NODE 128u
 #define S_TRI 48u
 #define S_SURF 176u
 #define S_FB 16u
@@ -172,6 +173,14 @@ typedef struct {                 /* 64-byte interior node: both child boxes + ch
   int32_t pad0, pad1;
 } node_t;
 
+/* 128-byte 4-wide node, SoA: the traversal structure (the binary node_t above is only the build's
+ * intermediate).  code: >=0 wide node index; <0 leaf (as in node_t); ORA_EMPTY unused slot. */
+typedef struct {
+  float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];
+  int32_t code[4];
+  int32_t pad[4];
+} wnode_t;
+
 typedef struct { v3 v0, e1, e2, ng; float area; v3 Le; float pmf; uint32_t prim; } light_t;
 
 struct ora_ctx {
@@ -190,7 +199,8 @@ struct ora_ctx {
   /* BVH (triangles in sorted order) */
   uint32_t* order;                     /* sorted position → original prim id */
   v3 *tv0, *te1, *te2;                 /* per sorted position */
-  node_t* nodes; uint32_t n_nodes; uint32_t max_depth;
+  node_t* nodes; uint32_t n_nodes; uint32_t max_depth;   /* binary radix tree (intermediate) */
+  wnode_t* wnodes; uint32_t n_wnodes; uint32_t wdepth;   /* 4-wide collapse: what rays traverse */
   int32_t* prim_light;                 /* original prim id → light index or -1 */
   light_t* lights; float* cdf; uint32_t n_lights;
   float scene_lo[3], scene_hi[3]; float ray_eps;
@@ -208,9 +218,9 @@ ora_ctx* ora_create(void) {
 }
 static void free_committed(ora_ctx* c) {
   free(c->wv); free(c->widx); free(c->tri_mat); free(c->order); free(c->tv0); free(c->te1); free(c->te2);
-  free(c->nodes); free(c->prim_light); free(c->lights); free(c->cdf);
+  free(c->nodes); free(c->wnodes); free(c->prim_light); free(c->lights); free(c->cdf);
   c->wv = NULL; c->widx = NULL; c->tri_mat = NULL; c->order = NULL; c->tv0 = c->te1 = c->te2 = NULL;
-  c->nodes = NULL; c->prim_light = NULL; c->lights = NULL; c->cdf = NULL; c->committed = 0;
+  c->nodes = NULL; c->wnodes = NULL; c->prim_light = NULL; c->lights = NULL; c->cdf = NULL; c->committed = 0;
 }
 static void free_description(ora_ctx* c) {
   for (int i = 0; i < c->n_meshes; ++i) { free(c->meshes[i].v); free(c->meshes[i].idx); }
@@ -402,6 +412,50 @@ static int32_t build_node(build_t* b, uint32_t lo, uint32_t hi, uint32_t depth) 
   return (int32_t)me;
 }
 
+/* 4-wide collapse of the binary tree (greedy by surface area): start from a binary node's two children and
+ * keep replacing the interior child with the largest half-area (ties: lowest slot) by its own two children,
+ * in place, until there are 4 children or only leaves remain. */
+typedef struct { float lo[3], hi[3]; int32_t code; } wchild;
+static inline float half_area(const float lo[3], const float hi[3]) {
+  float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+  return ex * ey + ey * ez + ez * ex;
+}
+static inline wchild bin_child(const node_t* n, int k) {
+  wchild w;
+  memcpy(w.lo, k ? n->lo1 : n->lo0, 12); memcpy(w.hi, k ? n->hi1 : n->hi0, 12); w.code = k ? n->c1 : n->c0;
+  return w;
+}
+static int32_t widen(ora_ctx* c, int32_t bin_idx, uint32_t depth, uint32_t* next, uint32_t* maxd) {
+  uint32_t me = (*next)++;
+  if (depth > *maxd) *maxd = depth;
+  wchild list[4]; int n = 2;
+  list[0] = bin_child(&c->nodes[bin_idx], 0); list[1] = bin_child(&c->nodes[bin_idx], 1);
+  while (n < 4) {
+    int best = -1; float besta = 0.0f;
+    for (int i = 0; i < n; ++i) {
+      if (list[i].code < 0) continue;
+      float a = half_area(list[i].lo, list[i].hi);
+      if (best < 0 || a > besta) { best = i; besta = a; }
+    }
+    if (best < 0) break;
+    const node_t* bn = &c->nodes[list[best].code];
+    for (int j = n; j > best + 1; --j) list[j] = list[j - 1];
+    list[best] = bin_child(bn, 0); list[best + 1] = bin_child(bn, 1);
+    ++n;
+  }
+  wnode_t w; memset(&w, 0, sizeof w);
+  for (int i = 0; i < 4; ++i) {
+    if (i >= n) {                                   /* unused slot: inverted box, never entered */
+      w.code[i] = ORA_EMPTY; w.lox[i] = w.loy[i] = w.loz[i] = 3.0e38f; w.hix[i] = w.hiy[i] = w.hiz[i] = -3.0e38f; continue;
+    }
+    w.lox[i] = list[i].lo[0]; w.loy[i] = list[i].lo[1]; w.loz[i] = list[i].lo[2];
+    w.hix[i] = list[i].hi[0]; w.hiy[i] = list[i].hi[1]; w.hiz[i] = list[i].hi[2];
+    w.code[i] = list[i].code < 0 ? list[i].code : widen(c, list[i].code, depth + 1, next, maxd);
+  }
+  c->wnodes[me] = w;
+  return (int32_t)me;
+}
+
 int ora_scene_commit(ora_ctx* c) {
   free_committed(c);
   if (!c->have_cam) return fail(c, "scene_commit: no camera");
@@ -484,6 +538,8 @@ int ora_scene_commit(ora_ctx* c) {
     build_node(&b, 0, n - 1, 0);
   }
   c->n_nodes = b.next; c->max_depth = b.depth_max;
+  c->wnodes = (wnode_t*)calloc(c->n_nodes, sizeof(wnode_t));
+  { uint32_t next = 0, maxd = 0; widen(c, 0, 0, &next, &maxd); c->n_wnodes = next; c->wdepth = maxd; }
   free(keys); free(tlo); free(thi);
   /* P7: emitter table in original primitive order, power pmf/cdf */
   c->prim_light = (int32_t*)malloc(4u * n);
@@ -513,7 +569,7 @@ int ora_scene_commit(ora_ctx* c) {
   for (uint32_t i = 0; i < nl; ++i) { run += c->lights[i].pmf; c->cdf[i] = run / total; c->lights[i].pmf = c->lights[i].pmf / total; }
   if (nl) c->cdf[nl - 1] = 1.0f;
   memset(&c->stats, 0, sizeof c->stats);
-  c->stats.n_triangles = n; c->stats.n_bvh_nodes = c->n_nodes; c->stats.n_emitters = nl; c->stats.bvh_max_depth = c->max_depth;
+  c->stats.n_triangles = n; c->stats.n_bvh_nodes = c->n_wnodes; c->stats.n_emitters = nl; c->stats.bvh_max_depth = c->wdepth;
   c->committed = 1;
   return 0;
 }
@@ -530,9 +586,9 @@ int ora_get_flat_scene(ora_ctx* c, uint32_t* nv, uint32_t* nt, void* verts, uint
 
 int ora_get_bvh(ora_ctx* c, uint32_t* nn, uint32_t* nt, float* nodes, float* tris) {
   if (!c->committed) return fail(c, "get_bvh: scene not committed");
-  if (nn) *nn = c->n_nodes;
+  if (nn) *nn = c->n_wnodes;
   if (nt) *nt = c->n_tris;
-  if (nodes) memcpy(nodes, c->nodes, sizeof(node_t) * c->n_nodes);
+  if (nodes) memcpy(nodes, c->wnodes, sizeof(wnode_t) * c->n_wnodes);
   if (tris) for (uint32_t i = 0; i < c->n_tris; ++i) {
     float* o = tris + (size_t)i * 12; uint32_t p = c->order[i];
     const material_t* m = &c->mats[c->tri_mat[p]];
@@ -584,23 +640,41 @@ static inline int tri_test(const ray_t* r, v3 v0, v3 e1, v3 e2, int cull, float*
 
 typedef struct { float t, u, v; int32_t prim; uint32_t pos; } hit_t;
 
+/* One wide-node step: test the (up to 4) children against [tmin, tlimit], order the hits by
+ * key = (bits(tnear) & ~3) | slot  (tnear >= 0, so the bit pattern orders like the value; the two dropped
+ * mantissa bits make room for the slot, which also breaks ties), return them nearest first. */
+typedef struct { int32_t code; uint32_t key; } cand_t;
+typedef struct { int32_t code; float tq; } sent_t;
+static inline int wide_step(const wnode_t* n, const ray_t* r, float tmin, float tlimit, cand_t out[4]) {
+  int nh = 0;
+  for (int i = 0; i < 4; ++i) {
+    if (n->code[i] == ORA_EMPTY) continue;
+    float lo[3] = {n->lox[i], n->loy[i], n->loz[i]}, hi[3] = {n->hix[i], n->hiy[i], n->hiz[i]};
+    float tn;
+    if (!box_hit(r, lo, hi, tmin, tlimit, &tn)) continue;
+    union { float f; uint32_t u; } b; b.f = tn;
+    cand_t cd; cd.code = n->code[i]; cd.key = (b.u & 0xfffffffcu) | (uint32_t)i;
+    int j = nh++;
+    while (j > 0 && out[j - 1].key > cd.key) { out[j] = out[j - 1]; --j; }
+    out[j] = cd;
+  }
+  return nh;
+}
+static inline float key_tq(uint32_t key) { union { float f; uint32_t u; } b; b.u = key & 0xfffffffcu; return b.f; }
+
 static hit_t trace_closest(const ora_ctx* c, v3 o, v3 d, float tmin, float tmax, int cull, trav_count* cnt) {
   hit_t best; best.t = tmax; best.prim = 0x7fffffff; best.u = best.v = 0.0f; best.pos = 0; int found = 0;
   ray_t r = make_ray(o, d);
-  int32_t stack[ORA_STACK]; int sp = 0; int32_t cur = 0;
+  sent_t stack[ORA_STACK]; int sp = 0; int32_t cur = 0;
   for (;;) {
     while (cur >= 0) {
-      const node_t* n = &c->nodes[cur]; cnt->nodes++;
-      float t0, t1;
-      int h0 = box_hit(&r, n->lo0, n->hi0, tmin, best.t, &t0);
-      int h1 = box_hit(&r, n->lo1, n->hi1, tmin, best.t, &t1);
-      if (h0 && h1) {
-        int32_t first = n->c0, second = n->c1;
-        if (t1 < t0) { first = n->c1; second = n->c0; }
-        stack[sp++] = second; cur = first;
-      } else if (h0) cur = n->c0;
-      else if (h1) cur = n->c1;
-      else { if (sp == 0) goto done; cur = stack[--sp]; }
+      cand_t cd[4]; cnt->nodes++;
+      int nh = wide_step(&c->wnodes[cur], &r, tmin, best.t, cd);
+      for (int k = nh - 1; k >= 1; --k) { stack[sp].code = cd[k].code; stack[sp].tq = key_tq(cd[k].key); ++sp; }   /* farthest first */
+      if (nh > 0) { cur = cd[0].code; continue; }
+      cur = ORA_EMPTY;                                        /* pop, skipping entries that are now too far */
+      while (sp > 0) { sent_t e = stack[--sp]; if (e.tq > best.t) continue; cur = e.code; break; }
+      if (cur == ORA_EMPTY) goto done;
     }
     {
       uint32_t code = (uint32_t)~cur; uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
@@ -610,8 +684,9 @@ static hit_t trace_closest(const ora_ctx* c, v3 o, v3 d, float tmin, float tmax,
         int32_t pid = (int32_t)c->order[i];
         if (t > tmin && (t < best.t || (t == best.t && pid < best.prim))) { best.t = t; best.u = u; best.v = v; best.prim = pid; best.pos = i; found = 1; }
       }
-      if (sp == 0) break;
-      cur = stack[--sp];
+      cur = ORA_EMPTY;
+      while (sp > 0) { sent_t e = stack[--sp]; if (e.tq > best.t) continue; cur = e.code; break; }
+      if (cur == ORA_EMPTY) break;
     }
   }
 done:
@@ -623,17 +698,12 @@ static int trace_any(const ora_ctx* c, v3 o, v3 d, float tmin, float tmax, trav_
   int32_t stack[ORA_STACK]; int sp = 0; int32_t cur = 0;
   for (;;) {
     while (cur >= 0) {
-      const node_t* n = &c->nodes[cur]; cnt->nodes++;
-      float t0, t1;
-      int h0 = box_hit(&r, n->lo0, n->hi0, tmin, tmax, &t0);
-      int h1 = box_hit(&r, n->lo1, n->hi1, tmin, tmax, &t1);
-      if (h0 && h1) {
-        int32_t first = n->c0, second = n->c1;
-        if (t1 < t0) { first = n->c1; second = n->c0; }
-        stack[sp++] = second; cur = first;
-      } else if (h0) cur = n->c0;
-      else if (h1) cur = n->c1;
-      else { if (sp == 0) return 0; cur = stack[--sp]; }
+      cand_t cd[4]; cnt->nodes++;
+      int nh = wide_step(&c->wnodes[cur], &r, tmin, tmax, cd);
+      for (int k = nh - 1; k >= 1; --k) stack[sp++] = cd[k].code;
+      if (nh > 0) { cur = cd[0].code; continue; }
+      if (sp == 0) return 0;
+      cur = stack[--sp];
     }
     uint32_t code = (uint32_t)~cur; uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
     for (uint32_t i = first; i < first + count; ++i) {

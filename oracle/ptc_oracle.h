@@ -53,7 +53,7 @@ int ora_trace_any(ora_ctx*, const float* origins, const float* dirs, const float
 int ora_get_flat_scene(ora_ctx*, uint32_t* n_verts, uint32_t* n_tris, void* verts48,
                        uint32_t* indices, int32_t* tri_material);
 
-/* BVH as built: nodes n_nodes*16 floats (same record as the product's), sorted triangles n_tris*12 floats
+/* BVH as built: 4-wide nodes, n_nodes*32 floats (same record as the product's), sorted triangles n_tris*12 floats
  * (v0,prim | e1,class | e2,0).  NULL pointers to query sizes. */
 int ora_get_bvh(ora_ctx*, uint32_t* n_nodes, uint32_t* n_tris, float* nodes, float* tris);
 

@@ -21,7 +21,9 @@
 #define TRACE_WAVES (TRACE_BLOCK / 64)
 #define TRACE_CHUNK 512u          // rays per work-fetch atomic
 #define TRACE_REFILL_IDLE 16      // refill as soon as this many lanes are idle
-#define SCRATCH_STACK_DEPTH 64
+#ifndef TRACE_NODE_MIN
+#define TRACE_NODE_MIN 24         // leave the node loop when fewer lanes than this are still at interior nodes
+#endif                            // while others wait at a leaf (keeps both phases well populated)
 #define SHADE_BLOCK 512
 #define SHADE_WAVES (SHADE_BLOCK / 64)
 #define CUR_DONE ((int)0x80000000)
@@ -86,37 +88,83 @@ __global__ __launch_bounds__(256) void k_raygen(DevCamera cam, DevFrame fr, DevQ
 
 // =================================================================================================
 // traversal machinery shared by the closest-hit and any-hit kernels
-template <bool LDS_STACK> struct Stack;
-template <> struct Stack<true> {    // per-lane stack in LDS, stride 64 dwords: bank = lane at every depth
-  int* base; int sp;
-  PT_DEV void init(int* lds_base) { base = lds_base; sp = 0; }
+//
+// Per-lane stack of (child code, entry distance) pairs.  The first `L` entries live in LDS
+// (8-byte entries, stride 64 lanes: ds_read/write_b64 is conflict-free at every mix of depths), deeper
+// entries — rare — go to a global overflow slab laid out [wave][depth][lane].
+struct WStack {
+  uint2* lds; uint2* ovf; int sp; int L;
+  PT_DEV void init(uint2* lds_base, uint2* ovf_base, int l) { lds = lds_base; ovf = ovf_base; sp = 0; L = l; }
   PT_DEV void reset() { sp = 0; }
-  PT_DEV void push(int v) { base[sp * 64] = v; ++sp; }
-  PT_DEV int pop() { --sp; return base[sp * 64]; }
-  PT_DEV bool empty() const { return sp == 0; }
-};
-template <> struct Stack<false> {   // deep trees: private (scratch) stack
-  int st[SCRATCH_STACK_DEPTH]; int sp;
-  PT_DEV void init(int*) { sp = 0; }
-  PT_DEV void reset() { sp = 0; }
-  PT_DEV void push(int v) { st[sp] = v; ++sp; }
-  PT_DEV int pop() { --sp; return st[sp]; }
+  PT_DEV void push(int code, uint32_t key) {
+    const uint2 e = make_uint2((uint32_t)code, key & 0xfffffffcu);
+    if (sp < L) lds[sp * 64] = e; else ovf[(sp - L) * 64] = e;
+    ++sp;
+  }
+  PT_DEV uint2 pop() { --sp; return sp < L ? lds[sp * 64] : ovf[(sp - L) * 64]; }
   PT_DEV bool empty() const { return sp == 0; }
 };
 
-struct Node16 { float4 q0, q1, q2, q3; };
+PT_DEV void cswap(uint32_t& ka, int& ca, uint32_t& kb, int& cb) {
+  const bool s = kb < ka;
+  const uint32_t tk = s ? kb : ka; const int tc = s ? cb : ca;
+  kb = s ? ka : kb; cb = s ? ca : cb;
+  ka = tk; ca = tc;
+}
+
+#define KEY_MISS 0xffffffffu
+#define CODE_EMPTY ((int)0x80000000)
+
+// Per-ray constants for the 4-wide slab test: which float4 of the node holds the near / far plane of
+// each axis (chosen by the sign of the direction), so that min/max of the two plane distances needs no
+// instruction.  Identical values to min(t0,t1)/max(t0,t1): fma is monotonic in the plane coordinate.
+struct Octant { int nx, ny, nz; };
+PT_DEV Octant make_octant(const ray_t& r) {
+  Octant o;
+  o.nx = r.inv.x >= 0.0f ? 0 : 3; o.ny = r.inv.y >= 0.0f ? 1 : 4; o.nz = r.inv.z >= 0.0f ? 2 : 5;
+  return o;
+}
+
+// One step at wide node `cur`: slab-test the four children against [tmin, tlimit], order the hits by
+// key = (bits(tnear) & ~3) | slot, push all but the nearest (farthest first), return the nearest child's
+// code or CODE_EMPTY when nothing was hit.  Unused slots hold an inverted box (lo = +3e38, hi = -3e38),
+// which the near/far-plane form of the slab test can never hit, so no validity test is needed.
+// Instruction budget per step: 7 dwordx4 loads, 12 v_pk_fma_f32, 8 v_max3/v_min3 + 8 v_max/v_min,
+// 4 compares + key builds, a 5-comparator sorting network.
+typedef float float2v __attribute__((ext_vector_type(2)));
+PT_DEV float2v pk_fma(float2v a, float2v b, float2v c) { return __builtin_elementwise_fma(a, b, c); }
+PT_DEV float hw_max(float a, float b) { return __builtin_fmaxf(a, b); }   // v_max_f32 / v_max3_f32: same value as
+PT_DEV float hw_min(float a, float b) { return __builtin_fminf(a, b); }   // the ternary for non-NaN operands (±0 aside)
 
 template <bool NODELETS>
-PT_DEV Node16 load_node(const DevScene& sc, const float4* lds_nodes, int cur) {
-  Node16 n;
-  if (NODELETS && (uint32_t)cur < sc.n_nodelets) {
-    const float4* p = lds_nodes + (size_t)cur * 4;
-    n.q0 = p[0]; n.q1 = p[1]; n.q2 = p[2]; n.q3 = p[3];
-  } else {
-    const float4* p = sc.nodes + (size_t)cur * 4;
-    n.q0 = p[0]; n.q1 = p[1]; n.q2 = p[2]; n.q3 = p[3];
-  }
-  return n;
+PT_DEV int wide_step(const DevScene& sc, const float4* lds_nodes, int cur, const ray_t& r, const Octant& oc, float tmin, float tlimit, WStack& st) {
+  const float4* p = (NODELETS && (uint32_t)cur < sc.n_nodelets) ? lds_nodes + (size_t)cur * 8 : sc.nodes + (size_t)cur * 8;
+  const float4 nxq = p[oc.nx], nyq = p[oc.ny], nzq = p[oc.nz];
+  const float4 fxq = p[3 - oc.nx], fyq = p[5 - oc.ny], fzq = p[7 - oc.nz];
+  const float4 cq = p[6];
+  const float2v ix = {r.inv.x, r.inv.x}, iy = {r.inv.y, r.inv.y}, iz = {r.inv.z, r.inv.z};
+  const float2v ox = {-r.ood.x, -r.ood.x}, oy = {-r.ood.y, -r.ood.y}, oz = {-r.ood.z, -r.ood.z};
+  const float2v nx01 = pk_fma(float2v{nxq.x, nxq.y}, ix, ox), nx23 = pk_fma(float2v{nxq.z, nxq.w}, ix, ox);
+  const float2v ny01 = pk_fma(float2v{nyq.x, nyq.y}, iy, oy), ny23 = pk_fma(float2v{nyq.z, nyq.w}, iy, oy);
+  const float2v nz01 = pk_fma(float2v{nzq.x, nzq.y}, iz, oz), nz23 = pk_fma(float2v{nzq.z, nzq.w}, iz, oz);
+  const float2v fx01 = pk_fma(float2v{fxq.x, fxq.y}, ix, ox), fx23 = pk_fma(float2v{fxq.z, fxq.w}, ix, ox);
+  const float2v fy01 = pk_fma(float2v{fyq.x, fyq.y}, iy, oy), fy23 = pk_fma(float2v{fyq.z, fyq.w}, iy, oy);
+  const float2v fz01 = pk_fma(float2v{fzq.x, fzq.y}, iz, oz), fz23 = pk_fma(float2v{fzq.z, fzq.w}, iz, oz);
+  const float tn[4] = {hw_max(hw_max(hw_max(nx01.x, ny01.x), nz01.x), tmin), hw_max(hw_max(hw_max(nx01.y, ny01.y), nz01.y), tmin),
+                       hw_max(hw_max(hw_max(nx23.x, ny23.x), nz23.x), tmin), hw_max(hw_max(hw_max(nx23.y, ny23.y), nz23.y), tmin)};
+  const float tf[4] = {hw_min(hw_min(hw_min(fx01.x, fy01.x), fz01.x), tlimit), hw_min(hw_min(hw_min(fx01.y, fy01.y), fz01.y), tlimit),
+                       hw_min(hw_min(hw_min(fx23.x, fy23.x), fz23.x), tlimit), hw_min(hw_min(hw_min(fx23.y, fy23.y), fz23.y), tlimit)};
+  int c[4] = {__float_as_int(cq.x), __float_as_int(cq.y), __float_as_int(cq.z), __float_as_int(cq.w)};
+  uint32_t k[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) k[i] = (tn[i] <= tf[i]) ? ((__float_as_uint(tn[i]) & 0xfffffffcu) | (uint32_t)i) : KEY_MISS;
+  cswap(k[0], c[0], k[1], c[1]); cswap(k[2], c[2], k[3], c[3]);
+  cswap(k[0], c[0], k[2], c[2]); cswap(k[1], c[1], k[3], c[3]);
+  cswap(k[1], c[1], k[2], c[2]);
+  if (k[3] != KEY_MISS) st.push(c[3], k[3]);
+  if (k[2] != KEY_MISS) st.push(c[2], k[2]);
+  if (k[1] != KEY_MISS) st.push(c[1], k[1]);
+  return k[0] != KEY_MISS ? c[0] : CODE_EMPTY;
 }
 
 // Wave-private reservoir of input slots: one atomic fetches TRACE_CHUNK consecutive rays, idle lanes are
@@ -142,31 +190,44 @@ struct Reservoir {
   }
 };
 
+#define CUR_FINISHED (CUR_DONE + 1)
+
+#ifdef PT_DIAG
+#define DIAG_ITER(var) do { const uint64_t m_ = __ballot(true); if ((int)lane == __ffsll((unsigned long long)m_) - 1) ++(var); } while (0)
+#else
+#define DIAG_ITER(var) do { } while (0)
+#endif
+
 // =================================================================================================
-// P3 closest-hit traversal + triangle intersection: persistent waves, dynamic lane refill.
-// Near child first, ties to child 0; closest hit = lexicographic minimum of (t, original primitive id).
+// P3 closest-hit traversal + triangle intersection: persistent waves, dynamic lane refill, 4-wide LBVH.
+// Children are visited nearest first (order key above); a popped entry whose entry distance exceeds the
+// current best hit is skipped.  Closest hit = lexicographic minimum of (t, original primitive id).
 // The hit record (t, prim | class<<28, u, v) is written IN PLACE at the ray's slot (miss: prim = -1).
 // CULL: R6 back-face culling + per-ray [tmin,tmax] from B.zw (raster-compat primary rays).
-template <bool CULL, bool LDS_STACK, bool NODELETS>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DevScene sc, DevQueues q, int qi, uint32_t stack_depth) {
+template <bool CULL, bool NODELETS>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DevScene sc, DevQueues q, int qi, int stack_lds) {
   extern __shared__ float4 lds_raw[];
-  float4* lds_nodes = lds_raw;                                       // [n_nodelets × 64 B]
-  int* lds_stack = reinterpret_cast<int*>(lds_raw + (NODELETS ? (size_t)sc.n_nodelets * 4 : 0));   // [waves][depth][64]
+  float4* lds_nodes = lds_raw;                                                       // [n_nodelets × 128 B]
+  uint2* lds_stack = reinterpret_cast<uint2*>(lds_raw + (NODELETS ? (size_t)sc.n_nodelets * 8 : 0));   // [waves][L][64]
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
   if (NODELETS) {
-    for (uint32_t i = threadIdx.x; i < sc.n_nodelets * 4u; i += TRACE_BLOCK) lds_nodes[i] = sc.nodes[i];
+    for (uint32_t i = threadIdx.x; i < sc.n_nodelets * 8u; i += TRACE_BLOCK) lds_nodes[i] = sc.nodes[i];
     __syncthreads();
   }
   const RayQ rq = q.ray[qi];
   const uint32_t n = q.cnt[CNT_RAYS];
   uint32_t nv = 0, nt = 0, nr = 0, nh = 0;
+  uint32_t d_node = 0, d_tri = 0, d_leaf = 0, d_round = 0;
+  (void)d_node; (void)d_tri; (void)d_leaf; (void)d_round;
   Reservoir res; res.init();
-  Stack<LDS_STACK> st;
-  st.init(lds_stack + wave * (stack_depth * 64u) + lane);
+  WStack st;
+  st.init(lds_stack + (size_t)wave * (size_t)stack_lds * 64u + lane,
+          sc.stack_ovf + ((size_t)(blockIdx.x * TRACE_WAVES + wave) * sc.ovf_depth) * 64u + lane, stack_lds);
   int cur = CUR_DONE;
   uint32_t ri = 0;
   ray_t r = make_ray(V3(0, 0, 0), V3(0, 0, 1));
+  Octant oc = make_octant(r);
   float tmin = 0.0f, best_t = PT_T_INF, best_u = 0.0f, best_v = 0.0f;
   int best_prim = 0x7fffffff, best_cls = 0;
   bool found = false;
@@ -175,6 +236,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DevScene sc, DevQ
     if (res.refill(&q.cnt[CNT_WORK_TRACE], n, cur == CUR_DONE, lane, ri)) {
       const float4 A = rq.A[ri], Bq = rq.B[ri];
       r = make_ray(V3(A.x, A.y, A.z), V3(A.w, Bq.x, Bq.y));
+      oc = make_octant(r);
       tmin = CULL ? Bq.z : 0.0f;
       best_t = CULL ? Bq.w : PT_T_INF; best_u = 0.0f; best_v = 0.0f; best_prim = 0x7fffffff; best_cls = 0; found = false;
       st.reset();
@@ -186,28 +248,29 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DevScene sc, DevQ
       continue;
     }
     // ---- traverse until enough lanes have finished to make a refill worthwhile ----
+    DIAG_ITER(d_round);
     do {
-      while (cur >= 0) {
-        const Node16 nd = load_node<NODELETS>(sc, lds_nodes, cur);
-        ++nv;
-        float t0, t1;
-        const bool h0 = box_hit(r, nd.q0.x, nd.q0.y, nd.q0.z, nd.q0.w, nd.q1.x, nd.q1.y, tmin, best_t, t0);
-        const bool h1 = box_hit(r, nd.q1.z, nd.q1.w, nd.q2.x, nd.q2.y, nd.q2.z, nd.q2.w, tmin, best_t, t1);
-        const int c0 = __float_as_int(nd.q3.x), c1 = __float_as_int(nd.q3.y);
-        if (h0 && h1) {
-          int first = c0, second = c1;
-          if (t1 < t0) { first = c1; second = c0; }
-          st.push(second);
-          cur = first;
-        } else if (h0) cur = c0;
-        else if (h1) cur = c1;
-        else cur = st.empty() ? CUR_DONE + 1 : st.pop();
+      for (;;) {
+        const uint64_t mn = __ballot(cur >= 0);
+        if (!mn) break;
+        if (__popcll(mn) < TRACE_NODE_MIN && __ballot(cur < 0 && cur > CUR_FINISHED)) break;   // few walkers, leaves waiting
+        if (cur >= 0) {
+          DIAG_ITER(d_node);
+          ++nv;
+          cur = wide_step<NODELETS>(sc, lds_nodes, cur, r, oc, tmin, best_t, st);
+          if (cur == CODE_EMPTY) {                                     // nothing hit: pop, skipping culled entries
+            cur = CUR_FINISHED;
+            while (!st.empty()) { const uint2 e = st.pop(); if (__uint_as_float(e.y) > best_t) continue; cur = (int)e.x; break; }
+          }
+        }
       }
-      if (cur > CUR_DONE + 1) {                                        // a leaf
+      if (cur < 0 && cur > CUR_FINISHED) {                                        // a leaf
         const uint32_t code = (uint32_t)~cur;
         const uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
+        DIAG_ITER(d_leaf);
         for (uint32_t k = first; k < first + count; ++k) {
           const float4 a = sc.tris[(size_t)k * 3 + 0], b = sc.tris[(size_t)k * 3 + 1], c = sc.tris[(size_t)k * 3 + 2];
+          DIAG_ITER(d_tri);
           ++nt;
           float t, u, v;
           if (!tri_test<CULL>(r, V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), t, u, v)) continue;
@@ -216,9 +279,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DevScene sc, DevQ
             best_t = t; best_u = u; best_v = v; best_prim = pid; best_cls = __float_as_int(b.w); found = true;
           }
         }
-        cur = st.empty() ? CUR_DONE + 1 : st.pop();
+        cur = CUR_FINISHED;
+        while (!st.empty()) { const uint2 e = st.pop(); if (__uint_as_float(e.y) > best_t) continue; cur = (int)e.x; break; }
       }
-      if (cur == CUR_DONE + 1) {                                       // this lane's ray is finished: publish in place
+      if (cur == CUR_FINISHED) {                                       // this lane's ray is finished: publish in place
         q.hit[ri] = make_float4(found ? best_t : -1.0f, __int_as_float(found ? (best_prim | (best_cls << HIT_CLASS_SHIFT)) : -1), best_u, best_v);
         nh += found ? 1u : 0u;
         cur = CUR_DONE;
@@ -230,36 +294,46 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DevScene sc, DevQ
     atomicAdd(&q.stats[ST_NODES_C], c_nodes); atomicAdd(&q.stats[ST_TRIS_C], c_tris);
     atomicAdd(&q.stats[ST_SEGMENTS], c_rays); atomicAdd(&q.stats[ST_HITS], c_hits);
   }
+#ifdef PT_DIAG
+  {
+    unsigned long long a0 = wave_sum(d_node), a1 = wave_sum(d_tri), a2 = wave_sum(d_leaf), a3 = wave_sum(d_round);
+    if (lane == 0) { atomicAdd(&q.stats[ST_DIAG_NODE_ITERS], a0); atomicAdd(&q.stats[ST_DIAG_TRI_ITERS], a1); atomicAdd(&q.stats[ST_DIAG_LEAF_VISITS], a2); atomicAdd(&q.stats[ST_DIAG_ROUNDS], a3); }
+  }
+#endif
 }
 
 // =================================================================================================
-// P4 any-hit traversal for the NEE shadow rays (same machinery); an unoccluded ray adds its contribution
-// to the path's radiance word (single owner: one shadow ray per path per bounce).
-template <bool LDS_STACK, bool NODELETS, bool DEBUG_OUT>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_any(DevScene sc, DevQueues q, uint32_t stack_depth, uint8_t* debug_out) {
+// P4 any-hit traversal for the NEE shadow rays (same machinery, no distance culling: the interval is
+// fixed); an unoccluded ray adds its contribution to the path's radiance word (single owner: one shadow
+// ray per path per bounce).
+template <bool NODELETS, bool DEBUG_OUT>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_any(DevScene sc, DevQueues q, int stack_lds, uint8_t* debug_out) {
   extern __shared__ float4 lds_raw[];
   float4* lds_nodes = lds_raw;
-  int* lds_stack = reinterpret_cast<int*>(lds_raw + (NODELETS ? (size_t)sc.n_nodelets * 4 : 0));
+  uint2* lds_stack = reinterpret_cast<uint2*>(lds_raw + (NODELETS ? (size_t)sc.n_nodelets * 8 : 0));
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
   if (NODELETS) {
-    for (uint32_t i = threadIdx.x; i < sc.n_nodelets * 4u; i += TRACE_BLOCK) lds_nodes[i] = sc.nodes[i];
+    for (uint32_t i = threadIdx.x; i < sc.n_nodelets * 8u; i += TRACE_BLOCK) lds_nodes[i] = sc.nodes[i];
     __syncthreads();
   }
   const uint32_t n = q.cnt[CNT_SHADOW];
   uint32_t nv = 0, nt = 0, nr = 0;
   Reservoir res; res.init();
-  Stack<LDS_STACK> st;
-  st.init(lds_stack + wave * (stack_depth * 64u) + lane);
+  WStack st;
+  st.init(lds_stack + (size_t)wave * (size_t)stack_lds * 64u + lane,
+          sc.stack_ovf + ((size_t)(blockIdx.x * TRACE_WAVES + wave) * sc.ovf_depth) * 64u + lane, stack_lds);
   int cur = CUR_DONE;
   uint32_t ri = 0, path = 0;
   ray_t r = make_ray(V3(0, 0, 0), V3(0, 0, 1));
+  Octant oc = make_octant(r);
   float tmax = 0.0f;
   bool occluded = false;
   for (;;) {
     if (res.refill(&q.cnt[CNT_WORK_SHADOW], n, cur == CUR_DONE, lane, ri)) {
       const float4 A = q.shadow.A[ri], Bq = q.shadow.B[ri];
       r = make_ray(V3(A.x, A.y, A.z), V3(A.w, Bq.x, Bq.y));
+      oc = make_octant(r);
       tmax = Bq.z; path = __float_as_uint(Bq.w);
       occluded = false;
       st.reset();
@@ -271,23 +345,17 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_any(DevScene sc, DevQueue
       continue;
     }
     do {
-      while (cur >= 0) {
-        const Node16 nd = load_node<NODELETS>(sc, lds_nodes, cur);
-        ++nv;
-        float t0, t1;
-        const bool h0 = box_hit(r, nd.q0.x, nd.q0.y, nd.q0.z, nd.q0.w, nd.q1.x, nd.q1.y, 0.0f, tmax, t0);
-        const bool h1 = box_hit(r, nd.q1.z, nd.q1.w, nd.q2.x, nd.q2.y, nd.q2.z, nd.q2.w, 0.0f, tmax, t1);
-        const int c0 = __float_as_int(nd.q3.x), c1 = __float_as_int(nd.q3.y);
-        if (h0 && h1) {
-          int first = c0, second = c1;
-          if (t1 < t0) { first = c1; second = c0; }
-          st.push(second);
-          cur = first;
-        } else if (h0) cur = c0;
-        else if (h1) cur = c1;
-        else cur = st.empty() ? CUR_DONE + 1 : st.pop();
+      for (;;) {
+        const uint64_t mn = __ballot(cur >= 0);
+        if (!mn) break;
+        if (__popcll(mn) < TRACE_NODE_MIN && __ballot(cur < 0 && cur > CUR_FINISHED)) break;
+        if (cur >= 0) {
+          ++nv;
+          cur = wide_step<NODELETS>(sc, lds_nodes, cur, r, oc, 0.0f, tmax, st);
+          if (cur == CODE_EMPTY) cur = st.empty() ? CUR_FINISHED : (int)st.pop().x;
+        }
       }
-      if (cur > CUR_DONE + 1) {
+      if (cur < 0 && cur > CUR_FINISHED) {
         const uint32_t code = (uint32_t)~cur;
         const uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
         for (uint32_t k = first; k < first + count; ++k) {
@@ -299,9 +367,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_any(DevScene sc, DevQueue
             break;
           }
         }
-        cur = (occluded || st.empty()) ? CUR_DONE + 1 : st.pop();
+        cur = (occluded || st.empty()) ? CUR_FINISHED : (int)st.pop().x;
       }
-      if (cur == CUR_DONE + 1) {
+      if (cur == CUR_FINISHED) {
         if (DEBUG_OUT) debug_out[ri] = occluded ? 1 : 0;
         else if (!occluded) {
           const float4 Cq = q.shadow.C[ri];
@@ -597,10 +665,8 @@ __global__ __launch_bounds__(256) void k_tonemap(const float4* radiance, uint32_
 
 // =================================================================================================
 // launchers
-static size_t trace_lds_bytes(const LaunchCfg& cfg, const DevScene& sc, bool nodelets) {
-  size_t b = nodelets ? (size_t)sc.n_nodelets * 64 : 0;
-  if (cfg.lds_stack) b += (size_t)TRACE_WAVES * cfg.stack_depth * 64 * 4;
-  return b;
+static size_t trace_lds_bytes(const LaunchCfg& cfg, const DevScene& sc) {
+  return (size_t)sc.n_nodelets * 128 + (size_t)TRACE_WAVES * cfg.stack_lds * 64 * 8;
 }
 
 void pt_launch_set_counts(hipStream_t s, const DevQueues& q, uint32_t n_rays, uint32_t n_shadow) { hipLaunchKernelGGL(k_set_counts, dim3(1), dim3(64), 0, s, q.cnt, n_rays, n_shadow); }
@@ -616,32 +682,20 @@ void pt_launch_raygen(hipStream_t s, const DevCamera& cam, const DevFrame& fr, c
 void pt_launch_trace_closest(hipStream_t s, const LaunchCfg& cfg, const DevScene& sc, const DevQueues& q, int qi, bool cull) {
   const bool nodelets = sc.n_nodelets > 0;
   const dim3 grid((unsigned)(cfg.n_cu * cfg.trace_blocks_per_cu));
-  const size_t lds = trace_lds_bytes(cfg, sc, nodelets);
-  const uint32_t sd = (uint32_t)cfg.stack_depth;
-#define TC(C, L, N) hipLaunchKernelGGL((k_trace_closest<C, L, N>), grid, dim3(TRACE_BLOCK), lds, s, sc, q, qi, sd)
-  if (cull) {
-    if (cfg.lds_stack) { if (nodelets) TC(true, true, true); else TC(true, true, false); }
-    else { if (nodelets) TC(true, false, true); else TC(true, false, false); }
-  } else {
-    if (cfg.lds_stack) { if (nodelets) TC(false, true, true); else TC(false, true, false); }
-    else { if (nodelets) TC(false, false, true); else TC(false, false, false); }
-  }
+  const size_t lds = trace_lds_bytes(cfg, sc);
+#define TC(C, N) hipLaunchKernelGGL((k_trace_closest<C, N>), grid, dim3(TRACE_BLOCK), lds, s, sc, q, qi, cfg.stack_lds)
+  if (cull) { if (nodelets) TC(true, true); else TC(true, false); }
+  else { if (nodelets) TC(false, true); else TC(false, false); }
 #undef TC
 }
 
 void pt_launch_trace_any(hipStream_t s, const LaunchCfg& cfg, const DevScene& sc, const DevQueues& q, uint8_t* debug_out) {
   const bool nodelets = sc.n_nodelets > 0;
   const dim3 grid((unsigned)(cfg.n_cu * cfg.trace_blocks_per_cu));
-  const size_t lds = trace_lds_bytes(cfg, sc, nodelets);
-  const uint32_t sd = (uint32_t)cfg.stack_depth;
-#define TA(L, N, D) hipLaunchKernelGGL((k_trace_any<L, N, D>), grid, dim3(TRACE_BLOCK), lds, s, sc, q, sd, debug_out)
-  if (debug_out) {
-    if (cfg.lds_stack) { if (nodelets) TA(true, true, true); else TA(true, false, true); }
-    else { if (nodelets) TA(false, true, true); else TA(false, false, true); }
-  } else {
-    if (cfg.lds_stack) { if (nodelets) TA(true, true, false); else TA(true, false, false); }
-    else { if (nodelets) TA(false, true, false); else TA(false, false, false); }
-  }
+  const size_t lds = trace_lds_bytes(cfg, sc);
+#define TA(N, D) hipLaunchKernelGGL((k_trace_any<N, D>), grid, dim3(TRACE_BLOCK), lds, s, sc, q, cfg.stack_lds, debug_out)
+  if (debug_out) { if (nodelets) TA(true, true); else TA(false, true); }
+  else { if (nodelets) TA(true, false); else TA(false, false); }
 #undef TA
 }
 

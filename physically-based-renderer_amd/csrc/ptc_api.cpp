@@ -149,16 +149,28 @@ struct ScopedSpan {   // records a start/stop event pair around launches on the 
   ~ScopedSpan() { if (on) { (void)hipEventRecord(s.b, c->stream); c->spans.push_back(s); } }
 };
 
-void configure_launch(ptc_ctx* c) {
-  // LDS budget per trace block: nodelets + per-wave stacks.  160 KiB per CU, at most 8 blocks of 4 waves.
-  // The per-lane traversal stack needs max_depth+1 entries (one deferred sibling per interior level).
-  c->cfg.stack_depth = (int)c->built.max_depth + 1;
-  c->cfg.lds_stack = c->cfg.stack_depth <= 40;
-  size_t lds = (size_t)c->built.n_nodelets * 64 + (c->cfg.lds_stack ? (size_t)4 * c->cfg.stack_depth * 64 * 4 : 0);
-  int per_cu = 8;
-  if (lds > 0) { per_cu = (int)((160u * 1024u) / lds); if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1; }
-  if (const char* e = std::getenv("PTC_TRACE_BLOCKS_PER_CU")) { int v = std::atoi(e); if (v >= 1 && v <= 8) per_cu = v; }
+int configure_launch(ptc_ctx* c) {
+  // Traversal stack: a 4-wide node defers up to 3 children per level, so a ray needs at most
+  // 3·(depth+1) entries.  `stack_lds` of them live in LDS (8 B each, 512 B per level and wave), the rest in
+  // a global overflow slab.  LDS per 256-thread block = nodelets·128 B + 4 waves·stack_lds·512 B.
+  const int need = 3 * ((int)c->built.max_depth + 1);
+  int l = 12;
+  if (const char* e = std::getenv("PTC_STACK_LDS")) { int v = std::atoi(e); if (v >= 1 && v <= 64) l = v; }
+  if (l > need) l = need;
+  c->cfg.stack_lds = l;
+  const size_t lds = (size_t)c->built.n_nodelets * 128 + (size_t)4 * l * 512;
+  int per_cu = (int)((160u * 1024u) / lds);
+  if (per_cu > 8) per_cu = 8;
+  if (per_cu < 1) return fail(c, PTC_E_ARG, "configure_launch: nodelets + stack exceed the 160 KiB of LDS");
+  if (const char* e = std::getenv("PTC_TRACE_BLOCKS_PER_CU")) { int v = std::atoi(e); if (v >= 1 && v <= per_cu) per_cu = v; }
   c->cfg.trace_blocks_per_cu = per_cu;
+  const uint32_t ovf = (uint32_t)(need - l > 0 ? need - l : 1);
+  const size_t waves = (size_t)c->cfg.n_cu * 8 * 4;               // upper bound on resident trace waves
+  uint2* p = nullptr;
+  int rc = dev_alloc(c, c->scene_allocs, &p, waves * ovf * 64);
+  if (rc) return rc;
+  c->dsc.stack_ovf = p; c->dsc.ovf_depth = ovf;
+  return PTC_OK;
 }
 
 // One wavefront batch of n samples per owned pixel, fully asynchronous.
@@ -226,8 +238,8 @@ ptc_ctx* ptc_create(int device_id) {
   c->device = device_id;
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { g_create_error = std::string("ptc_create: ") + hipGetErrorString(e); delete c; return nullptr; }
   c->cfg.n_cu = prop.multiProcessorCount;
-  c->cfg.trace_blocks_per_cu = 5;
-  c->cfg.lds_stack = true;
+  c->cfg.trace_blocks_per_cu = 4;
+  c->cfg.stack_lds = 12;
   if (const char* s = std::getenv("PTC_NODELETS")) c->nodelet_budget = (uint32_t)std::strtoul(s, nullptr, 10);
   if (const char* s = std::getenv("PTC_BATCH_PATHS")) { size_t v = std::strtoull(s, nullptr, 10); if (v >= 1024) c->max_batch_paths = v; }
   if (const char* s = std::getenv("PTC_TIMING")) c->timing = std::atoi(s) != 0;
@@ -351,7 +363,7 @@ int ptc_scene_commit(ptc_ctx* c) {
   if (rc) { free_all(c->scene_allocs); return PTC_E_DEVICE; }
   d.n_lights = B.n_lights; d.n_nodelets = B.n_nodelets; d.ray_eps = B.ray_eps;
   c->dsc = d;
-  configure_launch(c);
+  { int rc2 = configure_launch(c); if (rc2) { free_all(c->scene_allocs); return rc2; } }
   c->committed = true; c->in_frame = false;
   std::memset(&c->stats, 0, sizeof c->stats);
   c->stats.seconds_commit = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -506,8 +518,8 @@ int ptc_get_stats(ptc_ctx* c, ptc_stats* out) {
     s.node_visits_closest = st[ST_NODES_C]; s.tri_tests_closest = st[ST_TRIS_C];
     s.node_visits_any = st[ST_NODES_A]; s.tri_tests_any = st[ST_TRIS_A];
     // SURVEY §8d byte model with this build's record sizes (DESIGN.md §"Algorithmic bytes")
-    s.algorithmic_bytes = s.segments * (2u * 56u + 2u * 16u) + s.node_visits_closest * 64u + s.tri_tests_closest * 48u + s.hits * 176u +
-                          s.shadow_rays * (2u * 44u) + s.node_visits_any * 64u + s.tri_tests_any * 48u + s.paths * (2u * 16u);
+    s.algorithmic_bytes = s.segments * (2u * 56u + 2u * 16u) + s.node_visits_closest * 128u + s.tri_tests_closest * 48u + s.hits * 176u +
+                          s.shadow_rays * (2u * 44u) + s.node_visits_any * 128u + s.tri_tests_any * 48u + s.paths * (2u * 16u);
   }
   collect_times(c);
   *out = c->stats;
@@ -586,6 +598,19 @@ int ptc_debug_get_flat_scene(ptc_ctx* c, uint32_t* n_verts, uint32_t* n_tris, pt
   if (indices) std::memcpy(indices, B.widx.data(), B.widx.size() * 4);
   if (tri_material) std::memcpy(tri_material, B.tri_mat.data(), B.tri_mat.size() * 4);
   return PTC_OK;
+}
+
+int ptc_debug_get_counters(ptc_ctx* c, uint64_t* out, int n) {
+  if (!c) return PTC_E_ARG;
+  if (c->device < 0) return fail(c, PTC_E_DEVICE, "this context has no device (PTC_DEVICE_NONE): the call needs a gfx950 GPU; there is no CPU path");
+  if (!out || n <= 0) return fail(c, PTC_E_ARG, "debug_get_counters: bad argument");
+  if (!c->q.stats) return fail(c, PTC_E_STATE, "debug_get_counters: nothing rendered");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  unsigned long long st[ST_N];
+  HIP_TRY(c, hipMemcpy(st, c->q.stats, sizeof st, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; ++i) out[i] = i < ST_N ? st[i] : 0;
+  return ST_N;
 }
 
 int ptc_debug_get_bvh(ptc_ctx* c, uint32_t* n_nodes, uint32_t* n_tris, float* nodes, float* tris) {

@@ -9,7 +9,7 @@
 
 // ---- HBM layout of the committed scene (DESIGN.md §"Data layout in HBM") -----------------------
 struct DevScene {
-  const float4* nodes;        // 4 × float4 per interior node (64 B): both child boxes + child codes
+  const float4* nodes;        // 8 × float4 per 4-wide node (128 B, SoA): lo.x lo.y lo.z hi.x hi.y hi.z code pad
   const float4* tris;         // 3 × float4 per triangle in Morton order (48 B): (v0,prim) (e1,class) (e2,-)
   const float* wverts;        // world-space ptc_vertex records, 12 floats each (R1 layout)
   const uint32_t* widx;       // 3 per original primitive id
@@ -20,6 +20,8 @@ struct DevScene {
   const float* cdf;           // emitter power cdf
   uint32_t n_lights;
   uint32_t n_nodelets;        // leading nodes (BFS order) that the trace kernels stage in LDS
+  uint2* stack_ovf;           // per-lane traversal-stack overflow: [wave][ovf_depth][64] entries of (code, tnear)
+  uint32_t ovf_depth;
   float ray_eps;
 };
 
@@ -52,9 +54,12 @@ struct DevQueues {
 };
 
 enum { CNT_RAYS = 0, CNT_NEXT, CNT_SHADOW, CNT_WORK_TRACE, CNT_WORK_SHADE, CNT_WORK_SHADOW, CNT_N };
-enum { ST_SEGMENTS = 0, ST_SHADOW, ST_HITS, ST_NODES_C, ST_TRIS_C, ST_NODES_A, ST_TRIS_A, ST_N };
+enum { ST_SEGMENTS = 0, ST_SHADOW, ST_HITS, ST_NODES_C, ST_TRIS_C, ST_NODES_A, ST_TRIS_A,
+       // wave-level iteration counts of the trace kernels' loops (filled only by a -DPT_DIAG build): lane
+       // utilisation of a phase = lane-level count / (64 x wave-level count)
+       ST_DIAG_NODE_ITERS, ST_DIAG_TRI_ITERS, ST_DIAG_LEAF_VISITS, ST_DIAG_ROUNDS, ST_DIAG_REFILLED, ST_N };
 
-struct LaunchCfg { int n_cu; int trace_blocks_per_cu; bool lds_stack; int stack_depth; };
+struct LaunchCfg { int n_cu; int trace_blocks_per_cu; int stack_lds; /* stack entries kept in LDS per lane */ };
 
 // ---- kernel launchers (pt_kernels.hip) ------------------------------------------------------------
 void pt_launch_set_counts(hipStream_t, const DevQueues&, uint32_t n_rays, uint32_t n_shadow);
@@ -79,7 +84,7 @@ struct HostBuilt {
   std::vector<uint32_t> widx;
   std::vector<int32_t> tri_mat;
   std::vector<int32_t> prim_light;
-  std::vector<float> nodes;      // 16 floats per node
+  std::vector<float> nodes;      // 32 floats per 4-wide node
   std::vector<float> tris;       // 12 floats per sorted triangle
   std::vector<float> mats;       // 12 floats per material
   std::vector<float> lights;     // 20 floats per emitter

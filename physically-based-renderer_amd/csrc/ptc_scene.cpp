@@ -260,93 +260,140 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
     o[8] = c[0] - a[0]; o[9] = c[1] - a[1]; o[10] = c[2] - a[2]; o[11] = 0.0f;
   }
   // ---- hierarchy --------------------------------------------------------------------------------------
-  // Output node = 16 floats: lo0 hi0 lo1 hi1 (12) + c0 c1 pad pad.  Subtrees of <= kLeafMax triangles
-  // collapse into leaves.  Layout: the first `nodelet_budget` nodes in breadth-first order (they are
-  // staged in LDS by the trace kernels), the remainder depth-first under each frontier node.
+  // Binary radix tree (Karras) → subtrees of <= kLeafMax triangles collapse into leaves → 4-wide collapse,
+  // greedy by surface area: a node starts from its two binary children and keeps replacing the interior
+  // child with the largest half-area (ties: lowest slot) by that child's two children, in place, until it
+  // has 4 children or only leaves are left.
+  // Output node = 32 floats (128 B, one L2 line), SoA: lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4]
+  // code[4] pad[4]; code >= 0 wide node index, < 0 leaf ~(first | (count-1)<<28), kEmpty unused slot.
+  // Layout: the first `nodelet_budget` nodes breadth-first (the trace kernels stage them in LDS), the rest
+  // depth-first below them.
+  constexpr int32_t kEmpty = (int32_t)0x80000000;
+  struct WChild { bool leaf; uint32_t lo, hi; int32_t radix; Box box; };
+  std::vector<RadixNode> radix;
+  std::vector<Box> radix_box;
   auto range_box = [&](uint32_t lo, uint32_t hi) {
     Box b = empty_box();
     for (uint32_t i = lo; i <= hi; ++i) grow(b, tbox[(uint32_t)(keys[i] & 0xffffffffu)]);
     return b;
   };
-  struct Child { bool leaf; uint32_t lo, hi; int32_t radix; };
-  std::vector<RadixNode> radix;
   auto child_of = [&](int32_t link) {
-    Child c;
-    if (link < 0) { c.leaf = true; c.lo = c.hi = (uint32_t)~link; c.radix = -1; return c; }
+    WChild c;
+    if (link < 0) { c.leaf = true; c.lo = c.hi = (uint32_t)~link; c.radix = -1; c.box = range_box(c.lo, c.hi); return c; }
     const RadixNode& r = radix[(size_t)link];
     c.lo = r.lo; c.hi = r.hi; c.radix = link;
     c.leaf = (r.hi - r.lo + 1u) <= (uint32_t)kLeafMax;
+    c.box = radix_box[(size_t)link];
     return c;
   };
-  auto put_node = [&](uint32_t idx, const Box& b0, const Box& b1, int32_t c0, int32_t c1) {
-    if (B.nodes.size() < (size_t)(idx + 1) * 16) B.nodes.resize((size_t)(idx + 1) * 16);
-    float* o = &B.nodes[(size_t)idx * 16];
-    o[0] = b0.lo[0]; o[1] = b0.lo[1]; o[2] = b0.lo[2]; o[3] = b0.hi[0]; o[4] = b0.hi[1]; o[5] = b0.hi[2];
-    o[6] = b1.lo[0]; o[7] = b1.lo[1]; o[8] = b1.lo[2]; o[9] = b1.hi[0]; o[10] = b1.hi[1]; o[11] = b1.hi[2];
-    std::memcpy(&o[12], &c0, 4); std::memcpy(&o[13], &c1, 4); o[14] = 0.0f; o[15] = 0.0f;
+  auto half_area = [](const Box& b) {
+    const float ex = b.hi[0] - b.lo[0], ey = b.hi[1] - b.lo[1], ez = b.hi[2] - b.lo[2];
+    return ex * ey + ey * ez + ez * ex;
   };
-  if (n == 1) {   // both children are the one leaf
-    const Box b = range_box(0, 0);
-    put_node(0, b, b, leaf_code(0, 1), leaf_code(0, 1));
+  struct Wide { WChild kid[4]; int n; };
+  auto expand = [&](int32_t r) {
+    Wide w;
+    w.n = 2;
+    w.kid[0] = child_of(radix[(size_t)r].left);
+    w.kid[1] = child_of(radix[(size_t)r].right);
+    while (w.n < 4) {
+      int best = -1; float besta = 0.0f;
+      for (int i = 0; i < w.n; ++i) {
+        if (w.kid[i].leaf) continue;
+        const float a = half_area(w.kid[i].box);
+        if (best < 0 || a > besta) { best = i; besta = a; }
+      }
+      if (best < 0) break;
+      const RadixNode& rn = radix[(size_t)w.kid[best].radix];
+      for (int j = w.n; j > best + 1; --j) w.kid[j] = w.kid[j - 1];
+      const WChild l = child_of(rn.left), rr = child_of(rn.right);
+      w.kid[best] = l; w.kid[best + 1] = rr;
+      ++w.n;
+    }
+    return w;
+  };
+  auto put_node = [&](uint32_t idx, const Wide& w, const int32_t code[4]) {
+    float* o = &B.nodes[(size_t)idx * 32];
+    for (int i = 0; i < 4; ++i) {
+      const bool used = i < w.n;
+      // unused slots: an inverted box (lo > hi) that the slab test cannot hit
+      o[0 + i] = used ? w.kid[i].box.lo[0] : 3.0e38f; o[4 + i] = used ? w.kid[i].box.lo[1] : 3.0e38f; o[8 + i] = used ? w.kid[i].box.lo[2] : 3.0e38f;
+      o[12 + i] = used ? w.kid[i].box.hi[0] : -3.0e38f; o[16 + i] = used ? w.kid[i].box.hi[1] : -3.0e38f; o[20 + i] = used ? w.kid[i].box.hi[2] : -3.0e38f;
+      const int32_t cd = used ? code[i] : kEmpty;
+      std::memcpy(&o[24 + i], &cd, 4);
+      o[28 + i] = 0.0f;
+    }
+  };
+  if (n == 1) {   // a single triangle: two identical leaf children (mirrors the binary special case)
+    Wide w; w.n = 2;
+    for (int k = 0; k < 2; ++k) { w.kid[k].leaf = true; w.kid[k].lo = w.kid[k].hi = 0; w.kid[k].radix = -1; w.kid[k].box = range_box(0, 0); }
+    B.nodes.assign(32, 0.0f);
+    const int32_t code[4] = {leaf_code(0, 1), leaf_code(0, 1), kEmpty, kEmpty};
+    put_node(0, w, code);
     B.n_nodes = 1; B.max_depth = 0;
   } else {
     build_radix_tree(keys, radix);
-    // pass 1: assign output indices (BFS for the first nodelet_budget, DFS below), remember depth
-    struct Slot { int32_t radix; uint32_t depth; };
-    std::vector<int32_t> out_index(radix.size(), -1);
-    std::vector<Slot> order;   // output index → radix node
-    size_t head = 0;
-    out_index[0] = 0; order.push_back({0, 0});
-    // breadth-first part
-    std::vector<Slot> bfs{{0, 0}};
-    while (head < bfs.size() && order.size() < nodelet_budget) {
-      const Slot s = bfs[head++];
-      const RadixNode& r = radix[(size_t)s.radix];
-      for (int32_t link : {r.left, r.right}) {
-        const Child c = child_of(link);
-        if (c.leaf) continue;
-        if (order.size() >= nodelet_budget) break;
-        out_index[(size_t)c.radix] = (int32_t)order.size();
-        order.push_back({c.radix, s.depth + 1});
-        bfs.push_back({c.radix, s.depth + 1});
+    // boxes of all radix nodes, bottom-up (iterative post-order)
+    radix_box.assign(radix.size(), empty_box());
+    {
+      std::vector<std::pair<int32_t, int>> stk{{0, 0}};
+      while (!stk.empty()) {
+        auto& top = stk.back();
+        const RadixNode& r = radix[(size_t)top.first];
+        if (top.second == 0) { top.second = 1; if (r.left >= 0) { stk.push_back({r.left, 0}); continue; } }
+        if (top.second == 1) { top.second = 2; if (r.right >= 0) { stk.push_back({r.right, 0}); continue; } }
+        Box b = r.left < 0 ? tbox[(uint32_t)(keys[(size_t)~r.left] & 0xffffffffu)] : radix_box[(size_t)r.left];
+        grow(b, r.right < 0 ? tbox[(uint32_t)(keys[(size_t)~r.right] & 0xffffffffu)] : radix_box[(size_t)r.right]);
+        radix_box[(size_t)top.first] = b;
+        stk.pop_back();
       }
     }
-    // depth-first part: subtrees hanging below the breadth-first top, numbered in preorder
+    struct Slot { int32_t radix; uint32_t depth; };
+    std::vector<int32_t> out_index(radix.size(), -1);
+    std::vector<Slot> order;       // output index → radix node
+    std::vector<Wide> wide;        // output index → its children
+    auto number = [&](int32_t r, uint32_t depth) {
+      out_index[(size_t)r] = (int32_t)order.size();
+      order.push_back({r, depth});
+      wide.push_back(expand(r));
+    };
+    number(0, 0);
+    // breadth-first top
+    for (size_t head = 0; head < order.size() && order.size() < nodelet_budget; ++head) {
+      const Wide w = wide[head];
+      for (int i = 0; i < w.n && order.size() < nodelet_budget; ++i)
+        if (!w.kid[i].leaf && out_index[(size_t)w.kid[i].radix] < 0) number(w.kid[i].radix, order[head].depth + 1);
+    }
+    // depth-first remainder, preorder
     {
       std::vector<Slot> stack;
       const size_t n_top = order.size();
       for (size_t i = 0; i < n_top; ++i) {
-        const Slot top = order[i];
-        const RadixNode& r = radix[(size_t)top.radix];
-        for (int32_t link : {r.left, r.right}) {
-          const Child c = child_of(link);
-          if (c.leaf || out_index[(size_t)c.radix] >= 0) continue;
-          stack.push_back({c.radix, top.depth + 1});
+        const Wide w = wide[i];
+        for (int k = 0; k < w.n; ++k) {
+          if (w.kid[k].leaf || out_index[(size_t)w.kid[k].radix] >= 0) continue;
+          stack.push_back({w.kid[k].radix, order[i].depth + 1});
           while (!stack.empty()) {
             const Slot s = stack.back();
             stack.pop_back();
-            out_index[(size_t)s.radix] = (int32_t)order.size();
-            order.push_back(s);
-            const RadixNode& rr = radix[(size_t)s.radix];
-            const Child cl = child_of(rr.left), cr = child_of(rr.right);
-            if (!cr.leaf) stack.push_back({cr.radix, s.depth + 1});   // right first: left follows its parent
-            if (!cl.leaf) stack.push_back({cl.radix, s.depth + 1});
+            number(s.radix, s.depth);
+            const Wide ww = wide.back();
+            for (int j = ww.n - 1; j >= 0; --j)   // reverse: the first child follows its parent
+              if (!ww.kid[j].leaf) stack.push_back({ww.kid[j].radix, s.depth + 1});
           }
         }
       }
     }
-    // pass 2: emit
     B.n_nodes = (uint32_t)order.size();
-    B.nodes.assign((size_t)B.n_nodes * 16, 0.0f);
+    B.nodes.assign((size_t)B.n_nodes * 32, 0.0f);
     uint32_t maxd = 0;
     for (uint32_t idx = 0; idx < B.n_nodes; ++idx) {
-      const Slot s = order[idx];
-      if (s.depth > maxd) maxd = s.depth;
-      const RadixNode& r = radix[(size_t)s.radix];
-      const Child cl = child_of(r.left), cr = child_of(r.right);
-      const int32_t c0 = cl.leaf ? leaf_code(cl.lo, cl.hi - cl.lo + 1u) : out_index[(size_t)cl.radix];
-      const int32_t c1 = cr.leaf ? leaf_code(cr.lo, cr.hi - cr.lo + 1u) : out_index[(size_t)cr.radix];
-      put_node(idx, range_box(cl.lo, cl.hi), range_box(cr.lo, cr.hi), c0, c1);
+      if (order[idx].depth > maxd) maxd = order[idx].depth;
+      const Wide& w = wide[idx];
+      int32_t code[4] = {kEmpty, kEmpty, kEmpty, kEmpty};
+      for (int i = 0; i < w.n; ++i)
+        code[i] = w.kid[i].leaf ? leaf_code(w.kid[i].lo, w.kid[i].hi - w.kid[i].lo + 1u) : out_index[(size_t)w.kid[i].radix];
+      put_node(idx, w, code);
     }
     B.max_depth = maxd;
   }

@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "ptc_add_texture_rgba8", "ptc_add_mesh", "ptc_add_instance", "ptc_set_camera", "ptc_scene_commit", "ptc_render",
     "ptc_frame_begin", "ptc_frame_add_samples", "ptc_frame_resolve", "ptc_sync", "ptc_read_radiance_rgba32f",
     "ptc_radiance_device_ptr", "ptc_write_radiance_rgba32f", "ptc_tonemap_rgba8", "ptc_get_stats",
-    "ptc_debug_trace_closest", "ptc_debug_trace_any", "ptc_debug_get_flat_scene", "ptc_debug_get_bvh",
+    "ptc_debug_trace_closest", "ptc_debug_trace_any", "ptc_debug_get_flat_scene", "ptc_debug_get_bvh", "ptc_debug_get_counters",
 ]
 
 
@@ -95,6 +95,7 @@ def load_library():
     L.ptc_debug_trace_any.argtypes = [vp, fp, fp, fp, C.c_uint32, u8p]
     L.ptc_debug_get_flat_scene.argtypes = [vp, u32p, u32p, vp, u32p, i32p]
     L.ptc_debug_get_bvh.argtypes = [vp, u32p, u32p, fp, fp]
+    L.ptc_debug_get_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
     _lib = L
     return L
 
@@ -225,7 +226,12 @@ class PathTracer:
     def bvh(self):
         nn, nt = C.c_uint32(), C.c_uint32()
         self._ck(self._L.ptc_debug_get_bvh(self._h, C.byref(nn), C.byref(nt), None, None))
-        nodes = np.zeros((nn.value, 16), np.float32)
+        nodes = np.zeros((nn.value, 32), np.float32)
         tris = np.zeros((nt.value, 12), np.float32)
         self._ck(self._L.ptc_debug_get_bvh(self._h, None, None, nodes.ctypes.data_as(C.POINTER(C.c_float)), tris.ctypes.data_as(C.POINTER(C.c_float))))
         return nodes, tris
+
+    def raw_counters(self):
+        buf = (C.c_uint64 * 32)()
+        n = self._ck(self._L.ptc_debug_get_counters(self._h, buf, 32))
+        return [int(buf[i]) for i in range(n)]

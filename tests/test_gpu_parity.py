@@ -156,10 +156,10 @@ def test_edge_cases(gpu, ora):
         gpu.PathTracer(0).render(8, 8, 1)                                   # no scene
 
 
-def test_deep_tree_uses_scratch_stack(gpu, ora):
-    """An LBVH deeper than the 32-entry LDS stack (one far triangle per Morton bit + 6000 coincident
-    triangles whose keys differ only in the primitive id: depth 40) must switch the trace kernels to their
-    scratch-stack variant — still bit-exact, path tracer and raster-compat alike."""
+def test_deep_tree_uses_stack_overflow(gpu, ora):
+    """A deep LBVH (one far triangle per Morton bit + 6000 coincident triangles whose keys differ only in the
+    primitive id: binary depth 40, 4-wide depth 18) traversed with only 2 stack entries in LDS, so that most
+    pushes go through the global overflow slab — still bit-exact, path tracer and raster-compat alike."""
     sc = gpu.scene
     cents = [(1024.0, 1024.0, 1024.0)]
     for k in range(10):
@@ -175,8 +175,12 @@ def test_deep_tree_uses_scratch_stack(gpu, ora):
     emis = sc.Material((0.6, 0.6, 0.6, 1), 0.0, 1.0, (1.0, 1.0, 1.0))
     d = sc.SceneDesc([emis], [sc.MeshDesc(v, np.arange(3 * n, dtype=np.uint32), 0)], [sc.InstanceDesc(0, (0, 0, 0), (1, 0, 0, 0), (1, 1, 1))],
                      sc.CameraDesc((0.0, 0.0, 3.0), (0, 0, 0), 0.2, 1.0))
-    pt, o = _pair(gpu, ora, d)
-    assert pt.stats()["bvh_max_depth"] + 1 > 32
+    os.environ["PTC_STACK_LDS"] = "2"
+    try:
+        pt, o = _pair(gpu, ora, d)
+    finally:
+        del os.environ["PTC_STACK_LDS"]
+    assert pt.stats()["bvh_max_depth"] >= 15 and pt.stats()["bvh_max_depth"] == o.stats()["bvh_max_depth"]
     for integ, spp in ((1, 1), (0, 2)):
         g, c2 = pt.render(64, 64, spp, seed=2, max_bounces=2, integrator=integ), o.render(64, 64, spp, seed=2, max_bounces=2, integrator=integ)
         assert _bits_equal(g, c2)

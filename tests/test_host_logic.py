@@ -6,10 +6,14 @@ import numpy as np
 import pytest
 
 
+EMPTY = -(2 ** 31)
+
+
 def _canon(nodes):
-    """Layout-independent form of the node array: child boxes + leaf codes, rows sorted."""
-    b = nodes[:, :12].view(np.uint32)
-    c = nodes[:, 12:14].view(np.int32)
+    """Layout-independent form of the 4-wide node array (32 floats per node: lo.x[4] lo.y[4] lo.z[4] hi.x[4]
+    hi.y[4] hi.z[4] code[4] pad[4]): child boxes + leaf codes (interior links → 0, empty slots → EMPTY), rows sorted."""
+    b = nodes[:, :24].view(np.uint32)
+    c = nodes[:, 24:28].view(np.int32)
     rows = np.concatenate([b, np.where(c < 0, c, 0).view(np.uint32)], axis=1)
     return rows[np.lexsort(rows.T[::-1])]
 
@@ -38,15 +42,20 @@ def test_bvh_is_a_valid_partition(pbr):
     nodes, tris = pt.bvh()
     n_tris = tris.shape[0]
     seen = np.zeros(n_tris, int)
-    code = nodes[:, 12:14].view(np.int32)
+    code = nodes[:, 24:28].view(np.int32)
     interior_refs = np.zeros(nodes.shape[0], int)
     P0, E1, E2 = tris[:, 0:3], tris[:, 4:7], tris[:, 8:11]
     lo_t = np.minimum(np.minimum(P0, P0 + E1), P0 + E2)
     hi_t = np.maximum(np.maximum(P0, P0 + E1), P0 + E2)
+    n_children = 0
     for i in range(nodes.shape[0]):
-        for c in range(2):
-            lo, hi = nodes[i, c * 6:c * 6 + 3], nodes[i, c * 6 + 3:c * 6 + 6]
+        for c in range(4):
             k = int(code[i, c])
+            if k == EMPTY:
+                assert c >= 2                                   # slots fill from the front, at least two children
+                continue
+            n_children += 1
+            lo, hi = nodes[i, [c, 4 + c, 8 + c]], nodes[i, [12 + c, 16 + c, 20 + c]]
             if k < 0:
                 v = ~k & 0xFFFFFFFF
                 first, cnt = v & 0x0FFFFFFF, (v >> 28) + 1
@@ -56,11 +65,13 @@ def test_bvh_is_a_valid_partition(pbr):
             else:
                 interior_refs[k] += 1
                 ch = nodes[k]
-                clo = np.minimum(ch[0:3], ch[6:9])
-                chi = np.maximum(ch[3:6], ch[9:12])
+                used = ch[24:28].view(np.int32) != EMPTY
+                clo = np.array([ch[0:4][used].min(), ch[4:8][used].min(), ch[8:12][used].min()])
+                chi = np.array([ch[12:16][used].max(), ch[16:20][used].max(), ch[20:24][used].max()])
                 assert (clo >= lo - 1e-5).all() and (chi <= hi + 1e-5).all()
     assert (seen == 1).all()                                    # every triangle in exactly one leaf
     assert interior_refs[0] == 0 and (interior_refs[1:] == 1).all()   # a tree rooted at node 0
+    assert n_children / nodes.shape[0] > 3.0                    # the greedy collapse fills the nodes
     prim = tris[:, 3].view(np.uint32)
     assert np.array_equal(np.sort(prim), np.arange(n_tris))      # Morton order is a permutation
 

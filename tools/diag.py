@@ -1,0 +1,17 @@
+"""Lane-utilisation diagnostics of k_trace_closest (needs libptc built with EXTRA=-DPT_DIAG)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "physically-based-renderer_amd"))
+import pbr_amd
+from pbr_amd import scenes
+pt = pbr_amd.PathTracer(0).load_scene(scenes.atrium())
+pt.frame_begin(1920, 1080, 4, seed=3, max_bounces=8)
+pt.frame_add_samples(4); pt.sync()
+st = pt.stats(); c = pt.raw_counters()
+names = ["segments", "shadow", "hits", "nodes_c", "tris_c", "nodes_a", "tris_a", "node_iters", "tri_iters", "leaf_visits", "rounds", "refilled"]
+d = dict(zip(names, c)); print(d)
+print("node-phase lane utilisation  %.3f" % (d["nodes_c"] / (64.0 * max(1, d["node_iters"]))))
+print("tri-phase lane utilisation   %.3f" % (d["tris_c"] / (64.0 * max(1, d["tri_iters"]))))
+print("rays per refill round        %.2f" % (d["segments"] / max(1, d["rounds"])))
+print("node visits/ray %.1f tri tests/ray %.1f  node wave-iters/ray %.2f tri wave-iters/ray %.2f" % (d["nodes_c"]/d["segments"], d["tris_c"]/d["segments"], d["node_iters"]*64/d["segments"], d["tri_iters"]*64/d["segments"]))
+print({k: st[k] for k in ("seconds_trace_closest", "seconds_trace_any", "seconds_shade", "seconds_render")})
