@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--max-bounces", type=int, default=8)
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--scene-scale", type=float, default=1.0, help="atrium tessellation scale (1.0 = 249,936 triangles)")
-    ap.add_argument("--cpu-spp", type=int, default=2, help="samples per pixel of the bounded CPU-baseline render")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the bounded CPU-baseline render")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -171,14 +171,18 @@ def main():
             o = ora.Oracle().load_scene(desc)
             cores = ora.hw_threads()
             tc0 = time.perf_counter()
-            o.render(args.width, args.height, args.cpu_spp, args.seed, args.max_bounces, 0, 0, 1, cores)
+            o.render(args.width, args.height, 1, args.seed, args.max_bounces, 0, 0, 1, cores)       # probe: 1 spp
+            probe = time.perf_counter() - tc0
+            cpu_spp = max(1, min(64, int(args.cpu_seconds / max(probe, 1e-3))))
+            tc0 = time.perf_counter()
+            o.render(args.width, args.height, cpu_spp, args.seed, args.max_bounces, 0, 0, 1, cores)
             tc = time.perf_counter() - tc0
             out["cpu_baseline"] = {
-                "value": args.width * args.height * args.cpu_spp / tc / 1e6,
+                "value": args.width * args.height * cpu_spp / tc / 1e6,
                 "unit": "Mpaths/s",
                 "cores": cores,
                 "kind": "port",
-                "sample": f"same scene and camera, {args.width}x{args.height} x {args.cpu_spp} spp ({tc:.1f} s of CPU work), oracle/ptc_oracle.c -O2 -ffp-contract=off, pthreads over rows",
+                "sample": f"same scene and camera, {args.width}x{args.height} x {cpu_spp} spp ({tc:.1f} s of CPU work), oracle/ptc_oracle.c -O2 -ffp-contract=off, pthreads over rows, all online cores",
             }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -22,7 +22,7 @@
 #define TRACE_CHUNK 512u          // rays per work-fetch atomic
 #define TRACE_REFILL_IDLE 16      // refill as soon as this many lanes are idle
 #ifndef TRACE_NODE_MIN
-#define TRACE_NODE_MIN 24         // leave the node loop when fewer lanes than this are still at interior nodes
+#define TRACE_NODE_MIN 20         // leave the node loop when fewer lanes than this are still at interior nodes
 #endif                            // while others wait at a leaf (keeps both phases well populated)
 #define SHADE_BLOCK 512
 #define SHADE_WAVES (SHADE_BLOCK / 64)
@@ -170,15 +170,21 @@ PT_DEV int wide_step(const DevScene& sc, const float4* lds_nodes, int cur, const
 // Wave-private reservoir of input slots: one atomic fetches TRACE_CHUNK consecutive rays, idle lanes are
 // refilled from it (ballot + mbcnt).  Returns, per lane, whether it received slot `ri`.
 struct Reservoir {
-  uint32_t next, end; bool exhausted;
-  PT_DEV void init() { next = 0; end = 0; exhausted = false; }
+  uint32_t next, end, chunk; bool exhausted;
+  // chunk: TRACE_CHUNK rays per atomic when the queue is long (a single word takes ~88 atomics/us), down to
+  // one wave's worth when it is short, so that a small late-bounce queue still spreads over the whole chip
+  PT_DEV void init(uint32_t n) {
+    next = 0; end = 0; exhausted = false;
+    const uint32_t per_wave = n / (gridDim.x * TRACE_WAVES * 4u);
+    chunk = per_wave >= TRACE_CHUNK ? TRACE_CHUNK : (per_wave < 64u ? 64u : (per_wave & ~63u));
+  }
   PT_DEV bool refill(uint32_t* ctr, uint32_t n, bool idle, uint32_t lane, uint32_t& ri) {
     const uint64_t mi = __ballot(idle);
     if (!mi) return false;
     if (next >= end && !exhausted) {
-      const uint32_t base = wave_fetch(ctr, TRACE_CHUNK, lane);
+      const uint32_t base = wave_fetch(ctr, chunk, lane);
       if (base >= n) exhausted = true;
-      else { next = base; end = (base + TRACE_CHUNK < n) ? base + TRACE_CHUNK : n; }
+      else { next = base; end = (base + chunk < n) ? base + chunk : n; }
     }
     const uint32_t avail = end - next;
     if (avail == 0) return false;
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DevScene sc, DevQ
   uint32_t nv = 0, nt = 0, nr = 0, nh = 0;
   uint32_t d_node = 0, d_tri = 0, d_leaf = 0, d_round = 0;
   (void)d_node; (void)d_tri; (void)d_leaf; (void)d_round;
-  Reservoir res; res.init();
+  Reservoir res; res.init(n);
   WStack st;
   st.init(lds_stack + (size_t)wave * (size_t)stack_lds * 64u + lane,
           sc.stack_ovf + ((size_t)(blockIdx.x * TRACE_WAVES + wave) * sc.ovf_depth) * 64u + lane, stack_lds);
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_any(DevScene sc, DevQueue
   }
   const uint32_t n = q.cnt[CNT_SHADOW];
   uint32_t nv = 0, nt = 0, nr = 0;
-  Reservoir res; res.init();
+  Reservoir res; res.init(n);
   WStack st;
   st.init(lds_stack + (size_t)wave * (size_t)stack_lds * 64u + lane,
           sc.stack_ovf + ((size_t)(blockIdx.x * TRACE_WAVES + wave) * sc.ovf_depth) * 64u + lane, stack_lds);

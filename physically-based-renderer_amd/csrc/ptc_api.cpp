@@ -31,8 +31,8 @@ struct ptc_ctx {
   hipStream_t stream = nullptr;
   std::string err;
   LaunchCfg cfg{};
-  uint32_t nodelet_budget = 0;
-  size_t max_batch_paths = (size_t)1 << 23;
+  uint32_t nodelet_budget = 149;  // wide nodes staged in LDS (breadth-first top of the tree, 18.6 KB)
+  size_t max_batch_paths = (size_t)1 << 25;   // paths per wavefront batch: large batches amortise launch tails (288 GB of HBM)
   bool timing = true;
   // description
   std::vector<HostMaterial> mats;
@@ -154,7 +154,7 @@ int configure_launch(ptc_ctx* c) {
   // 3·(depth+1) entries.  `stack_lds` of them live in LDS (8 B each, 512 B per level and wave), the rest in
   // a global overflow slab.  LDS per 256-thread block = nodelets·128 B + 4 waves·stack_lds·512 B.
   const int need = 3 * ((int)c->built.max_depth + 1);
-  int l = 12;
+  int l = 10;   // measured on MI355X: 4 blocks/CU (VGPR-bound) x (10 x 2 KB stack + 149 nodelets) beats deeper LDS stacks
   if (const char* e = std::getenv("PTC_STACK_LDS")) { int v = std::atoi(e); if (v >= 1 && v <= 64) l = v; }
   if (l > need) l = need;
   c->cfg.stack_lds = l;
