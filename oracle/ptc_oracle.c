@@ -694,14 +694,22 @@ done:
   return best;
 }
 static int trace_any(const ora_ctx* c, v3 o, v3 d, float tmin, float tmax, trav_count* cnt) {
+  /* occlusion needs no front-to-back order: hit children are taken in slot order (first one entered, the
+   * others pushed so that they pop in slot order) */
   ray_t r = make_ray(o, d);
   int32_t stack[ORA_STACK]; int sp = 0; int32_t cur = 0;
   for (;;) {
     while (cur >= 0) {
-      cand_t cd[4]; cnt->nodes++;
-      int nh = wide_step(&c->wnodes[cur], &r, tmin, tmax, cd);
-      for (int k = nh - 1; k >= 1; --k) stack[sp++] = cd[k].code;
-      if (nh > 0) { cur = cd[0].code; continue; }
+      const wnode_t* n = &c->wnodes[cur]; cnt->nodes++;
+      int32_t hit[4]; int nh = 0;
+      for (int i = 0; i < 4; ++i) {
+        if (n->code[i] == ORA_EMPTY) continue;
+        float lo[3] = {n->lox[i], n->loy[i], n->loz[i]}, hi[3] = {n->hix[i], n->hiy[i], n->hiz[i]};
+        float tn;
+        if (box_hit(&r, lo, hi, tmin, tmax, &tn)) hit[nh++] = n->code[i];
+      }
+      for (int k = nh - 1; k >= 1; --k) stack[sp++] = hit[k];
+      if (nh > 0) { cur = hit[0]; continue; }
       if (sp == 0) return 0;
       cur = stack[--sp];
     }

@@ -142,6 +142,10 @@ PT_DEV int wide_step(const DevScene& sc, const float4* lds_nodes, int cur, const
   const float4 nxq = p[oc.nx], nyq = p[oc.ny], nzq = p[oc.nz];
   const float4 fxq = p[3 - oc.nx], fyq = p[5 - oc.ny], fzq = p[7 - oc.nz];
   const float4 cq = p[6];
+#ifdef EXP_EXTRA_LOADS   // timing experiment: two more 16-byte gathers per node visit (results unchanged)
+  const float4 e0 = p[7], e1 = p[8 + 7];
+  tmin = tmin + 0.0f * (e0.x + e1.x);
+#endif
   const float2v ix = {r.inv.x, r.inv.x}, iy = {r.inv.y, r.inv.y}, iz = {r.inv.z, r.inv.z};
   const float2v ox = {-r.ood.x, -r.ood.x}, oy = {-r.ood.y, -r.ood.y}, oz = {-r.ood.z, -r.ood.z};
   const float2v nx01 = pk_fma(float2v{nxq.x, nxq.y}, ix, ox), nx23 = pk_fma(float2v{nxq.z, nxq.w}, ix, ox);
@@ -165,6 +169,33 @@ PT_DEV int wide_step(const DevScene& sc, const float4* lds_nodes, int cur, const
   if (k[2] != KEY_MISS) st.push(c[2], k[2]);
   if (k[1] != KEY_MISS) st.push(c[1], k[1]);
   return k[0] != KEY_MISS ? c[0] : CODE_EMPTY;
+}
+
+// Any-hit variant: occlusion needs no front-to-back order, so the hits are taken in slot order — the first
+// hit child is entered, the others pushed so that they pop in slot order — and the sorting network is saved.
+template <bool NODELETS>
+PT_DEV int wide_step_any(const DevScene& sc, const float4* lds_nodes, int cur, const ray_t& r, const Octant& oc, float tmax, WStack& st) {
+  const float4* p = (NODELETS && (uint32_t)cur < sc.n_nodelets) ? lds_nodes + (size_t)cur * 8 : sc.nodes + (size_t)cur * 8;
+  const float4 nxq = p[oc.nx], nyq = p[oc.ny], nzq = p[oc.nz];
+  const float4 fxq = p[3 - oc.nx], fyq = p[5 - oc.ny], fzq = p[7 - oc.nz];
+  const float4 cq = p[6];
+  const float2v ix = {r.inv.x, r.inv.x}, iy = {r.inv.y, r.inv.y}, iz = {r.inv.z, r.inv.z};
+  const float2v ox = {-r.ood.x, -r.ood.x}, oy = {-r.ood.y, -r.ood.y}, oz = {-r.ood.z, -r.ood.z};
+  const float2v nx01 = pk_fma(float2v{nxq.x, nxq.y}, ix, ox), nx23 = pk_fma(float2v{nxq.z, nxq.w}, ix, ox);
+  const float2v ny01 = pk_fma(float2v{nyq.x, nyq.y}, iy, oy), ny23 = pk_fma(float2v{nyq.z, nyq.w}, iy, oy);
+  const float2v nz01 = pk_fma(float2v{nzq.x, nzq.y}, iz, oz), nz23 = pk_fma(float2v{nzq.z, nzq.w}, iz, oz);
+  const float2v fx01 = pk_fma(float2v{fxq.x, fxq.y}, ix, ox), fx23 = pk_fma(float2v{fxq.z, fxq.w}, ix, ox);
+  const float2v fy01 = pk_fma(float2v{fyq.x, fyq.y}, iy, oy), fy23 = pk_fma(float2v{fyq.z, fyq.w}, iy, oy);
+  const float2v fz01 = pk_fma(float2v{fzq.x, fzq.y}, iz, oz), fz23 = pk_fma(float2v{fzq.z, fzq.w}, iz, oz);
+  const bool h0 = hw_max(hw_max(hw_max(nx01.x, ny01.x), nz01.x), 0.0f) <= hw_min(hw_min(hw_min(fx01.x, fy01.x), fz01.x), tmax);
+  const bool h1 = hw_max(hw_max(hw_max(nx01.y, ny01.y), nz01.y), 0.0f) <= hw_min(hw_min(hw_min(fx01.y, fy01.y), fz01.y), tmax);
+  const bool h2 = hw_max(hw_max(hw_max(nx23.x, ny23.x), nz23.x), 0.0f) <= hw_min(hw_min(hw_min(fx23.x, fy23.x), fz23.x), tmax);
+  const bool h3 = hw_max(hw_max(hw_max(nx23.y, ny23.y), nz23.y), 0.0f) <= hw_min(hw_min(hw_min(fx23.y, fy23.y), fz23.y), tmax);
+  const int c0 = __float_as_int(cq.x), c1 = __float_as_int(cq.y), c2 = __float_as_int(cq.z), c3 = __float_as_int(cq.w);
+  if (h3 && (h0 || h1 || h2)) st.push(c3, 0u);
+  if (h2 && (h0 || h1)) st.push(c2, 0u);
+  if (h1 && h0) st.push(c1, 0u);
+  return h0 ? c0 : (h1 ? c1 : (h2 ? c2 : (h3 ? c3 : CODE_EMPTY)));
 }
 
 // Wave-private reservoir of input slots: one atomic fetches TRACE_CHUNK consecutive rays, idle lanes are
@@ -223,7 +254,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DevScene sc, DevQ
   }
   const RayQ rq = q.ray[qi];
   const uint32_t n = q.cnt[CNT_RAYS];
-  uint32_t nv = 0, nt = 0, nr = 0, nh = 0;
+  unsigned long long nv = 0, nr = 0, nh = 0;   // wave totals, only updated at wave-uniform points: they live in SGPRs
+  uint32_t nt = 0;                               // per lane (updated inside the divergent leaf loop)
   uint32_t d_node = 0, d_tri = 0, d_leaf = 0, d_round = 0;
   (void)d_node; (void)d_tri; (void)d_leaf; (void)d_round;
   Reservoir res; res.init(n);
@@ -239,7 +271,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DevScene sc, DevQ
   bool found = false;
   for (;;) {
     // ---- refill idle lanes from the wave's reservoir ----
-    if (res.refill(&q.cnt[CNT_WORK_TRACE], n, cur == CUR_DONE, lane, ri)) {
+    const bool got = res.refill(&q.cnt[CNT_WORK_TRACE], n, cur == CUR_DONE, lane, ri);
+    nr += (unsigned long long)__popcll(__ballot(got));
+    if (got) {
       const float4 A = rq.A[ri], Bq = rq.B[ri];
       r = make_ray(V3(A.x, A.y, A.z), V3(A.w, Bq.x, Bq.y));
       oc = make_octant(r);
@@ -247,7 +281,6 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DevScene sc, DevQ
       best_t = CULL ? Bq.w : PT_T_INF; best_u = 0.0f; best_v = 0.0f; best_prim = 0x7fffffff; best_cls = 0; found = false;
       st.reset();
       cur = 0;
-      ++nr;
     }
     if (!__ballot(cur != CUR_DONE)) {
       if (res.exhausted) break;
@@ -260,9 +293,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DevScene sc, DevQ
         const uint64_t mn = __ballot(cur >= 0);
         if (!mn) break;
         if (__popcll(mn) < TRACE_NODE_MIN && __ballot(cur < 0 && cur > CUR_FINISHED)) break;   // few walkers, leaves waiting
+        nv += (unsigned long long)__popcll(mn);
         if (cur >= 0) {
           DIAG_ITER(d_node);
-          ++nv;
           cur = wide_step<NODELETS>(sc, lds_nodes, cur, r, oc, tmin, best_t, st);
           if (cur == CODE_EMPTY) {                                     // nothing hit: pop, skipping culled entries
             cur = CUR_FINISHED;
@@ -288,17 +321,17 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DevScene sc, DevQ
         cur = CUR_FINISHED;
         while (!st.empty()) { const uint2 e = st.pop(); if (__uint_as_float(e.y) > best_t) continue; cur = (int)e.x; break; }
       }
+      nh += (unsigned long long)__popcll(__ballot(cur == CUR_FINISHED && found));
       if (cur == CUR_FINISHED) {                                       // this lane's ray is finished: publish in place
         q.hit[ri] = make_float4(found ? best_t : -1.0f, __int_as_float(found ? (best_prim | (best_cls << HIT_CLASS_SHIFT)) : -1), best_u, best_v);
-        nh += found ? 1u : 0u;
         cur = CUR_DONE;
       }
     } while (__popcll(__ballot(cur == CUR_DONE)) < TRACE_REFILL_IDLE || (res.exhausted && res.next >= res.end && __ballot(cur != CUR_DONE)));
   }
-  unsigned long long c_nodes = wave_sum(nv), c_tris = wave_sum(nt), c_rays = wave_sum(nr), c_hits = wave_sum(nh);
-  if (lane == 0 && c_rays) {
-    atomicAdd(&q.stats[ST_NODES_C], c_nodes); atomicAdd(&q.stats[ST_TRIS_C], c_tris);
-    atomicAdd(&q.stats[ST_SEGMENTS], c_rays); atomicAdd(&q.stats[ST_HITS], c_hits);
+  const unsigned long long c_tris = wave_sum(nt);
+  if (lane == 0 && nr) {
+    atomicAdd(&q.stats[ST_NODES_C], nv); atomicAdd(&q.stats[ST_TRIS_C], c_tris);
+    atomicAdd(&q.stats[ST_SEGMENTS], nr); atomicAdd(&q.stats[ST_HITS], nh);
   }
 #ifdef PT_DIAG
   {
@@ -324,7 +357,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_any(DevScene sc, DevQueue
     __syncthreads();
   }
   const uint32_t n = q.cnt[CNT_SHADOW];
-  uint32_t nv = 0, nt = 0, nr = 0;
+  unsigned long long nv = 0, nr = 0;
+  uint32_t nt = 0;
   Reservoir res; res.init(n);
   WStack st;
   st.init(lds_stack + (size_t)wave * (size_t)stack_lds * 64u + lane,
@@ -336,7 +370,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_any(DevScene sc, DevQueue
   float tmax = 0.0f;
   bool occluded = false;
   for (;;) {
-    if (res.refill(&q.cnt[CNT_WORK_SHADOW], n, cur == CUR_DONE, lane, ri)) {
+    const bool got = res.refill(&q.cnt[CNT_WORK_SHADOW], n, cur == CUR_DONE, lane, ri);
+    nr += (unsigned long long)__popcll(__ballot(got));
+    if (got) {
       const float4 A = q.shadow.A[ri], Bq = q.shadow.B[ri];
       r = make_ray(V3(A.x, A.y, A.z), V3(A.w, Bq.x, Bq.y));
       oc = make_octant(r);
@@ -344,7 +380,6 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_any(DevScene sc, DevQueue
       occluded = false;
       st.reset();
       cur = 0;
-      ++nr;
     }
     if (!__ballot(cur != CUR_DONE)) {
       if (res.exhausted) break;
@@ -355,9 +390,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_any(DevScene sc, DevQueue
         const uint64_t mn = __ballot(cur >= 0);
         if (!mn) break;
         if (__popcll(mn) < TRACE_NODE_MIN && __ballot(cur < 0 && cur > CUR_FINISHED)) break;
+        nv += (unsigned long long)__popcll(mn);
         if (cur >= 0) {
-          ++nv;
-          cur = wide_step<NODELETS>(sc, lds_nodes, cur, r, oc, 0.0f, tmax, st);
+          cur = wide_step_any<NODELETS>(sc, lds_nodes, cur, r, oc, tmax, st);
           if (cur == CODE_EMPTY) cur = st.empty() ? CUR_FINISHED : (int)st.pop().x;
         }
       }
@@ -387,9 +422,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_any(DevScene sc, DevQueue
       }
     } while (__popcll(__ballot(cur == CUR_DONE)) < TRACE_REFILL_IDLE || (res.exhausted && res.next >= res.end && __ballot(cur != CUR_DONE)));
   }
-  unsigned long long c_nodes = wave_sum(nv), c_tris = wave_sum(nt), c_rays = wave_sum(nr);
-  if (lane == 0 && c_rays) {
-    atomicAdd(&q.stats[ST_NODES_A], c_nodes); atomicAdd(&q.stats[ST_TRIS_A], c_tris); atomicAdd(&q.stats[ST_SHADOW], c_rays);
+  const unsigned long long c_tris = wave_sum(nt);
+  if (lane == 0 && nr) {
+    atomicAdd(&q.stats[ST_NODES_A], nv); atomicAdd(&q.stats[ST_TRIS_A], c_tris); atomicAdd(&q.stats[ST_SHADOW], nr);
   }
 }
 
