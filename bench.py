@@ -15,7 +15,7 @@ collective of the path — the RCCL fp32 sum of the framebuffer onto rank 0 — 
 region.
 
 Extra objects on the JSON line:
-  roofline     dominant kernel k_trace_closest: algorithmic bytes (counted node visits × 128 B +
+  roofline     dominant kernel k_trace_closest: algorithmic bytes (counted node visits × 48 B +
                triangle tests × 48 B + ray/hit records) ÷ its HIP-event time, against 8 TB/s HBM.
   cpu_baseline the oracle (scalar C restatement, kind "port") timed on this box's host cores on a
                bounded sample of the same workload (rank 0, N=1 only).
@@ -119,7 +119,7 @@ def main():
         # × record sizes (DESIGN.md §Algorithmic bytes) ÷ launches; duration = HIP events on the
         # kernel's own stream, summed by the library, ÷ launches.
         n_launch = max(1, d["launches_trace_closest"])
-        tc_bytes = d["segments"] * (56 + 16) + d["node_visits_closest"] * 128 + d["tri_tests_closest"] * 48
+        tc_bytes = d["segments"] * (56 + 16) + d["node_visits_closest"] * 48 + d["tri_tests_closest"] * 48
         tc_sec = d["seconds_trace_closest"]
         achieved = tc_bytes / tc_sec / 1e9 if tc_sec > 0 else 0.0
         traffic = None

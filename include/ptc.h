@@ -185,9 +185,10 @@ int ptc_debug_get_flat_scene(ptc_ctx*, uint32_t* n_verts, uint32_t* n_tris, ptc_
  * loop-iteration diagnostics a -DPT_DIAG build fills).  Returns the number of counters the library keeps. */
 int ptc_debug_get_counters(ptc_ctx*, uint64_t* out, int n);
 
-/* The flattened 4-wide LBVH as committed: nodes (n_nodes*32 floats, SoA: lo.x[4] lo.y[4] lo.z[4] hi.x[4]
- * hi.y[4] hi.z[4], child codes[4] as int32 bits, 4 pads) and Morton-ordered triangle records (n_tris*12
- * floats: v0,prim | e1,class | e2,0).  Pass NULL to query sizes only. */
+/* The flattened 4-wide LBVH as committed: nodes (n_nodes*12 32-bit words = 48 bytes each: org.xyz, packed
+ * exponents + child descriptors, 8-bit quantised child planes, child / triangle base indices; layout in
+ * csrc/ptc_scene.cpp) and triangle records in node order (n_tris*12 floats: v0,prim | e1,class | e2,0).
+ * Pass NULL to query sizes only. */
 int ptc_debug_get_bvh(ptc_ctx*, uint32_t* n_nodes, uint32_t* n_tris, float* nodes, float* tris);
 
 #ifdef __cplusplus

@@ -35,7 +35,7 @@
 
 /* ------------------------------------------------------------------------------------------ */
 /* constants of the specification                                                              */
-#define ORA_LEAF_MAX 4          /* triangles per BVH leaf                                      */
+#define ORA_LEAF_MAX 2          /* triangles per BVH leaf                                      */
 #define ORA_STACK 256           /* traversal stack entries (3 per wide level, worst case)      */
 #define ORA_EMPTY ((int32_t)0x80000000)  /* unused child slot of a wide node                    */
 #define ORA_RR_START 3          /* Russian roulette from this bounce index on                  */
@@ -53,7 +53,7 @@
 #define S_RAY 56u
 #define S_HIT 16u
 #define S_SHADOW 44u
-#define S_NODE 128u
+#define S_NODE 48u
 #define S_TRI 48u
 #define S_SURF 176u
 #define S_FB 16u
@@ -173,12 +173,15 @@ typedef struct {                 /* 64-byte interior node: both child boxes + ch
   int32_t pad0, pad1;
 } node_t;
 
-/* 128-byte 4-wide node, SoA: the traversal structure (the binary node_t above is only the build's
- * intermediate).  code: >=0 wide node index; <0 leaf (as in node_t); ORA_EMPTY unused slot. */
+/* 4-wide node with quantised child boxes: the traversal structure (the binary node_t above is only the
+ * build's intermediate).  A child plane on axis k is  org[k] + q * 2^(e[k]-127)  with q an 8-bit integer
+ * (lower planes rounded down, upper planes rounded up, so the quantised box contains the exact one).
+ * code: >=0 wide node index; <0 leaf (as in node_t); ORA_EMPTY unused slot. */
 typedef struct {
-  float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];
+  float org[3];
+  uint32_t e[3];
+  uint32_t qlo[3][4], qhi[3][4];     /* [axis][child], values 0..255 */
   int32_t code[4];
-  int32_t pad[4];
 } wnode_t;
 
 typedef struct { v3 v0, e1, e2, ng; float area; v3 Le; float pmf; uint32_t prim; } light_t;
@@ -425,6 +428,39 @@ static inline wchild bin_child(const node_t* n, int k) {
   memcpy(w.lo, k ? n->lo1 : n->lo0, 12); memcpy(w.hi, k ? n->hi1 : n->hi0, 12); w.code = k ? n->c1 : n->c0;
   return w;
 }
+/* Quantise the children's [lo,hi] on one axis against the node's own [org, nhi]: scale 2^(e-127) is the
+ * smallest power of two with (nhi-org)/scale <= 255; lower planes floor, upper planes ceil, each then nudged
+ * until the float expression  org + q*scale  really brackets the exact plane. */
+static inline float pow2_biased(uint32_t e) { union { float f; uint32_t u; } b; b.u = e << 23; return b.f; }
+static void quantize_axis(const float* clo, const float* chi, int n, float org, float nhi, uint32_t* e_out, uint32_t* qlo, uint32_t* qhi) {
+  float f = (nhi - org) / 255.0f;
+  union { float f; uint32_t u; } b; b.f = f;
+  uint32_t e = (b.u >> 23) & 255u;
+  if (b.u & 0x007fffffu) e += 1u;
+  if (e < 1u) e = 1u;
+  for (;; ++e) {
+    float s = pow2_biased(e);
+    int ok = 1;
+    for (int i = 0; i < n && ok; ++i) {
+      float fl = floorf((clo[i] - org) / s);
+      if (fl < 0.0f) fl = 0.0f;
+      if (fl > 255.0f) fl = 255.0f;
+      int q = (int)fl;
+      while (q > 0 && org + (float)q * s > clo[i]) --q;
+      qlo[i] = (uint32_t)q;
+      float ce = ceilf((chi[i] - org) / s);
+      if (ce < 0.0f) ce = 0.0f;
+      if (ce > 255.0f) { ok = 0; break; }
+      int q2 = (int)ce;
+      while (q2 < 255 && org + (float)q2 * s < chi[i]) ++q2;
+      if (org + (float)q2 * s < chi[i]) { ok = 0; break; }
+      qhi[i] = (uint32_t)q2;
+    }
+    if (ok) break;
+  }
+  *e_out = e;
+}
+
 static int32_t widen(ora_ctx* c, int32_t bin_idx, uint32_t depth, uint32_t* next, uint32_t* maxd) {
   uint32_t me = (*next)++;
   if (depth > *maxd) *maxd = depth;
@@ -444,12 +480,14 @@ static int32_t widen(ora_ctx* c, int32_t bin_idx, uint32_t depth, uint32_t* next
     ++n;
   }
   wnode_t w; memset(&w, 0, sizeof w);
+  for (int k = 0; k < 3; ++k) {
+    float nlo = list[0].lo[k], nhi = list[0].hi[k], clo[4], chi[4];
+    for (int i = 0; i < n; ++i) { clo[i] = list[i].lo[k]; chi[i] = list[i].hi[k]; nlo = fmin2(nlo, clo[i]); nhi = fmax2(nhi, chi[i]); }
+    w.org[k] = nlo;
+    quantize_axis(clo, chi, n, nlo, nhi, &w.e[k], w.qlo[k], w.qhi[k]);
+  }
   for (int i = 0; i < 4; ++i) {
-    if (i >= n) {                                   /* unused slot: inverted box, never entered */
-      w.code[i] = ORA_EMPTY; w.lox[i] = w.loy[i] = w.loz[i] = 3.0e38f; w.hix[i] = w.hiy[i] = w.hiz[i] = -3.0e38f; continue;
-    }
-    w.lox[i] = list[i].lo[0]; w.loy[i] = list[i].lo[1]; w.loz[i] = list[i].lo[2];
-    w.hix[i] = list[i].hi[0]; w.hiy[i] = list[i].hi[1]; w.hiz[i] = list[i].hi[2];
+    if (i >= n) { w.code[i] = ORA_EMPTY; for (int k = 0; k < 3; ++k) { w.qlo[k][i] = 255; w.qhi[k][i] = 0; } continue; }
     w.code[i] = list[i].code < 0 ? list[i].code : widen(c, list[i].code, depth + 1, next, maxd);
   }
   c->wnodes[me] = w;
@@ -645,13 +683,24 @@ typedef struct { float t, u, v; int32_t prim; uint32_t pos; } hit_t;
  * mantissa bits make room for the slot, which also breaks ties), return them nearest first. */
 typedef struct { int32_t code; uint32_t key; } cand_t;
 typedef struct { int32_t code; float tq; } sent_t;
+/* slab test of child i of a quantised node: plane distance = fma(q, scale*inv, fma(org, inv, -ood)) */
+static inline int qbox_hit(const wnode_t* n, int i, const ray_t* r, float tmin, float tlimit, float* tn) {
+  float ax = pow2_biased(n->e[0]) * r->inv.x, ay = pow2_biased(n->e[1]) * r->inv.y, az = pow2_biased(n->e[2]) * r->inv.z;
+  float bx = fmaf(n->org[0], r->inv.x, -r->ood.x), by = fmaf(n->org[1], r->inv.y, -r->ood.y), bz = fmaf(n->org[2], r->inv.z, -r->ood.z);
+  float x0 = fmaf((float)n->qlo[0][i], ax, bx), x1 = fmaf((float)n->qhi[0][i], ax, bx);
+  float y0 = fmaf((float)n->qlo[1][i], ay, by), y1 = fmaf((float)n->qhi[1][i], ay, by);
+  float z0 = fmaf((float)n->qlo[2][i], az, bz), z1 = fmaf((float)n->qhi[2][i], az, bz);
+  float tnear = fmax2(fmax2(fmin2(x0, x1), fmin2(y0, y1)), fmax2(fmin2(z0, z1), tmin));
+  float tfar = fmin2(fmin2(fmax2(x0, x1), fmax2(y0, y1)), fmin2(fmax2(z0, z1), tlimit));
+  *tn = tnear;
+  return tnear <= tfar;
+}
 static inline int wide_step(const wnode_t* n, const ray_t* r, float tmin, float tlimit, cand_t out[4]) {
   int nh = 0;
   for (int i = 0; i < 4; ++i) {
     if (n->code[i] == ORA_EMPTY) continue;
-    float lo[3] = {n->lox[i], n->loy[i], n->loz[i]}, hi[3] = {n->hix[i], n->hiy[i], n->hiz[i]};
     float tn;
-    if (!box_hit(r, lo, hi, tmin, tlimit, &tn)) continue;
+    if (!qbox_hit(n, i, r, tmin, tlimit, &tn)) continue;
     union { float f; uint32_t u; } b; b.f = tn;
     cand_t cd; cd.code = n->code[i]; cd.key = (b.u & 0xfffffffcu) | (uint32_t)i;
     int j = nh++;
@@ -704,9 +753,8 @@ static int trace_any(const ora_ctx* c, v3 o, v3 d, float tmin, float tmax, trav_
       int32_t hit[4]; int nh = 0;
       for (int i = 0; i < 4; ++i) {
         if (n->code[i] == ORA_EMPTY) continue;
-        float lo[3] = {n->lox[i], n->loy[i], n->loz[i]}, hi[3] = {n->hix[i], n->hiy[i], n->hiz[i]};
         float tn;
-        if (box_hit(&r, lo, hi, tmin, tmax, &tn)) hit[nh++] = n->code[i];
+        if (qbox_hit(n, i, &r, tmin, tmax, &tn)) hit[nh++] = n->code[i];
       }
       for (int k = nh - 1; k >= 1; --k) stack[sp++] = hit[k];
       if (nh > 0) { cur = hit[0]; continue; }

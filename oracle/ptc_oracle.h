@@ -53,7 +53,8 @@ int ora_trace_any(ora_ctx*, const float* origins, const float* dirs, const float
 int ora_get_flat_scene(ora_ctx*, uint32_t* n_verts, uint32_t* n_tris, void* verts48,
                        uint32_t* indices, int32_t* tri_material);
 
-/* BVH as built: 4-wide nodes, n_nodes*32 floats (same record as the product's), sorted triangles n_tris*12 floats
+/* BVH as built: 4-wide quantised nodes, n_nodes*34 32-bit words each: org[3] (float bits), e[3], qlo[3][4], qhi[3][4],
+ * code[4]  (the product stores the same information packed into 48 bytes; tests decode both), sorted triangles n_tris*12 floats
  * (v0,prim | e1,class | e2,0).  NULL pointers to query sizes. */
 int ora_get_bvh(ora_ctx*, uint32_t* n_nodes, uint32_t* n_tris, float* nodes, float* tris);
 

@@ -12,7 +12,7 @@
 
 #define PT_DEV __device__ __forceinline__
 
-#define PT_LEAF_MAX 4
+#define PT_LEAF_MAX 2
 #define PT_RR_START 3u
 #define PT_RR_PMIN 0.05f
 #define PT_ALPHA_MIN 0.001f

