@@ -1,0 +1,130 @@
+// ptc_render — dependency-free C++17 offline renderer over the C-ABI (include/ptc.h).
+//   ptc_render --scene cornell|sphere --width W --height H --spp N --seed S --bounces B [--raster]
+//              --out image.pfm [--ppm image.ppm]
+// The scenes are the procedural stand-ins of BASELINE configs 1 and 2 (the reference's assets are stripped).
+#include "pbr_pt.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+
+namespace {
+using V3 = std::array<float, 3>;
+
+pbr::MeshBuilder::Primitive quad(V3 a, V3 b, V3 c, V3 d, int material) {   // CCW seen from the front
+  V3 e1{b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2{c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+  V3 n{e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+  float l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), le = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+  pbr::MeshBuilder::Primitive p;
+  p.material = material;
+  const V3 pts[4] = {a, b, c, d};
+  const float uv[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};
+  for (int i = 0; i < 4; ++i) {
+    pbr::MeshVertex v;
+    v.position = pts[i]; v.normal = {n[0] / l, n[1] / l, n[2] / l}; v.tangent = {e1[0] / le, e1[1] / le, e1[2] / le, 1.0f};
+    v.texCoords = {uv[i][0], uv[i][1]};
+    p.vertices.push_back(v);
+  }
+  p.indices = {0, 1, 2, 0, 2, 3};
+  return p;
+}
+
+pbr::MeshBuilder::Primitive uvSphere(int nu, int nv, float radius, int material) {
+  pbr::MeshBuilder::Primitive p;
+  p.material = material;
+  const double pi = 3.14159265358979323846;
+  for (int j = 0; j <= nv; ++j)
+    for (int i = 0; i <= nu; ++i) {
+      const double th = pi * j / nv, ph = 2.0 * pi * i / nu;
+      const float nx = (float)(std::sin(th) * std::cos(ph)), ny = (float)std::cos(th), nz = (float)(std::sin(th) * std::sin(ph));
+      pbr::MeshVertex v;
+      v.position = {radius * nx, radius * ny, radius * nz}; v.normal = {nx, ny, nz};
+      v.tangent = {(float)-std::sin(ph), 0.0f, (float)std::cos(ph), 1.0f}; v.texCoords = {(float)i / nu, (float)j / nv};
+      p.vertices.push_back(v);
+    }
+  for (int j = 0; j < nv; ++j)
+    for (int i = 0; i < nu; ++i) {
+      const std::uint32_t a = j * (nu + 1) + i, b = a + 1, c = a + nu + 1, d = c + 1;
+      if (j != 0) p.indices.insert(p.indices.end(), {a, b, c});
+      if (j != nv - 1) p.indices.insert(p.indices.end(), {b, d, c});
+    }
+  return p;
+}
+
+void buildCornell(pbr::PathTraceRenderSystem& rs) {
+  rs.beginScene();
+  const int white = rs.addMaterial({{0.73f, 0.73f, 0.73f, 1}, 0, 1, {0, 0, 0}});
+  const int red = rs.addMaterial({{0.65f, 0.05f, 0.05f, 1}, 0, 1, {0, 0, 0}});
+  const int green = rs.addMaterial({{0.12f, 0.45f, 0.15f, 1}, 0, 1, {0, 0, 0}});
+  const int light = rs.addMaterial({{0, 0, 0, 1}, 0, 1, {15, 15, 15}});
+  pbr::MeshBuilder mb;
+  mb.addPrimitive(quad({-1, -1, 1}, {1, -1, 1}, {1, -1, -1}, {-1, -1, -1}, white));
+  mb.addPrimitive(quad({-1, 1, -1}, {1, 1, -1}, {1, 1, 1}, {-1, 1, 1}, white));
+  mb.addPrimitive(quad({-1, -1, -1}, {1, -1, -1}, {1, 1, -1}, {-1, 1, -1}, white));
+  mb.addPrimitive(quad({-1, -1, 1}, {-1, -1, -1}, {-1, 1, -1}, {-1, 1, 1}, red));
+  mb.addPrimitive(quad({1, -1, -1}, {1, -1, 1}, {1, 1, 1}, {1, 1, -1}, green));
+  mb.addPrimitive(quad({-0.25f, 0.998f, -0.25f}, {0.25f, 0.998f, -0.25f}, {0.25f, 0.998f, 0.25f}, {-0.25f, 0.998f, 0.25f}, light));
+  for (int m : rs.addMesh(mb.build())) rs.addInstance(m, pbr::Transform{});
+  const float d = 1.0f / std::tan(20.0f * 3.14159265f / 180.0f);
+  rs.setCamera({0, 0, 1 + d}, {0, 0, 0}, 40.0f * 3.14159265f / 180.0f, 1.0f);
+  rs.commitScene();
+}
+
+void buildSphere(pbr::PathTraceRenderSystem& rs, float aspect) {
+  rs.beginScene();
+  const int gold = rs.addMaterial({{0.9f, 0.6f, 0.2f, 1}, 1.0f, 0.3f, {0, 0, 0}});
+  const int ground = rs.addMaterial({{0.6f, 0.6f, 0.6f, 1}, 0, 1, {0, 0, 0}});
+  const int light = rs.addMaterial({{0, 0, 0, 1}, 0, 1, {12, 11, 10}});
+  pbr::MeshBuilder mb;
+  mb.addPrimitive(uvSphere(100, 51, 1.0f, gold));
+  const int sphere = rs.addMesh(mb.build())[0];
+  pbr::MeshBuilder rest;
+  rest.addPrimitive(quad({-10, -1, 10}, {10, -1, 10}, {10, -1, -10}, {-10, -1, -10}, ground));
+  rest.addPrimitive(quad({-2, 4, -2}, {2, 4, -2}, {2, 4, 2}, {-2, 4, 2}, light));
+  const float a = 30.0f * 3.14159265f / 180.0f;
+  rs.addInstance(sphere, pbr::Transform{{0, -0.2f, 0}, {std::cos(a / 2), 0, std::sin(a / 2), 0}, {1, 0.8f, 1}});
+  for (int m : rs.addMesh(rest.build())) rs.addInstance(m, pbr::Transform{});
+  rs.setCamera({0, 1.2f, 4.5f}, {0, -0.1f, 0}, 45.0f * 3.14159265f / 180.0f, aspect);
+  rs.commitScene();
+}
+}  // namespace
+
+int main(int argc, char** argv) {
+  std::string scene = "cornell", out = "out.pfm", ppm;
+  int w = 256, h = 256, spp = 64, bounces = 8, device = 0, integrator = PTC_INTEGRATOR_PATH;
+  std::uint64_t seed = 1;
+  for (int i = 1; i < argc; ++i) {
+    const std::string a = argv[i];
+    auto next = [&]() -> const char* { if (i + 1 >= argc) { std::cerr << "missing value for " << a << "\n"; std::exit(2); } return argv[++i]; };
+    if (a == "--scene") scene = next(); else if (a == "--width") w = std::atoi(next()); else if (a == "--height") h = std::atoi(next());
+    else if (a == "--spp") spp = std::atoi(next()); else if (a == "--seed") seed = std::strtoull(next(), nullptr, 10);
+    else if (a == "--bounces") bounces = std::atoi(next()); else if (a == "--device") device = std::atoi(next());
+    else if (a == "--out") out = next(); else if (a == "--ppm") ppm = next(); else if (a == "--raster") integrator = PTC_INTEGRATOR_RASTER_COMPAT;
+    else { std::cerr << "unknown argument " << a << "\n"; return 2; }
+  }
+  try {
+    pbr::PathTraceRenderSystem rs(device);
+    if (scene == "cornell") buildCornell(rs); else if (scene == "sphere") buildSphere(rs, (float)w / h); else throw std::runtime_error("unknown scene " + scene);
+    const std::vector<float> img = rs.render(w, h, spp, seed, bounces, integrator);
+    const ptc_stats st = rs.stats();
+    std::ofstream f(out, std::ios::binary);                       // PFM stores rows bottom-up
+    f << "PF\n" << w << " " << h << "\n-1.0\n";
+    for (int y = h - 1; y >= 0; --y)
+      for (int x = 0; x < w; ++x) f.write(reinterpret_cast<const char*>(&img[((std::size_t)y * w + x) * 4]), 12);
+    if (!ppm.empty()) {
+      const std::vector<std::uint8_t> ldr = rs.tonemap();
+      std::ofstream g(ppm, std::ios::binary);
+      g << "P6\n" << w << " " << h << "\n255\n";
+      for (std::size_t p = 0; p < (std::size_t)w * h; ++p) g.write(reinterpret_cast<const char*>(&ldr[p * 4]), 3);
+    }
+    std::printf("{\"scene\": \"%s\", \"paths\": %llu, \"seconds_render\": %.6f, \"mpaths_per_s\": %.2f, \"node_visits\": %llu}\n", scene.c_str(),
+                (unsigned long long)st.paths, st.seconds_render, st.seconds_render > 0 ? st.paths / st.seconds_render / 1e6 : 0.0,
+                (unsigned long long)(st.node_visits_closest + st.node_visits_any));
+  } catch (std::exception const& e) {
+    std::cerr << "ptc_render: " << e.what() << "\n";
+    return 1;
+  }
+  return 0;
+}

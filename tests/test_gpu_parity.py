@@ -242,3 +242,30 @@ def test_full_size_properties(gpu):
         pt.sync()
         acc += gpu.dist.radiance_tensor(pt, w, h)
     assert np.array_equal(acc.cpu().numpy(), a)
+
+
+def test_cpp_host_cli(gpu, ora, tmp_path):
+    """The C++ host (host/pbr_pt.hpp + ptc_render.cpp, mirroring the reference's MeshBuilder/Transform/camera
+    interface) drives the same C-ABI: its Cornell box must equal the oracle's render of the Python-built scene."""
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(gpu.ptc.LIB_PATH), "ptc_render")
+    assert os.path.exists(exe), "ptc_render not built"
+    out, ppm = str(tmp_path / "c.pfm"), str(tmp_path / "c.ppm")
+    r = subprocess.run([exe, "--scene", "cornell", "--width", "96", "--height", "64", "--spp", "8", "--seed", "5", "--bounces", "4", "--out", out, "--ppm", ppm],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    assert info["paths"] == 96 * 64 * 8
+    raw = open(out, "rb").read()
+    head, body = raw.split(b"-1.0\n", 1)
+    assert head.startswith(b"PF\n96 64")
+    img = np.frombuffer(body, "<f4").reshape(64, 96, 3)[::-1]                 # PFM rows are bottom-up
+    d = gpu.scenes.cornell_box()
+    d.camera.aspect = 1.0                                                     # the CLI keeps Cornell's aspect 1 like scenes.cornell_box()
+    ref = ora.Oracle().load_scene(d).render(96, 64, 8, seed=5, max_bounces=4)
+    assert _bits_equal(np.ascontiguousarray(img), np.ascontiguousarray(ref[..., :3]))
+    ldr = np.frombuffer(open(ppm, "rb").read().split(b"255\n", 1)[1], np.uint8).reshape(64, 96, 3)
+    assert np.array_equal(ldr, ora.tonemap_rgba8(ref)[..., :3])
+    bad = subprocess.run([exe, "--scene", "nope"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 1 and "unknown scene" in bad.stderr
