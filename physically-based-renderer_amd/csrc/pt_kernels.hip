@@ -26,6 +26,8 @@
 #endif                            // while others wait at a leaf (keeps both phases well populated)
 #define SHADE_BLOCK 512
 #define SHADE_WAVES (SHADE_BLOCK / 64)
+#define SHADE_LDS_LIGHTS 64       // emitter table and material table are staged in LDS when they fit
+#define SHADE_LDS_MATS 64
 #define CUR_DONE ((int)0x80000000)
 #define HIT_CLASS_SHIFT 28
 
@@ -445,8 +447,22 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DevScene sc, DevFrame fr,
   __shared__ uint32_t s_cnt[4][SHADE_WAVES];     // per-wave counts: class0, class1, shadow, next
   __shared__ uint32_t s_base[2];                 // block's base slots in the shadow / next queues
   __shared__ uint16_t s_idx[SHADE_BLOCK];        // sorted local slot of each work item (0xffff = none)
+  // small scenes-wide tables staged once per block: emitter records + power cdf, materials
+  __shared__ float4 s_light[SHADE_LDS_LIGHTS * 5];
+  __shared__ float s_cdf[SHADE_LDS_LIGHTS];
+  __shared__ float4 s_mat[SHADE_LDS_MATS * 2];
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
+  const bool lds_lights = sc.n_lights <= SHADE_LDS_LIGHTS, lds_mats = sc.n_mats <= SHADE_LDS_MATS;
+  if (lds_lights) {
+    for (uint32_t i = threadIdx.x; i < sc.n_lights * 5u; i += SHADE_BLOCK) s_light[i] = sc.lights[i];
+    for (uint32_t i = threadIdx.x; i < sc.n_lights; i += SHADE_BLOCK) s_cdf[i] = sc.cdf[i];
+  }
+  if (lds_mats)
+    for (uint32_t i = threadIdx.x; i < sc.n_mats * 2u; i += SHADE_BLOCK) s_mat[i] = sc.mats[(i >> 1) * 3u + (i & 1u)];
+  __syncthreads();
+  const float4* lights = lds_lights ? s_light : sc.lights;
+  const float* cdf = lds_lights ? s_cdf : sc.cdf;
   const RayQ rin = q.ray[qi], rout = q.ray[qi ^ 1];
   const uint32_t n = q.cnt[CNT_RAYS];
   const uint32_t n_windows = (n + SHADE_BLOCK - 1u) / SHADE_BLOCK;
@@ -499,11 +515,11 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DevScene sc, DevFrame fr,
       const uint32_t path = __float_as_uint(Cq.z), key = __float_as_uint(Cq.w);
       const float ht = H.x, hu = H.z, hv = H.w;
       const uint32_t prim = (uint32_t)__float_as_int(H.y) & ((1u << HIT_CLASS_SHIFT) - 1u);
-      // ---- P5 surface reconstruction: gather the three R1 vertex records ----
-      const uint32_t i0 = sc.widx[prim * 3 + 0], i1 = sc.widx[prim * 3 + 1], i2 = sc.widx[prim * 3 + 2];
-      const float* va = sc.wverts + (size_t)i0 * 12; const float* vb = sc.wverts + (size_t)i1 * 12; const float* vc = sc.wverts + (size_t)i2 * 12;
-      const v3 Pa = V3(va[0], va[1], va[2]), Pb = V3(vb[0], vb[1], vb[2]), Pc = V3(vc[0], vc[1], vc[2]);
-      const v3 Na = V3(va[3], va[4], va[5]), Nb = V3(vb[3], vb[4], vb[5]), Nc = V3(vc[3], vc[4], vc[5]);
+      // ---- P5 surface reconstruction from the primitive's shading record (five 16-byte loads) ----
+      const float4* rec = sc.shade + (size_t)prim * 5;
+      const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4];
+      const v3 Pa = V3(r0.x, r0.y, r0.z), Pb = V3(r1.x, r1.y, r1.z), Pc = V3(r2.x, r2.y, r2.z);
+      const v3 Na = V3(r2.w, r3.x, r3.y), Nb = V3(r3.z, r3.w, r4.x), Nc = V3(r4.y, r4.z, r4.w);
       const float hw = 1.0f - hu - hv;
       const v3 P = V3(pt_fma(Pc.x, hv, pt_fma(Pb.x, hu, Pa.x * hw)), pt_fma(Pc.y, hv, pt_fma(Pb.y, hu, Pa.y * hw)), pt_fma(Pc.z, hv, pt_fma(Pb.z, hu, Pa.z * hw)));
       v3 ng = normalize3(cross3(Pb - Pa, Pc - Pa));
@@ -513,12 +529,12 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DevScene sc, DevFrame fr,
       if (dot3(ns, ng) < 0.0f) ns = -ns;
       if (!front) { ng = -ng; ns = -ns; }
       if (!(dot3(ns, wo) > 0.0f)) ns = ng;
-      const int mat = sc.tri_mat[prim];
-      const float4 M0 = sc.mats[mat * 3 + 0], M1 = sc.mats[mat * 3 + 1];
+      const int mat = __float_as_int(r0.w);
+      const float4 M0 = lds_mats ? s_mat[mat * 2 + 0] : sc.mats[mat * 3 + 0], M1 = lds_mats ? s_mat[mat * 2 + 1] : sc.mats[mat * 3 + 1];
       // ---- emission (one-sided), MIS against next-event estimation ----
-      const int li = sc.prim_light[prim];
+      const int li = __float_as_int(r1.w);
       if (li >= 0 && front) {
-        const float4 l0 = sc.lights[li * 5 + 0], l1 = sc.lights[li * 5 + 1], l4 = sc.lights[li * 5 + 4];
+        const float4 l0 = lights[li * 5 + 0], l1 = lights[li * 5 + 1], l4 = lights[li * 5 + 4];
         float wgt = 1.0f;
         if (b > 0u) {
           const float cosl = dot3(ng, wo);
@@ -541,8 +557,8 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DevScene sc, DevFrame fr,
         if (sc.n_lights > 0u) {
           const float u0 = rng_f(key, rb, 0), r1 = rng_f(key, rb, 1), r2 = rng_f(key, rb, 2);
           uint32_t lo = 0, hi = sc.n_lights - 1u;
-          while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sc.cdf[mid] > u0) hi = mid; else lo = mid + 1u; }
-          const float4 l0 = sc.lights[lo * 5 + 0], l1 = sc.lights[lo * 5 + 1], l2 = sc.lights[lo * 5 + 2], l3 = sc.lights[lo * 5 + 3], l4 = sc.lights[lo * 5 + 4];
+          while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cdf[mid] > u0) hi = mid; else lo = mid + 1u; }
+          const float4 l0 = lights[lo * 5 + 0], l1 = lights[lo * 5 + 1], l2 = lights[lo * 5 + 2], l3 = lights[lo * 5 + 3], l4 = lights[lo * 5 + 4];
           const float su = pt_sqrt(r1);
           const float bu = su * (1.0f - r2), bv = su * r2;
           const v3 y = vfma(V3(l2.x, l2.y, l2.z), bv, vfma(V3(l1.x, l1.y, l1.z), bu, V3(l0.x, l0.y, l0.z)));
@@ -661,11 +677,11 @@ __global__ __launch_bounds__(256) void k_shade_raster(DevScene sc, DevCamera cam
   if (pc >= 0) {
     const int prim = pc & ((1 << HIT_CLASS_SHIFT) - 1);
     const float hu = H.z, hv = H.w, hw = 1.0f - hu - hv;
-    const uint32_t i0 = sc.widx[prim * 3 + 0], i1 = sc.widx[prim * 3 + 1], i2 = sc.widx[prim * 3 + 2];
-    const float* va = sc.wverts + (size_t)i0 * 12; const float* vb = sc.wverts + (size_t)i1 * 12; const float* vc = sc.wverts + (size_t)i2 * 12;
-    const v3 P = V3(pt_fma(vc[0], hv, pt_fma(vb[0], hu, va[0] * hw)), pt_fma(vc[1], hv, pt_fma(vb[1], hu, va[1] * hw)), pt_fma(vc[2], hv, pt_fma(vb[2], hu, va[2] * hw)));
-    const v3 N = normalize3(V3(pt_fma(vc[3], hv, pt_fma(vb[3], hu, va[3] * hw)), pt_fma(vc[4], hv, pt_fma(vb[4], hu, va[4] * hw)), pt_fma(vc[5], hv, pt_fma(vb[5], hu, va[5] * hw))));
-    const int mat = sc.tri_mat[prim];
+    const float4* rec = sc.shade + (size_t)prim * 5;
+    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4];
+    const v3 P = V3(pt_fma(r2.x, hv, pt_fma(r1.x, hu, r0.x * hw)), pt_fma(r2.y, hv, pt_fma(r1.y, hu, r0.y * hw)), pt_fma(r2.z, hv, pt_fma(r1.z, hu, r0.z * hw)));
+    const v3 N = normalize3(V3(pt_fma(r4.y, hv, pt_fma(r3.z, hu, r2.w * hw)), pt_fma(r4.z, hv, pt_fma(r3.w, hu, r3.x * hw)), pt_fma(r4.w, hv, pt_fma(r4.x, hu, r3.y * hw))));
+    const int mat = __float_as_int(r0.w);
     const float4 M0 = sc.mats[mat * 3 + 0], M2 = sc.mats[mat * 3 + 2];
     const v3 V = normalize3(V3(cam.pos[0], cam.pos[1], cam.pos[2]) - P);
     const v3 Hh = normalize3(V + V);

@@ -354,14 +354,10 @@ int ptc_scene_commit(ptc_ctx* c) {
     rc |= dev_upload(c, c->scene_allocs, &p, B.mats); d.mats = (const float4*)p;
     rc |= dev_upload(c, c->scene_allocs, &p, B.lights); d.lights = (const float4*)p;
     rc |= dev_upload(c, c->scene_allocs, &d.cdf, B.cdf);
-    std::vector<float> wv((const float*)B.wverts.data(), (const float*)B.wverts.data() + B.wverts.size() * 12);
-    rc |= dev_upload(c, c->scene_allocs, &d.wverts, wv);
-    rc |= dev_upload(c, c->scene_allocs, &d.widx, B.widx);
-    rc |= dev_upload(c, c->scene_allocs, &d.tri_mat, B.tri_mat);
-    rc |= dev_upload(c, c->scene_allocs, &d.prim_light, B.prim_light);
+    rc |= dev_upload(c, c->scene_allocs, &p, B.shade); d.shade = (const float4*)p;
   }
   if (rc) { free_all(c->scene_allocs); return PTC_E_DEVICE; }
-  d.n_lights = B.n_lights; d.n_nodelets = B.n_nodelets; d.ray_eps = B.ray_eps;
+  d.n_lights = B.n_lights; d.n_mats = (uint32_t)c->mats.size(); d.n_nodelets = B.n_nodelets; d.ray_eps = B.ray_eps;
   c->dsc = d;
   { int rc2 = configure_launch(c); if (rc2) { free_all(c->scene_allocs); return rc2; } }
   c->committed = true; c->in_frame = false;

@@ -11,14 +11,13 @@
 struct DevScene {
   const float4* nodes;        // 3 × 16 B per 4-wide node (48 B): org+exponents, 8-bit child planes, child/triangle bases (ptc_scene.cpp)
   const float4* tris;         // 3 × float4 per triangle record (48 B): (v0,prim) (e1,class) (e2,-), grouped by owning node
-  const float* wverts;        // world-space ptc_vertex records, 12 floats each (R1 layout)
-  const uint32_t* widx;       // 3 per original primitive id
-  const int32_t* tri_mat;     // material per original primitive id
-  const int32_t* prim_light;  // emitter index per original primitive id, or -1
+  const float4* shade;        // 5 × float4 per original primitive id (80 B): the three R1 vertex records de-indexed to what
+                              // shading reads: (Pa,mat) (Pb,light) (Pc,Na.x) (Na.yz,Nb.xy) (Nb.z,Nc.xyz)
   const float4* mats;         // 3 × float4 per material: (base.rgb, metallic) (emissive.rgb, roughness) (base.a,-,-,-)
   const float4* lights;       // 5 × float4 per emitter: (v0,area) (e1,pmf) (e2,-) (ng,-) (Le,-)
   const float* cdf;           // emitter power cdf
   uint32_t n_lights;
+  uint32_t n_mats;
   uint32_t n_nodelets;        // leading nodes (BFS order) that the trace kernels stage in LDS
   uint2* stack_ovf;           // per-lane traversal-stack overflow: [wave][ovf_depth][64] entries of (code, tnear)
   uint32_t ovf_depth;
@@ -84,6 +83,7 @@ struct HostBuilt {
   std::vector<uint32_t> widx;
   std::vector<int32_t> tri_mat;
   std::vector<int32_t> prim_light;
+  std::vector<float> shade;      // 20 floats per primitive (see DevScene::shade)
   std::vector<float> nodes;      // 12 words per 4-wide node
   std::vector<float> tris;       // 12 floats per triangle record (node order)
   std::vector<float> mats;       // 12 floats per material

@@ -489,6 +489,19 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
     B.cdf[i] = run / total;
     B.lights[i * 20 + 7] = weight[i] / total;
   }
+  // ---- per-primitive shading records: positions + normals of the three vertices, material, emitter index
+  B.shade.resize((size_t)n * 20);
+  for (uint32_t p = 0; p < n; ++p) {
+    const HostVertex& a = B.wverts[B.widx[p * 3 + 0]];
+    const HostVertex& b = B.wverts[B.widx[p * 3 + 1]];
+    const HostVertex& c = B.wverts[B.widx[p * 3 + 2]];
+    float* o = &B.shade[(size_t)p * 20];
+    o[0] = a.position[0]; o[1] = a.position[1]; o[2] = a.position[2]; std::memcpy(&o[3], &B.tri_mat[p], 4);
+    o[4] = b.position[0]; o[5] = b.position[1]; o[6] = b.position[2]; std::memcpy(&o[7], &B.prim_light[p], 4);
+    o[8] = c.position[0]; o[9] = c.position[1]; o[10] = c.position[2]; o[11] = a.normal[0];
+    o[12] = a.normal[1]; o[13] = a.normal[2]; o[14] = b.normal[0]; o[15] = b.normal[1];
+    o[16] = b.normal[2]; o[17] = c.normal[0]; o[18] = c.normal[1]; o[19] = c.normal[2];
+  }
   if (!B.cdf.empty()) B.cdf.back() = 1.0f;
   if (B.cdf.empty()) B.cdf.push_back(1.0f);
   if (B.lights.empty()) B.lights.assign(20, 0.0f);

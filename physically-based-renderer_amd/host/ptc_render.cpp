@@ -67,8 +67,10 @@ void buildCornell(pbr::PathTraceRenderSystem& rs) {
   mb.addPrimitive(quad({1, -1, -1}, {1, -1, 1}, {1, 1, 1}, {1, 1, -1}, green));
   mb.addPrimitive(quad({-0.25f, 0.998f, -0.25f}, {0.25f, 0.998f, -0.25f}, {0.25f, 0.998f, 0.25f}, {-0.25f, 0.998f, 0.25f}, light));
   for (int m : rs.addMesh(mb.build())) rs.addInstance(m, pbr::Transform{});
-  const float d = 1.0f / std::tan(20.0f * 3.14159265f / 180.0f);
-  rs.setCamera({0, 0, 1 + d}, {0, 0, 0}, 40.0f * 3.14159265f / 180.0f, 1.0f);
+  // double arithmetic then one rounding to float, like the Python scene generator (pbr_amd/scenes.py)
+  const double deg = 3.14159265358979323846 / 180.0;
+  const double d = 1.0 / std::tan(20.0 * deg);
+  rs.setCamera({0, 0, (float)(1.0 + d)}, {0, 0, 0}, (float)(40.0 * deg), 1.0f);
   rs.commitScene();
 }
 
@@ -83,10 +85,10 @@ void buildSphere(pbr::PathTraceRenderSystem& rs, float aspect) {
   pbr::MeshBuilder rest;
   rest.addPrimitive(quad({-10, -1, 10}, {10, -1, 10}, {10, -1, -10}, {-10, -1, -10}, ground));
   rest.addPrimitive(quad({-2, 4, -2}, {2, 4, -2}, {2, 4, 2}, {-2, 4, 2}, light));
-  const float a = 30.0f * 3.14159265f / 180.0f;
-  rs.addInstance(sphere, pbr::Transform{{0, -0.2f, 0}, {std::cos(a / 2), 0, std::sin(a / 2), 0}, {1, 0.8f, 1}});
+  const double a = 30.0 * (3.14159265358979323846 / 180.0);
+  rs.addInstance(sphere, pbr::Transform{{0, -0.2f, 0}, {(float)std::cos(a / 2), 0, (float)std::sin(a / 2), 0}, {1, 0.8f, 1}});
   for (int m : rs.addMesh(rest.build())) rs.addInstance(m, pbr::Transform{});
-  rs.setCamera({0, 1.2f, 4.5f}, {0, -0.1f, 0}, 45.0f * 3.14159265f / 180.0f, aspect);
+  rs.setCamera({0, 1.2f, 4.5f}, {0, -0.1f, 0}, (float)(45.0 * (3.14159265358979323846 / 180.0)), aspect);
   rs.commitScene();
 }
 }  // namespace
