@@ -17,7 +17,12 @@
 #include "pt_device.h"
 #include "ptc_internal.h"
 
+#ifndef TRACE_BLOCK
 #define TRACE_BLOCK 256
+#endif
+#ifndef TRACE_MIN_WAVES
+#define TRACE_MIN_WAVES 7         // waves per SIMD the register allocator must leave room for (launch bounds)
+#endif
 #define TRACE_WAVES (TRACE_BLOCK / 64)
 #define TRACE_CHUNK 512u          // rays per work-fetch atomic
 #define TRACE_REFILL_IDLE 16      // refill as soon as this many lanes are idle
@@ -247,7 +252,7 @@ struct Reservoir {
 // The hit record (t, prim | class<<28, u, v) is written IN PLACE at the ray's slot (miss: prim = -1).
 // CULL: R6 back-face culling + per-ray [tmin,tmax] from B.zw (raster-compat primary rays).
 template <bool CULL, bool NODELETS>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DevScene sc, DevQueues q, int qi, int stack_lds) {
+__global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_closest(DevScene sc, DevQueues q, int qi, int stack_lds) {
   extern __shared__ float4 lds_raw[];
   float4* lds_nodes = lds_raw;                                                       // [n_nodelets × 48 B]
   uint2* lds_stack = reinterpret_cast<uint2*>(lds_raw + (NODELETS ? (size_t)sc.n_nodelets * 3 : 0));   // [waves][L][64]
@@ -263,6 +268,12 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DevScene sc, DevQ
   uint32_t nt = 0;                               // per lane (updated inside the divergent leaf loop)
   uint32_t d_node = 0, d_tri = 0, d_leaf = 0, d_round = 0;
   (void)d_node; (void)d_tri; (void)d_leaf; (void)d_round;
+#ifdef PT_STAMP
+  unsigned long long t_refill = 0, t_node = 0, t_leaf = 0, t_fin = 0, t_mark = __builtin_amdgcn_s_memtime();
+#define STAMP(acc) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - t_mark; t_mark = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(acc) do { } while (0)
+#endif
   Reservoir res; res.init(n);
   WStack st;
   st.init(lds_stack + (size_t)wave * (size_t)stack_lds * 64u + lane,
@@ -287,6 +298,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DevScene sc, DevQ
       st.reset();
       cur = 0;
     }
+    STAMP(t_refill);
     if (!__ballot(cur != CUR_DONE)) {
       if (res.exhausted) break;
       continue;
@@ -308,6 +320,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DevScene sc, DevQ
           }
         }
       }
+      STAMP(t_node);
       if (cur < 0 && cur > CUR_FINISHED) {                                        // a leaf
         const uint32_t code = (uint32_t)~cur;
         const uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
@@ -326,11 +339,13 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DevScene sc, DevQ
         cur = CUR_FINISHED;
         while (!st.empty()) { const uint2 e = st.pop(); if (__uint_as_float(e.y) > best_t) continue; cur = (int)e.x; break; }
       }
+      STAMP(t_leaf);
       nh += (unsigned long long)__popcll(__ballot(cur == CUR_FINISHED && found));
       if (cur == CUR_FINISHED) {                                       // this lane's ray is finished: publish in place
         q.hit[ri] = make_float4(found ? best_t : -1.0f, __int_as_float(found ? (best_prim | (best_cls << HIT_CLASS_SHIFT)) : -1), best_u, best_v);
         cur = CUR_DONE;
       }
+      STAMP(t_fin);
     } while (__popcll(__ballot(cur == CUR_DONE)) < TRACE_REFILL_IDLE || (res.exhausted && res.next >= res.end && __ballot(cur != CUR_DONE)));
   }
   const unsigned long long c_tris = wave_sum(nt);
@@ -338,6 +353,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DevScene sc, DevQ
     atomicAdd(&q.stats[ST_NODES_C], nv); atomicAdd(&q.stats[ST_TRIS_C], c_tris);
     atomicAdd(&q.stats[ST_SEGMENTS], nr); atomicAdd(&q.stats[ST_HITS], nh);
   }
+#ifdef PT_STAMP
+  if (lane == 0) { atomicAdd(&q.stats[ST_DIAG_NODE_ITERS], t_node); atomicAdd(&q.stats[ST_DIAG_TRI_ITERS], t_leaf); atomicAdd(&q.stats[ST_DIAG_LEAF_VISITS], t_fin); atomicAdd(&q.stats[ST_DIAG_ROUNDS], t_refill); }
+#endif
 #ifdef PT_DIAG
   {
     unsigned long long a0 = wave_sum(d_node), a1 = wave_sum(d_tri), a2 = wave_sum(d_leaf), a3 = wave_sum(d_round);
@@ -351,7 +369,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DevScene sc, DevQ
 // fixed); an unoccluded ray adds its contribution to the path's radiance word (single owner: one shadow
 // ray per path per bounce).
 template <bool NODELETS, bool DEBUG_OUT>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_any(DevScene sc, DevQueues q, int stack_lds, uint8_t* debug_out) {
+__global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_any(DevScene sc, DevQueues q, int stack_lds, uint8_t* debug_out) {
   extern __shared__ float4 lds_raw[];
   float4* lds_nodes = lds_raw;
   uint2* lds_stack = reinterpret_cast<uint2*>(lds_raw + (NODELETS ? (size_t)sc.n_nodelets * 3 : 0));
@@ -728,6 +746,8 @@ __global__ __launch_bounds__(256) void k_tonemap(const float4* radiance, uint32_
 static size_t trace_lds_bytes(const LaunchCfg& cfg, const DevScene& sc) {
   return (size_t)sc.n_nodelets * 48 + (size_t)TRACE_WAVES * cfg.stack_lds * 64 * 8;
 }
+
+int pt_trace_block_threads() { return TRACE_BLOCK; }
 
 void pt_launch_set_counts(hipStream_t s, const DevQueues& q, uint32_t n_rays, uint32_t n_shadow) { hipLaunchKernelGGL(k_set_counts, dim3(1), dim3(64), 0, s, q.cnt, n_rays, n_shadow); }
 void pt_launch_advance(hipStream_t s, const DevQueues& q) { hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, s, q.cnt); }

@@ -32,7 +32,8 @@ struct ptc_ctx {
   std::string err;
   LaunchCfg cfg{};
   uint32_t nodelet_budget = 200;  // wide nodes staged in LDS (breadth-first top of the tree, 48 B each: 9.4 KB)
-  size_t max_batch_paths = (size_t)1 << 25;   // paths per wavefront batch: large batches amortise launch tails (288 GB of HBM)
+  size_t max_batch_paths = (size_t)1 << 27;   // paths in flight over all lanes: large batches amortise launch tails (sized for 288 GB of HBM:
+                                              // 184 B per path -> 24.7 GB of queues at 1080p x 32 spp x 2 lanes)
   bool timing = true;
   // description
   std::vector<HostMaterial> mats;
@@ -47,9 +48,15 @@ struct ptc_ctx {
   DevScene dsc{};
   DevCamera cam{};
   std::vector<void*> scene_allocs;
-  // queues
+  // queues (lane 0); further lanes run independent batches on their own streams so that one batch's
+  // launch tails overlap another batch's full-occupancy phases
   DevQueues q{};
   std::vector<void*> queue_allocs;
+  struct Lane { hipStream_t stream = nullptr; DevQueues q{}; std::vector<void*> allocs; uint2* stack_ovf = nullptr; hipEvent_t acc_done = nullptr; };
+  std::vector<Lane> extra;          // lanes 1..n_lanes-1
+  int n_lanes = 2;
+  hipEvent_t acc_done0 = nullptr;   // lane 0's "accumulate finished" event
+  uint64_t batches_issued = 0;
   // frame
   bool in_frame = false;
   DevFrame fr{};
@@ -108,27 +115,34 @@ int ensure_buf_f4(ptc_ctx* c, DevBuf<float4>& b, size_t n) {
   return PTC_OK;
 }
 
-int ensure_queues(ptc_ctx* c, uint32_t cap) {
-  if (c->q.cap >= cap && c->q.cnt) return PTC_OK;
-  free_all(c->queue_allocs);
+int ensure_queues_in(ptc_ctx* c, DevQueues& dst, std::vector<void*>& allocs, uint32_t cap) {
+  if (dst.cap >= cap && dst.cnt) return PTC_OK;
+  free_all(allocs);
   DevQueues q{};
   int rc = 0;
   for (int k = 0; k < 2; ++k) {
-    rc |= dev_alloc(c, c->queue_allocs, &q.ray[k].A, cap); rc |= dev_alloc(c, c->queue_allocs, &q.ray[k].B, cap);
-    rc |= dev_alloc(c, c->queue_allocs, &q.ray[k].C, cap); rc |= dev_alloc(c, c->queue_allocs, &q.ray[k].D, cap);
+    rc |= dev_alloc(c, allocs, &q.ray[k].A, cap); rc |= dev_alloc(c, allocs, &q.ray[k].B, cap);
+    rc |= dev_alloc(c, allocs, &q.ray[k].C, cap); rc |= dev_alloc(c, allocs, &q.ray[k].D, cap);
   }
-  rc |= dev_alloc(c, c->queue_allocs, &q.shadow.A, cap); rc |= dev_alloc(c, c->queue_allocs, &q.shadow.B, cap);
-  rc |= dev_alloc(c, c->queue_allocs, &q.shadow.C, cap);
-  rc |= dev_alloc(c, c->queue_allocs, &q.hit, cap); rc |= dev_alloc(c, c->queue_allocs, &q.lpath, cap);
-  rc |= dev_alloc(c, c->queue_allocs, &q.cnt, (size_t)CNT_N);
-  rc |= dev_alloc(c, c->queue_allocs, &q.stats, (size_t)ST_N);
-  if (rc) { free_all(c->queue_allocs); c->q = DevQueues{}; return rc < 0 ? PTC_E_DEVICE : rc; }
+  rc |= dev_alloc(c, allocs, &q.shadow.A, cap); rc |= dev_alloc(c, allocs, &q.shadow.B, cap);
+  rc |= dev_alloc(c, allocs, &q.shadow.C, cap);
+  rc |= dev_alloc(c, allocs, &q.hit, cap); rc |= dev_alloc(c, allocs, &q.lpath, cap);
+  rc |= dev_alloc(c, allocs, &q.cnt, (size_t)CNT_N);
+  rc |= dev_alloc(c, allocs, &q.stats, (size_t)ST_N);
+  if (rc) { free_all(allocs); dst = DevQueues{}; return rc < 0 ? PTC_E_DEVICE : rc; }
   HIP_TRY(c, hipMemset(q.cnt, 0, CNT_N * sizeof(uint32_t)));
   HIP_TRY(c, hipMemset(q.stats, 0, ST_N * sizeof(unsigned long long)));
   q.cap = cap;
-  c->q = q;
+  dst = q;
   return PTC_OK;
 }
+int ensure_queues(ptc_ctx* c, uint32_t cap) { return ensure_queues_in(c, c->q, c->queue_allocs, cap); }
+
+// lane accessors: lane 0 is the context's primary stream / queues
+hipStream_t lane_stream(ptc_ctx* c, int l) { return l == 0 ? c->stream : c->extra[(size_t)l - 1].stream; }
+DevQueues& lane_q(ptc_ctx* c, int l) { return l == 0 ? c->q : c->extra[(size_t)l - 1].q; }
+hipEvent_t lane_acc_event(ptc_ctx* c, int l) { return l == 0 ? c->acc_done0 : c->extra[(size_t)l - 1].acc_done; }
+DevScene lane_scene(ptc_ctx* c, int l) { DevScene d = c->dsc; if (l > 0) d.stack_ovf = c->extra[(size_t)l - 1].stack_ovf; return d; }
 
 hipEvent_t next_event(ptc_ctx* c) {
   if (c->events_used == c->event_pool.size()) {
@@ -138,63 +152,87 @@ hipEvent_t next_event(ptc_ctx* c) {
   }
   return c->event_pool[c->events_used++];
 }
-struct ScopedSpan {   // records a start/stop event pair around launches on the context's stream
-  ptc_ctx* c; Span s{}; bool on;
-  ScopedSpan(ptc_ctx* c_, int kind) : c(c_), on(c_->timing) {
+struct ScopedSpan {   // records a start/stop event pair around launches on one of the context's streams
+  ptc_ctx* c; hipStream_t st; Span s{}; bool on;
+  ScopedSpan(ptc_ctx* c_, hipStream_t st_, int kind) : c(c_), st(st_), on(c_->timing) {
     if (!on) return;
     s.kind = kind; s.a = next_event(c); s.b = next_event(c);
     if (!s.a || !s.b) { on = false; return; }
-    (void)hipEventRecord(s.a, c->stream);
+    (void)hipEventRecord(s.a, st);
   }
-  ~ScopedSpan() { if (on) { (void)hipEventRecord(s.b, c->stream); c->spans.push_back(s); } }
+  ~ScopedSpan() { if (on) { (void)hipEventRecord(s.b, st); c->spans.push_back(s); } }
 };
 
 int configure_launch(ptc_ctx* c) {
   // Traversal stack: a 4-wide node defers up to 3 children per level, so a ray needs at most
   // 3·(depth+1) entries.  `stack_lds` of them live in LDS (8 B each, 512 B per level and wave), the rest in
-  // a global overflow slab.  LDS per 256-thread block = nodelets·48 B + 4 waves·stack_lds·512 B.
+  // a global overflow slab.  LDS per block = nodelets·48 B + waves·stack_lds·512 B.
   const int need = 3 * ((int)c->built.max_depth + 1);
   int l = 8;    // measured on MI355X: 5 blocks/CU (VGPR-bound), each 8 x 2 KB of stack + 200 nodelets, beats deeper LDS stacks
   if (const char* e = std::getenv("PTC_STACK_LDS")) { int v = std::atoi(e); if (v >= 1 && v <= 64) l = v; }
   if (l > need) l = need;
   c->cfg.stack_lds = l;
-  const size_t lds = (size_t)c->built.n_nodelets * 48 + (size_t)4 * l * 512;
+  const int waves = pt_trace_block_threads() / 64;
+  const size_t lds = (size_t)c->built.n_nodelets * 48 + (size_t)waves * l * 512;
   int per_cu = (int)((160u * 1024u) / lds);
-  if (per_cu > 8) per_cu = 8;
+  const int max_per_cu = 32 / waves;                             // 32 waves per CU
+  if (per_cu > max_per_cu) per_cu = max_per_cu;
   if (per_cu < 1) return fail(c, PTC_E_ARG, "configure_launch: nodelets + stack exceed the 160 KiB of LDS");
   if (const char* e = std::getenv("PTC_TRACE_BLOCKS_PER_CU")) { int v = std::atoi(e); if (v >= 1 && v <= per_cu) per_cu = v; }
   c->cfg.trace_blocks_per_cu = per_cu;
   const uint32_t ovf = (uint32_t)(need - l > 0 ? need - l : 1);
-  const size_t waves = (size_t)c->cfg.n_cu * 8 * 4;               // upper bound on resident trace waves
+  const size_t total_waves = (size_t)c->cfg.n_cu * 32;           // upper bound on resident trace waves
   uint2* p = nullptr;
-  int rc = dev_alloc(c, c->scene_allocs, &p, waves * ovf * 64);
+  int rc = dev_alloc(c, c->scene_allocs, &p, total_waves * ovf * 64);
   if (rc) return rc;
   c->dsc.stack_ovf = p; c->dsc.ovf_depth = ovf;
+  for (auto& ln : c->extra) {                                    // concurrent kernels must not share a slab
+    uint2* pl = nullptr;
+    if ((rc = dev_alloc(c, c->scene_allocs, &pl, total_waves * ovf * 64))) return rc;
+    ln.stack_ovf = pl;
+  }
   return PTC_OK;
 }
 
-// One wavefront batch of n samples per owned pixel, fully asynchronous.
-int run_batch(ptc_ctx* c, uint32_t n_samples) {
+// One wavefront batch of n samples per owned pixel on lane `l`, fully asynchronous.  Batches on different
+// lanes overlap; only the per-pixel accumulation is ordered (sample order), through the acc_done events.
+int run_batch(ptc_ctx* c, int l, uint32_t first_sample, uint32_t n_samples) {
   const uint32_t n_paths = c->fr.n_owned * n_samples;
-  ScopedSpan whole(c, 3);
-  pt_launch_set_counts(c->stream, c->q, n_paths, 0);
+  hipStream_t st = lane_stream(c, l);
+  const DevQueues& q = lane_q(c, l);
+  const DevScene sc = lane_scene(c, l);
+  ScopedSpan whole(c, st, 3);
+  pt_launch_set_counts(st, q, n_paths, 0);
   if (c->integrator == PTC_INTEGRATOR_RASTER_COMPAT) {
-    pt_launch_raygen(c->stream, c->cam, c->fr, c->q, 0, 1, true);
-    { ScopedSpan t(c, 0); pt_launch_trace_closest(c->stream, c->cfg, c->dsc, c->q, 0, true); c->stats.launches_trace_closest++; }
-    pt_launch_shade_raster(c->stream, c->dsc, c->cam, c->fr, c->q, c->accum.p);
+    pt_launch_raygen(st, c->cam, c->fr, q, 0, 1, true);
+    { ScopedSpan t(c, st, 0); pt_launch_trace_closest(st, c->cfg, sc, q, 0, true); c->stats.launches_trace_closest++; }
+    pt_launch_shade_raster(st, sc, c->cam, c->fr, q, c->accum.p);
   } else {
-    pt_launch_raygen(c->stream, c->cam, c->fr, c->q, c->samples_done, n_samples, false);
+    pt_launch_raygen(st, c->cam, c->fr, q, first_sample, n_samples, false);
     for (int b = 0; b <= c->fr.max_bounces; ++b) {
-      { ScopedSpan t(c, 0); pt_launch_trace_closest(c->stream, c->cfg, c->dsc, c->q, b & 1, false); c->stats.launches_trace_closest++; }
-      { ScopedSpan t(c, 2); pt_launch_shade(c->stream, c->cfg, c->dsc, c->fr, c->q, b & 1); }
-      if (b < c->fr.max_bounces && c->dsc.n_lights > 0) {
-        ScopedSpan t(c, 1); pt_launch_trace_any(c->stream, c->cfg, c->dsc, c->q, nullptr); c->stats.launches_trace_any++;
+      { ScopedSpan t(c, st, 0); pt_launch_trace_closest(st, c->cfg, sc, q, b & 1, false); c->stats.launches_trace_closest++; }
+      { ScopedSpan t(c, st, 2); pt_launch_shade(st, c->cfg, sc, c->fr, q, b & 1); }
+      if (b < c->fr.max_bounces && sc.n_lights > 0) {
+        ScopedSpan t(c, st, 1); pt_launch_trace_any(st, c->cfg, sc, q, nullptr); c->stats.launches_trace_any++;
       }
-      pt_launch_advance(c->stream, c->q);
+      pt_launch_advance(st, q);
     }
-    pt_launch_accumulate(c->stream, c->fr, c->q, c->accum.p, n_samples);
+    // sample-order accumulation: wait for the previous batch's accumulate (it ran on the previous lane)
+    if (c->n_lanes > 1 && c->batches_issued > 0) {
+      const int prev = (int)((c->batches_issued - 1) % (uint64_t)c->n_lanes);
+      if (prev != l) HIP_TRY(c, hipStreamWaitEvent(st, lane_acc_event(c, prev), 0));
+    }
+    pt_launch_accumulate(st, c->fr, q, c->accum.p, n_samples);
+    if (c->n_lanes > 1) HIP_TRY(c, hipEventRecord(lane_acc_event(c, l), st));
   }
+  c->batches_issued++;
   HIP_TRY(c, hipGetLastError());
+  return PTC_OK;
+}
+
+int sync_all_lanes(ptc_ctx* c) {
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (auto& ln : c->extra) HIP_TRY(c, hipStreamSynchronize(ln.stream));
   return PTC_OK;
 }
 
@@ -243,6 +281,12 @@ ptc_ctx* ptc_create(int device_id) {
   if (const char* s = std::getenv("PTC_NODELETS")) c->nodelet_budget = (uint32_t)std::strtoul(s, nullptr, 10);
   if (const char* s = std::getenv("PTC_BATCH_PATHS")) { size_t v = std::strtoull(s, nullptr, 10); if (v >= 1024) c->max_batch_paths = v; }
   if (const char* s = std::getenv("PTC_TIMING")) c->timing = std::atoi(s) != 0;
+  if (const char* s = std::getenv("PTC_LANES")) { int v = std::atoi(s); if (v >= 1 && v <= 8) c->n_lanes = v; }
+  bool ok = hipEventCreateWithFlags(&c->acc_done0, hipEventDisableTiming) == hipSuccess;
+  c->extra.resize((size_t)c->n_lanes - 1);
+  for (auto& ln : c->extra)
+    ok = ok && hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ln.acc_done, hipEventDisableTiming) == hipSuccess;
+  if (!ok) { g_create_error = "ptc_create: could not create the lane streams / events"; ptc_destroy(c); return nullptr; }
   return c;
 }
 
@@ -251,6 +295,12 @@ void ptc_destroy(ptc_ctx* c) {
   if (c->device < 0) { delete c; return; }
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto& ln : c->extra) {
+    if (ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); }
+    if (ln.acc_done) (void)hipEventDestroy(ln.acc_done);
+    free_all(ln.allocs);
+  }
+  if (c->acc_done0) (void)hipEventDestroy(c->acc_done0);
   free_all(c->scene_allocs); free_all(c->queue_allocs);
   c->owned.release(); c->accum.release(); c->radiance.release(); c->ldr.release();
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
@@ -264,7 +314,7 @@ int ptc_scene_begin(ptc_ctx* c) {
   if (!c) return PTC_E_ARG;
   if (c->device >= 0) {
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    { int rs = sync_all_lanes(c); if (rs) return rs; }
   }
   c->mats.clear(); c->meshes.clear(); c->insts.clear(); c->texs.clear();
   c->have_cam = false; c->committed = false; c->in_frame = false;
@@ -375,7 +425,7 @@ int ptc_frame_begin(ptc_ctx* c, int w, int h, int spp_total, uint64_t seed, int 
   if (integrator != PTC_INTEGRATOR_PATH && integrator != PTC_INTEGRATOR_RASTER_COMPAT) return fail(c, PTC_E_ARG, "frame_begin: unknown integrator");
   if (tile_count < 1 || tile_rank < 0 || tile_rank >= tile_count) return fail(c, PTC_E_ARG, "frame_begin: bad tile rank/count");
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  { int rs = sync_all_lanes(c); if (rs) return rs; }
   std::vector<uint32_t> owned;
   ptc_owned_pixels(w, h, tile_rank, tile_count, owned);
   int rc;
@@ -393,14 +443,17 @@ int ptc_frame_begin(ptc_ctx* c, int w, int h, int spp_total, uint64_t seed, int 
   }
   c->spp_total = integrator == PTC_INTEGRATOR_RASTER_COMPAT ? 1 : spp_total;
   c->integrator = integrator; c->samples_done = 0;
-  // queue capacity: as many samples per batch as fit max_batch_paths
-  size_t per = owned.empty() ? 1 : c->max_batch_paths / owned.size();
+  // queue capacity per lane: as many samples per batch as fit max_batch_paths split over the lanes
+  size_t per = owned.empty() ? 1 : c->max_batch_paths / owned.size() / (size_t)c->n_lanes;
   if (per < 1) per = 1;
   if (per > (size_t)c->spp_total) per = (size_t)c->spp_total;
   const size_t cap = (owned.empty() ? 1 : owned.size()) * per;
   if (cap > 0xfffffff0ull) return fail(c, PTC_E_ARG, "frame_begin: batch too large");
   if ((rc = ensure_queues(c, (uint32_t)cap))) return rc;
-  HIP_TRY(c, hipMemsetAsync(c->q.stats, 0, ST_N * sizeof(unsigned long long), c->stream));
+  for (auto& ln : c->extra) if ((rc = ensure_queues_in(c, ln.q, ln.allocs, (uint32_t)cap))) return rc;
+  for (int l = 0; l < c->n_lanes; ++l) HIP_TRY(c, hipMemsetAsync(lane_q(c, l).stats, 0, ST_N * sizeof(unsigned long long), lane_stream(c, l)));
+  { int rs = sync_all_lanes(c); if (rs) return rs; }     // accum/radiance/statistics are cleared before any lane starts
+  c->batches_issued = 0;
   ptc_stats keep = c->stats;
   std::memset(&c->stats, 0, sizeof c->stats);
   c->stats.seconds_commit = keep.seconds_commit; c->stats.n_triangles = keep.n_triangles; c->stats.n_bvh_nodes = keep.n_bvh_nodes;
@@ -418,7 +471,7 @@ int ptc_frame_add_samples(ptc_ctx* c, int n_samples) {
   HIP_TRY(c, hipSetDevice(c->device));
   if (c->fr.n_owned == 0) { c->samples_done += (uint32_t)n_samples; return PTC_OK; }
   if (c->integrator == PTC_INTEGRATOR_RASTER_COMPAT) {
-    if (c->samples_done == 0) { int rc = run_batch(c, 1); if (rc) return rc; }
+    if (c->samples_done == 0) { int rc = run_batch(c, 0, 0, 1); if (rc) return rc; }
     c->samples_done += (uint32_t)n_samples;
     c->stats.paths = c->fr.n_owned;
     return PTC_OK;
@@ -427,7 +480,7 @@ int ptc_frame_add_samples(ptc_ctx* c, int n_samples) {
   const uint32_t per = c->q.cap / c->fr.n_owned;
   while (left) {
     const uint32_t k = left < per ? left : per;
-    int rc = run_batch(c, k);
+    int rc = run_batch(c, (int)(c->batches_issued % (uint64_t)c->n_lanes), c->samples_done, k);
     if (rc) return rc;
     c->samples_done += k; left -= k;
     c->stats.paths += (uint64_t)c->fr.n_owned * k;
@@ -440,6 +493,10 @@ int ptc_frame_resolve(ptc_ctx* c) {
   if (c->device < 0) return fail(c, PTC_E_DEVICE, "this context has no device (PTC_DEVICE_NONE): the call needs a gfx950 GPU; there is no CPU path");
   if (!c->in_frame) return fail(c, PTC_E_STATE, "frame_resolve: no frame");
   HIP_TRY(c, hipSetDevice(c->device));
+  // the last accumulate may have run on another lane: stream 0 waits for every lane's accumulate event
+  if (c->n_lanes > 1 && c->integrator == PTC_INTEGRATOR_PATH && c->batches_issued > 0)
+    for (int l = 1; l < c->n_lanes && (uint64_t)l < c->batches_issued + 1; ++l)
+      if ((uint64_t)l < c->batches_issued) HIP_TRY(c, hipStreamWaitEvent(c->stream, lane_acc_event(c, l), 0));
   if (c->fr.n_owned) pt_launch_resolve(c->stream, c->fr, c->accum.p, c->radiance.p, (float)c->spp_total, c->integrator == PTC_INTEGRATOR_RASTER_COMPAT);
   HIP_TRY(c, hipGetLastError());
   return PTC_OK;
@@ -449,8 +506,7 @@ int ptc_sync(ptc_ctx* c) {
   if (!c) return PTC_E_ARG;
   if (c->device < 0) return fail(c, PTC_E_DEVICE, "this context has no device (PTC_DEVICE_NONE): the call needs a gfx950 GPU; there is no CPU path");
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  return PTC_OK;
+  return sync_all_lanes(c);
 }
 
 int ptc_render(ptc_ctx* c, int w, int h, int spp, uint64_t seed, int max_bounces, int integrator) {
@@ -467,7 +523,7 @@ int ptc_read_radiance_rgba32f(ptc_ctx* c, float* out) {
   if (!out) return fail(c, PTC_E_ARG, "read_radiance: null pointer");
   if (!c->radiance.p || c->rad_w == 0) return fail(c, PTC_E_STATE, "read_radiance: nothing rendered");
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  { int rs = sync_all_lanes(c); if (rs) return rs; }
   HIP_TRY(c, hipMemcpy(out, c->radiance.p, (size_t)c->rad_w * c->rad_h * sizeof(float4), hipMemcpyDeviceToHost));
   return PTC_OK;
 }
@@ -505,10 +561,15 @@ int ptc_get_stats(ptc_ctx* c, ptc_stats* out) {
   if (!out) return fail(c, PTC_E_ARG, "get_stats: null pointer");
   if (c->device < 0) { *out = c->stats; return PTC_OK; }
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  { int rs = sync_all_lanes(c); if (rs) return rs; }
   if (c->q.stats) {
-    unsigned long long st[ST_N];
-    HIP_TRY(c, hipMemcpy(st, c->q.stats, sizeof st, hipMemcpyDeviceToHost));
+    unsigned long long st[ST_N] = {0};
+    for (int l = 0; l < c->n_lanes; ++l) {
+      if (!lane_q(c, l).stats) continue;
+      unsigned long long one[ST_N];
+      HIP_TRY(c, hipMemcpy(one, lane_q(c, l).stats, sizeof one, hipMemcpyDeviceToHost));
+      for (int i = 0; i < ST_N; ++i) st[i] += one[i];
+    }
     ptc_stats& s = c->stats;
     s.segments = st[ST_SEGMENTS]; s.shadow_rays = st[ST_SHADOW]; s.hits = st[ST_HITS];
     s.node_visits_closest = st[ST_NODES_C]; s.tri_tests_closest = st[ST_TRIS_C];
@@ -524,6 +585,7 @@ int ptc_get_stats(ptc_ctx* c, ptc_stats* out) {
 
 // ---- test hooks -----------------------------------------------------------------------------------
 int ptc_debug_trace_closest(ptc_ctx* c, const float* origins, const float* dirs, uint32_t n, float* out_t, int32_t* out_prim, float* out_uv) {
+  if (c && c->device >= 0) { int rs = sync_all_lanes(c); if (rs) return rs; }
   if (!c) return PTC_E_ARG;
   if (c->device < 0) return fail(c, PTC_E_DEVICE, "this context has no device (PTC_DEVICE_NONE): the call needs a gfx950 GPU; there is no CPU path");
   if (!c->committed) return fail(c, PTC_E_STATE, "debug_trace_closest: scene not committed");
@@ -540,7 +602,7 @@ int ptc_debug_trace_closest(ptc_ctx* c, const float* origins, const float* dirs,
   }
   HIP_TRY(c, hipMemcpy(c->q.ray[0].A, A.data(), n * sizeof(float4), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->q.ray[0].B, B.data(), n * sizeof(float4), hipMemcpyHostToDevice));
-  HIP_TRY(c, hipMemsetAsync(c->q.stats, 0, ST_N * sizeof(unsigned long long), c->stream));
+  for (int l = 0; l < c->n_lanes; ++l) if (lane_q(c, l).stats) HIP_TRY(c, hipMemset(lane_q(c, l).stats, 0, ST_N * sizeof(unsigned long long)));
   pt_launch_set_counts(c->stream, c->q, n, 0);
   pt_launch_trace_closest(c->stream, c->cfg, c->dsc, c->q, 0, false);
   HIP_TRY(c, hipGetLastError());
@@ -555,6 +617,7 @@ int ptc_debug_trace_closest(ptc_ctx* c, const float* origins, const float* dirs,
 }
 
 int ptc_debug_trace_any(ptc_ctx* c, const float* origins, const float* dirs, const float* tmax, uint32_t n, uint8_t* out_occluded) {
+  if (c && c->device >= 0) { int rs = sync_all_lanes(c); if (rs) return rs; }
   if (!c) return PTC_E_ARG;
   if (c->device < 0) return fail(c, PTC_E_DEVICE, "this context has no device (PTC_DEVICE_NONE): the call needs a gfx950 GPU; there is no CPU path");
   if (!c->committed) return fail(c, PTC_E_STATE, "debug_trace_any: scene not committed");
@@ -573,7 +636,7 @@ int ptc_debug_trace_any(ptc_ctx* c, const float* origins, const float* dirs, con
   HIP_TRY(c, hipMemcpy(c->q.shadow.B, B.data(), n * sizeof(float4), hipMemcpyHostToDevice));
   uint8_t* d_out = nullptr;
   HIP_TRY(c, hipMalloc((void**)&d_out, n));
-  HIP_TRY(c, hipMemsetAsync(c->q.stats, 0, ST_N * sizeof(unsigned long long), c->stream));
+  for (int l = 0; l < c->n_lanes; ++l) if (lane_q(c, l).stats) HIP_TRY(c, hipMemset(lane_q(c, l).stats, 0, ST_N * sizeof(unsigned long long)));
   pt_launch_set_counts(c->stream, c->q, 0, n);
   pt_launch_trace_any(c->stream, c->cfg, c->dsc, c->q, d_out);
   hipError_t e = hipGetLastError();
@@ -602,9 +665,14 @@ int ptc_debug_get_counters(ptc_ctx* c, uint64_t* out, int n) {
   if (!out || n <= 0) return fail(c, PTC_E_ARG, "debug_get_counters: bad argument");
   if (!c->q.stats) return fail(c, PTC_E_STATE, "debug_get_counters: nothing rendered");
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  unsigned long long st[ST_N];
-  HIP_TRY(c, hipMemcpy(st, c->q.stats, sizeof st, hipMemcpyDeviceToHost));
+  { int rs = sync_all_lanes(c); if (rs) return rs; }
+  unsigned long long st[ST_N] = {0};
+  for (int l = 0; l < c->n_lanes; ++l) {
+    if (!lane_q(c, l).stats) continue;
+    unsigned long long one[ST_N];
+    HIP_TRY(c, hipMemcpy(one, lane_q(c, l).stats, sizeof one, hipMemcpyDeviceToHost));
+    for (int i = 0; i < ST_N; ++i) st[i] += one[i];
+  }
   for (int i = 0; i < n; ++i) out[i] = i < ST_N ? st[i] : 0;
   return ST_N;
 }

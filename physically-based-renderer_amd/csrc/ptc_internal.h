@@ -61,6 +61,7 @@ enum { ST_SEGMENTS = 0, ST_SHADOW, ST_HITS, ST_NODES_C, ST_TRIS_C, ST_NODES_A, S
 struct LaunchCfg { int n_cu; int trace_blocks_per_cu; int stack_lds; /* stack entries kept in LDS per lane */ };
 
 // ---- kernel launchers (pt_kernels.hip) ------------------------------------------------------------
+int pt_trace_block_threads();   // threads per block of the trace kernels (compile-time constant of pt_kernels.hip)
 void pt_launch_set_counts(hipStream_t, const DevQueues&, uint32_t n_rays, uint32_t n_shadow);
 void pt_launch_advance(hipStream_t, const DevQueues&);
 void pt_launch_raygen(hipStream_t, const DevCamera&, const DevFrame&, const DevQueues&, uint32_t first_sample, uint32_t n_samples, bool raster);
