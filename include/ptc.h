@@ -127,6 +127,9 @@ int ptc_add_mesh(ptc_ctx*, const ptc_vertex* verts, uint32_t n_verts, const uint
  * ModelPushConstant.hpp:33-46): model = T·R·S, quaternion order (w,x,y,z). */
 int ptc_add_instance(ptc_ctx*, int mesh, const float t[3], const float q_wxyz[4],
                      const float s[3]);
+/* makeModelPushConstant(glm::mat4x4 model) (ModelPushConstant.hpp:33-38): an instance by its column-major
+ * 4x4 model matrix (used by the glTF loader, which composes parent transforms). */
+int ptc_add_instance_matrix(ptc_ctx*, int mesh, const float model[16]);
 
 /* pbr::makeCameraData (engine/pbr/CameraData.hpp:22-32): lookAtRH(pos,target,up=(0,-1,0)),
  * perspective fovY/aspect; y-down un-flipped viewport (PbrRenderSystem.cpp:425-430). */

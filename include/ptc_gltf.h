@@ -1,0 +1,26 @@
+/* ptc_gltf.h — C-ABI of the glTF 2.0 / GLB loader (libptc_gltf.so), SURVEY.md §8f-1.
+ *
+ * Replaces, for the path tracer, gltf::Loader::loadAsset + Asset::loadScene
+ * (src/pbr_engine/gltf/pbr/gltf/Loader.hpp:20-21, Asset.hpp:76-78): reads a .gltf / .glb file and issues the
+ * ptc_add_material / ptc_add_mesh / ptc_add_instance_matrix calls of include/ptc.h on `ctx`.
+ * Call between ptc_scene_begin and ptc_scene_commit; the camera stays the caller's (the reference ignores glTF
+ * cameras too and injects its own, Asset.cpp:262-265).  Host-only: works on a PTC_DEVICE_NONE context.
+ */
+#ifndef PTC_GLTF_H
+#define PTC_GLTF_H
+#include "ptc.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* scene_index: -1 = the asset's default scene.  compose_parents: 1 = glTF-correct world transforms,
+ * 0 = each node with its local transform only (the reference's behaviour, PbrRenderSystem.cpp:444-446).
+ * bbox6 (may be NULL) receives the world bounds lo.xyz, hi.xyz.  err (may be NULL) receives the error text.
+ * Returns the number of triangles instanced (>= 0) or a negative PTC_E_* code. */
+long long ptc_gltf_load(ptc_ctx* ctx, const char* path, int scene_index, int compose_parents, float bbox6[6],
+                        char* err, int err_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

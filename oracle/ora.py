@@ -52,6 +52,7 @@ def lib():
         L.ora_add_material.argtypes = [vp, fp, C.c_float, C.c_float, fp, C.c_int, C.c_int, C.c_int]
         L.ora_add_mesh.argtypes = [vp, vp, C.c_uint32, u32p, C.c_uint32, C.c_int]
         L.ora_add_instance.argtypes = [vp, C.c_int, fp, fp, fp]
+        L.ora_add_instance_matrix.argtypes = [vp, C.c_int, fp]
         L.ora_set_camera.argtypes = [vp, fp, fp, C.c_float, C.c_float]
         L.ora_scene_commit.argtypes = [vp]
         L.ora_render.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp]
@@ -120,7 +121,10 @@ class Oracle:
             i = np.ascontiguousarray(me.indices, np.uint32)
             self._ck(L.ora_add_mesh(h, v.ctypes.data, v.size, i.ctypes.data_as(C.POINTER(C.c_uint32)), i.size, me.material))
         for it in desc.instances:
-            self._ck(L.ora_add_instance(h, it.mesh, _f(it.t)[1], _f(it.q_wxyz)[1], _f(it.s)[1]))
+            if getattr(it, "matrix", None) is not None:
+                self._ck(L.ora_add_instance_matrix(h, it.mesh, _f(np.asarray(it.matrix, np.float32).reshape(16))[1]))
+            else:
+                self._ck(L.ora_add_instance(h, it.mesh, _f(it.t)[1], _f(it.q_wxyz)[1], _f(it.s)[1]))
         c = desc.camera
         self._ck(L.ora_set_camera(h, _f(c.position)[1], _f(c.target)[1], c.fov_y, c.aspect))
         self._ck(L.ora_scene_commit(h))

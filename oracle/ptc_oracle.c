@@ -164,7 +164,7 @@ typedef struct {
 } material_t;
 
 typedef struct { vert48* v; uint32_t nv; uint32_t* idx; uint32_t ni; int material; } mesh_t;
-typedef struct { int mesh; float t[3], q[4], s[3]; } inst_t;
+typedef struct { int mesh; float m[16]; } inst_t;   /* column-major model matrix */
 typedef struct { uint8_t* px; int w, h; } tex_t;
 
 typedef struct {                 /* 64-byte interior node: both child boxes + child codes */
@@ -264,12 +264,22 @@ int ora_add_mesh(ora_ctx* c, const void* verts, uint32_t nv, const uint32_t* idx
   m->idx = (uint32_t*)malloc(4u * ni); memcpy(m->idx, idx, 4u * ni); m->ni = ni; m->material = material;
   return c->n_meshes++;
 }
+static void make_model(const float t[3], const float q[4], const float s[3], float M[16], float N[9]);
 int ora_add_instance(ora_ctx* c, int mesh, const float t[3], const float q[4], const float s[3]) {
   if (!t || !q || !s) return fail(c, "add_instance: null pointer");
   if (mesh < 0 || mesh >= c->n_meshes) return fail(c, "add_instance: mesh out of range");
   c->insts = (inst_t*)realloc(c->insts, sizeof(inst_t) * (size_t)(c->n_insts + 1));
   inst_t* in = &c->insts[c->n_insts];
-  in->mesh = mesh; memcpy(in->t, t, 12); memcpy(in->q, q, 16); memcpy(in->s, s, 12);
+  float N[9];
+  in->mesh = mesh; make_model(t, q, s, in->m, N);
+  return c->n_insts++;
+}
+int ora_add_instance_matrix(ora_ctx* c, int mesh, const float m[16]) {
+  if (!m) return fail(c, "add_instance_matrix: null pointer");
+  if (mesh < 0 || mesh >= c->n_meshes) return fail(c, "add_instance_matrix: mesh out of range");
+  c->insts = (inst_t*)realloc(c->insts, sizeof(inst_t) * (size_t)(c->n_insts + 1));
+  inst_t* in = &c->insts[c->n_insts];
+  in->mesh = mesh; memcpy(in->m, m, 64);
   return c->n_insts++;
 }
 int ora_set_camera(ora_ctx* c, const float pos[3], const float target[3], float fov, float aspect) {
@@ -281,20 +291,9 @@ int ora_set_camera(ora_ctx* c, const float pos[3], const float target[3], float 
 /* ------------------------------------------------------------------------------------------ */
 /* R3: model = translate(p)·toMat4(q)·scale(s); normalModel = mat3(transpose(inverse(model))).   */
 /* Column-major (glm): m[col*4+row].  Quaternion order (w,x,y,z) — gltf/Asset.cpp:242.           */
-static void make_model(const float t[3], const float q[4], const float s[3], float M[16], float N[9]) {
-  float w = q[0], x = q[1], y = q[2], z = q[3];
-  float qxx = x * x, qyy = y * y, qzz = z * z, qxz = x * z, qxy = x * y, qyz = y * z;
-  float qwx = w * x, qwy = w * y, qwz = w * z;
-  float R[9]; /* R[col*3+row], glm::mat3_cast */
-  R[0] = 1.0f - 2.0f * (qyy + qzz); R[1] = 2.0f * (qxy + qwz);        R[2] = 2.0f * (qxz - qwy);
-  R[3] = 2.0f * (qxy - qwz);        R[4] = 1.0f - 2.0f * (qxx + qzz); R[5] = 2.0f * (qyz + qwx);
-  R[6] = 2.0f * (qxz + qwy);        R[7] = 2.0f * (qyz - qwx);        R[8] = 1.0f - 2.0f * (qxx + qyy);
-  float A[9]; /* upper 3×3 of T·R·S = R·diag(s) */
-  for (int col = 0; col < 3; ++col) for (int row = 0; row < 3; ++row) A[col * 3 + row] = R[col * 3 + row] * s[col];
-  for (int col = 0; col < 3; ++col) { for (int row = 0; row < 3; ++row) M[col * 4 + row] = A[col * 3 + row]; M[col * 4 + 3] = 0.0f; }
-  M[12] = t[0]; M[13] = t[1]; M[14] = t[2]; M[15] = 1.0f;
-  /* inverse-transpose of A = cofactor(A)/det(A); a(r,c) = A[c*3+r] */
-#define a(r, c) A[(c) * 3 + (r)]
+static void normal_matrix(const float M[16], float N[9]) {
+  /* inverse-transpose of the upper 3x3 A of M = cofactor(A)/det(A); a(r,c) = M[c*4+r] */
+#define a(r, c) M[(c) * 4 + (r)]
   float c00 = a(1, 1) * a(2, 2) - a(1, 2) * a(2, 1);
   float c01 = a(1, 2) * a(2, 0) - a(1, 0) * a(2, 2);
   float c02 = a(1, 0) * a(2, 1) - a(1, 1) * a(2, 0);
@@ -311,6 +310,18 @@ static void make_model(const float t[3], const float q[4], const float s[3], flo
   N[0] = c00 * id; N[1] = c10 * id; N[2] = c20 * id;
   N[3] = c01 * id; N[4] = c11 * id; N[5] = c21 * id;
   N[6] = c02 * id; N[7] = c12 * id; N[8] = c22 * id;
+}
+static void make_model(const float t[3], const float q[4], const float s[3], float M[16], float N[9]) {
+  float w = q[0], x = q[1], y = q[2], z = q[3];
+  float qxx = x * x, qyy = y * y, qzz = z * z, qxz = x * z, qxy = x * y, qyz = y * z;
+  float qwx = w * x, qwy = w * y, qwz = w * z;
+  float R[9]; /* R[col*3+row], glm::mat3_cast */
+  R[0] = 1.0f - 2.0f * (qyy + qzz); R[1] = 2.0f * (qxy + qwz);        R[2] = 2.0f * (qxz - qwy);
+  R[3] = 2.0f * (qxy - qwz);        R[4] = 1.0f - 2.0f * (qxx + qzz); R[5] = 2.0f * (qyz + qwx);
+  R[6] = 2.0f * (qxz + qwy);        R[7] = 2.0f * (qyz - qwx);        R[8] = 1.0f - 2.0f * (qxx + qyy);
+  for (int col = 0; col < 3; ++col) { for (int row = 0; row < 3; ++row) M[col * 4 + row] = R[col * 3 + row] * s[col]; M[col * 4 + 3] = 0.0f; }
+  M[12] = t[0]; M[13] = t[1]; M[14] = t[2]; M[15] = 1.0f;
+  normal_matrix(M, N);
 }
 void ora_make_model(const float t[3], const float q[4], const float s[3], float M[16], float N[9]) { make_model(t, q, s, M, N); }
 
@@ -507,7 +518,7 @@ int ora_scene_commit(ora_ctx* c) {
   uint32_t vb = 0, tb = 0;
   for (int i = 0; i < c->n_insts; ++i) {
     const inst_t* in = &c->insts[i]; const mesh_t* m = &c->meshes[in->mesh];
-    float M[16], N[9]; make_model(in->t, in->q, in->s, M, N);
+    float M[16], N[9]; memcpy(M, in->m, 64); normal_matrix(M, N);
     for (uint32_t k = 0; k < m->nv; ++k) {
       const vert48* s = &m->v[k]; vert48* d = &c->wv[vb + k];
       v3 p = mat4_point(M, V3(s->position[0], s->position[1], s->position[2]));

@@ -37,6 +37,7 @@ int ora_add_texture_rgba8(ora_ctx*, const uint8_t* px, int w, int h);
 int ora_add_mesh(ora_ctx*, const void* verts48, uint32_t n_verts, const uint32_t* indices,
                  uint32_t n_indices, int material);
 int ora_add_instance(ora_ctx*, int mesh, const float t[3], const float q_wxyz[4], const float s[3]);
+int ora_add_instance_matrix(ora_ctx*, int mesh, const float model16[16]);
 int ora_set_camera(ora_ctx*, const float pos[3], const float target[3], float fov_y, float aspect);
 int ora_scene_commit(ora_ctx*);
 

@@ -363,7 +363,19 @@ int ptc_add_instance(ptc_ctx* c, int mesh, const float t[3], const float q_wxyz[
   if (!t || !q_wxyz || !s) return fail(c, PTC_E_ARG, "add_instance: null pointer");
   if (mesh < 0 || mesh >= (int)c->meshes.size()) return fail(c, PTC_E_ARG, "add_instance: mesh out of range");
   HostInstance in;
-  in.mesh = mesh; std::memcpy(in.t, t, 12); std::memcpy(in.q, q_wxyz, 16); std::memcpy(in.s, s, 12);
+  in.mesh = mesh;
+  ptc_trs_to_matrix(t, q_wxyz, s, in.m);
+  c->insts.push_back(in);
+  return (int)c->insts.size() - 1;
+}
+
+int ptc_add_instance_matrix(ptc_ctx* c, int mesh, const float model[16]) {
+  if (!c) return PTC_E_ARG;
+  if (!model) return fail(c, PTC_E_ARG, "add_instance_matrix: null pointer");
+  if (mesh < 0 || mesh >= (int)c->meshes.size()) return fail(c, PTC_E_ARG, "add_instance_matrix: mesh out of range");
+  HostInstance in;
+  in.mesh = mesh;
+  std::memcpy(in.m, model, 64);
   c->insts.push_back(in);
   return (int)c->insts.size() - 1;
 }

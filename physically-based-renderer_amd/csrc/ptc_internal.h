@@ -77,7 +77,7 @@ void pt_launch_tonemap(hipStream_t, const float4* radiance, uint32_t* rgba8, int
 struct HostMaterial { float base[4]; float metallic, roughness; float emissive[3]; int tex_color, tex_normal, tex_mr; };
 struct HostVertex { float position[3], normal[3], tangent[4], texcoord[2]; };
 struct HostMesh { std::vector<HostVertex> v; std::vector<uint32_t> idx; int material; };
-struct HostInstance { int mesh; float t[3], q[4], s[3]; };
+struct HostInstance { int mesh; float m[16]; };   // column-major model matrix
 
 struct HostBuilt {
   std::vector<HostVertex> wverts;
@@ -97,6 +97,7 @@ struct HostBuilt {
 // returns empty string on success, else the error text
 std::string ptc_build_scene(const std::vector<HostMaterial>&, const std::vector<HostMesh>&, const std::vector<HostInstance>&,
                             uint32_t nodelet_budget, HostBuilt& out);
+void ptc_trs_to_matrix(const float t[3], const float q_wxyz[4], const float s[3], float m16[16]);
 void ptc_make_camera(const float pos[3], const float target[3], float fov, float aspect, DevCamera& cam);
 // pixels owned by (rank,count) in tile-Morton order
 void ptc_owned_pixels(int w, int h, int tile_rank, int tile_count, std::vector<uint32_t>& out);

@@ -22,23 +22,14 @@ constexpr int kTile = 32;
 
 struct Mat34 { float m[16]; float n[9]; };  // column-major model (glm layout) + normal matrix
 
-// translate(t) * toMat4(q) * scale(s), then mat3(transpose(inverse(model))) via cofactors.
-Mat34 make_model(const float t[3], const float q[4], const float s[3]) {
+// mat3(transpose(inverse(model))) of a column-major 4x4 model matrix, via the cofactors of its upper 3x3
+// (makeModelPushConstant(glm::mat4x4), ModelPushConstant.hpp:33-38).
+Mat34 from_matrix(const float m[16]) {
   Mat34 r;
-  const float w = q[0], x = q[1], y = q[2], z = q[3];
-  const float xx = x * x, yy = y * y, zz = z * z, xz = x * z, xy = x * y, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
-  float R[9];
-  R[0] = 1.0f - 2.0f * (yy + zz); R[1] = 2.0f * (xy + wz);        R[2] = 2.0f * (xz - wy);
-  R[3] = 2.0f * (xy - wz);        R[4] = 1.0f - 2.0f * (xx + zz); R[5] = 2.0f * (yz + wx);
-  R[6] = 2.0f * (xz + wy);        R[7] = 2.0f * (yz - wx);        R[8] = 1.0f - 2.0f * (xx + yy);
+  std::memcpy(r.m, m, 64);
   float A[9];
   for (int c = 0; c < 3; ++c)
-    for (int k = 0; k < 3; ++k) A[c * 3 + k] = R[c * 3 + k] * s[c];
-  for (int c = 0; c < 3; ++c) {
-    for (int k = 0; k < 3; ++k) r.m[c * 4 + k] = A[c * 3 + k];
-    r.m[c * 4 + 3] = 0.0f;
-  }
-  r.m[12] = t[0]; r.m[13] = t[1]; r.m[14] = t[2]; r.m[15] = 1.0f;
+    for (int k = 0; k < 3; ++k) A[c * 3 + k] = m[c * 4 + k];
   auto a = [&](int row, int col) { return A[col * 3 + row]; };
   const float c00 = a(1, 1) * a(2, 2) - a(1, 2) * a(2, 1);
   const float c01 = a(1, 2) * a(2, 0) - a(1, 0) * a(2, 2);
@@ -138,6 +129,22 @@ inline int32_t leaf_code(uint32_t first, uint32_t count) { return (int32_t) ~(fi
 }  // namespace
 
 // =================================================================================================
+// translate(t) * toMat4(q) * scale(s)  (makeModelPushConstant(position, rotation, scale), ModelPushConstant.hpp:40-46);
+// column-major like glm, quaternion order (w,x,y,z).
+void ptc_trs_to_matrix(const float t[3], const float q[4], const float s[3], float m[16]) {
+  const float w = q[0], x = q[1], y = q[2], z = q[3];
+  const float xx = x * x, yy = y * y, zz = z * z, xz = x * z, xy = x * y, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+  float R[9];
+  R[0] = 1.0f - 2.0f * (yy + zz); R[1] = 2.0f * (xy + wz);        R[2] = 2.0f * (xz - wy);
+  R[3] = 2.0f * (xy - wz);        R[4] = 1.0f - 2.0f * (xx + zz); R[5] = 2.0f * (yz + wx);
+  R[6] = 2.0f * (xz + wy);        R[7] = 2.0f * (yz - wx);        R[8] = 1.0f - 2.0f * (xx + yy);
+  for (int c = 0; c < 3; ++c) {
+    for (int k = 0; k < 3; ++k) m[c * 4 + k] = R[c * 3 + k] * s[c];
+    m[c * 4 + 3] = 0.0f;
+  }
+  m[12] = t[0]; m[13] = t[1]; m[14] = t[2]; m[15] = 1.0f;
+}
+
 void ptc_make_camera(const float pos[3], const float target[3], float fov, float aspect, DevCamera& cam) {
   // glm::lookAtRH(pos, target, up = (0,-1,0)): f = normalize(target-pos), s = normalize(f × up), u = s × f
   float f[3] = {target[0] - pos[0], target[1] - pos[1], target[2] - pos[2]};
@@ -190,7 +197,7 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
   uint32_t vb = 0, tb = 0;
   for (const auto& in : insts) {
     const HostMesh& m = meshes[(size_t)in.mesh];
-    const Mat34 M = make_model(in.t, in.q, in.s);
+    const Mat34 M = from_matrix(in.m);
     for (size_t k = 0; k < m.v.size(); ++k) {
       const HostVertex& s = m.v[k];
       HostVertex& d = B.wverts[vb + k];

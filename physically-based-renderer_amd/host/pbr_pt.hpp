@@ -105,6 +105,7 @@ public:
     return out;
   }
   auto stats() -> ptc_stats { ptc_stats s; ck(ptc_get_stats(_ctx, &s)); return s; }
+  auto handle() -> ptc_ctx* { return _ctx; }
 
 private:
   auto ck(int rc) -> int { if (rc < 0) throw std::runtime_error(ptc_last_error(_ctx)); return rc; }

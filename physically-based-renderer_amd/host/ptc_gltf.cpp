@@ -1,0 +1,21 @@
+// ptc_gltf.cpp — C-ABI wrapper of gltf_loader.hpp (include/ptc_gltf.h).
+#include "gltf_loader.hpp"
+
+#include <ptc_gltf.h>
+
+#include <cstdio>
+
+extern "C" long long ptc_gltf_load(ptc_ctx* ctx, const char* path, int scene_index, int compose_parents, float bbox6[6], char* err, int err_len) {
+  auto say = [&](const std::string& m) { if (err && err_len > 0) std::snprintf(err, (size_t)err_len, "%s", m.c_str()); };
+  if (!ctx || !path) { say("ptc_gltf_load: null argument"); return PTC_E_ARG; }
+  try {
+    const pbr::gltf::FlatScene s = pbr::gltf::load(path, scene_index, compose_parents != 0);
+    const int rc = pbr::gltf::upload(ctx, s);
+    if (rc < 0) { say(std::string("ptc_gltf_load: ") + ptc_last_error(ctx)); return rc; }
+    if (bbox6) { for (int k = 0; k < 3; ++k) { bbox6[k] = s.bbox_lo[k]; bbox6[3 + k] = s.bbox_hi[k]; } }
+    return (long long)s.n_triangles;
+  } catch (std::exception const& e) {
+    say(std::string("ptc_gltf_load: ") + e.what());
+    return PTC_E_ARG;
+  }
+}

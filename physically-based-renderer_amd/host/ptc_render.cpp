@@ -1,7 +1,9 @@
 // ptc_render — dependency-free C++17 offline renderer over the C-ABI (include/ptc.h).
-//   ptc_render --scene cornell|sphere --width W --height H --spp N --seed S --bounces B [--raster]
-//              --out image.pfm [--ppm image.ppm]
+//   ptc_render (--scene cornell|sphere | --gltf file.glb [--cam-pos x y z --cam-target x y z --fov deg]) --width W --height H
+//              --spp N --seed S --bounces B [--raster] --out image.pfm [--ppm image.ppm]
+// Without --cam-* a glTF scene is framed from its bounding box (the reference ignores glTF cameras and injects its own).
 // The scenes are the procedural stand-ins of BASELINE configs 1 and 2 (the reference's assets are stripped).
+#include "gltf_loader.hpp"
 #include "pbr_pt.hpp"
 
 #include <cmath>
@@ -94,7 +96,9 @@ void buildSphere(pbr::PathTraceRenderSystem& rs, float aspect) {
 }  // namespace
 
 int main(int argc, char** argv) {
-  std::string scene = "cornell", out = "out.pfm", ppm;
+  std::string scene = "cornell", out = "out.pfm", ppm, gltf;
+  float camPos[3] = {0, 0, 0}, camTarget[3] = {0, 0, -1}, fovDeg = 60.0f;
+  bool haveCam = false;
   int w = 256, h = 256, spp = 64, bounces = 8, device = 0, integrator = PTC_INTEGRATOR_PATH;
   std::uint64_t seed = 1;
   for (int i = 1; i < argc; ++i) {
@@ -103,12 +107,30 @@ int main(int argc, char** argv) {
     if (a == "--scene") scene = next(); else if (a == "--width") w = std::atoi(next()); else if (a == "--height") h = std::atoi(next());
     else if (a == "--spp") spp = std::atoi(next()); else if (a == "--seed") seed = std::strtoull(next(), nullptr, 10);
     else if (a == "--bounces") bounces = std::atoi(next()); else if (a == "--device") device = std::atoi(next());
+    else if (a == "--gltf") gltf = next();
+    else if (a == "--cam-pos") { for (float& v : camPos) v = (float)std::atof(next()); haveCam = true; }
+    else if (a == "--cam-target") { for (float& v : camTarget) v = (float)std::atof(next()); }
+    else if (a == "--fov") fovDeg = (float)std::atof(next());
     else if (a == "--out") out = next(); else if (a == "--ppm") ppm = next(); else if (a == "--raster") integrator = PTC_INTEGRATOR_RASTER_COMPAT;
     else { std::cerr << "unknown argument " << a << "\n"; return 2; }
   }
   try {
     pbr::PathTraceRenderSystem rs(device);
-    if (scene == "cornell") buildCornell(rs); else if (scene == "sphere") buildSphere(rs, (float)w / h); else throw std::runtime_error("unknown scene " + scene);
+    if (!gltf.empty()) {
+      const pbr::gltf::FlatScene fs = pbr::gltf::load(gltf);
+      rs.beginScene();
+      if (pbr::gltf::upload(rs.handle(), fs) < 0) throw std::runtime_error(ptc_last_error(rs.handle()));
+      if (!haveCam) {   // frame the bounding box from +z
+        const float cx = 0.5f * (fs.bbox_lo[0] + fs.bbox_hi[0]), cy = 0.5f * (fs.bbox_lo[1] + fs.bbox_hi[1]), cz = 0.5f * (fs.bbox_lo[2] + fs.bbox_hi[2]);
+        const float r = 0.5f * std::sqrt((fs.bbox_hi[0] - fs.bbox_lo[0]) * (fs.bbox_hi[0] - fs.bbox_lo[0]) + (fs.bbox_hi[1] - fs.bbox_lo[1]) * (fs.bbox_hi[1] - fs.bbox_lo[1]) +
+                                         (fs.bbox_hi[2] - fs.bbox_lo[2]) * (fs.bbox_hi[2] - fs.bbox_lo[2]));
+        camTarget[0] = cx; camTarget[1] = cy; camTarget[2] = cz;
+        camPos[0] = cx; camPos[1] = cy; camPos[2] = cz + r / std::tan(0.5f * fovDeg * 3.14159265f / 180.0f) + r;
+      }
+      rs.setCamera({camPos[0], camPos[1], camPos[2]}, {camTarget[0], camTarget[1], camTarget[2]}, fovDeg * 3.14159265f / 180.0f, (float)w / h);
+      rs.commitScene();
+      scene = gltf;
+    } else if (scene == "cornell") buildCornell(rs); else if (scene == "sphere") buildSphere(rs, (float)w / h); else throw std::runtime_error("unknown scene " + scene);
     const std::vector<float> img = rs.render(w, h, spp, seed, bounces, integrator);
     const ptc_stats st = rs.stats();
     std::ofstream f(out, std::ios::binary);                       // PFM stores rows bottom-up

@@ -5,5 +5,5 @@
   pbr_amd.scenes  procedural stand-ins for BASELINE.json's configs
   pbr_amd.dist    one-process-per-GPU tile sharding + RCCL framebuffer reduce
 """
-from . import dist, scene, scenes  # noqa: F401
+from . import dist, gltf, scene, scenes  # noqa: F401
 from .ptc import DEVICE_NONE, INTEGRATOR_PATH, INTEGRATOR_RASTER_COMPAT, PathTracer, PtcError, load_library  # noqa: F401

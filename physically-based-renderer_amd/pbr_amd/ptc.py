@@ -26,7 +26,7 @@ INTEGRATOR_RASTER_COMPAT = 1
 # every symbol include/ptc.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "ptc_create", "ptc_destroy", "ptc_last_error", "ptc_abi_version", "ptc_scene_begin", "ptc_add_material",
-    "ptc_add_texture_rgba8", "ptc_add_mesh", "ptc_add_instance", "ptc_set_camera", "ptc_scene_commit", "ptc_render",
+    "ptc_add_texture_rgba8", "ptc_add_mesh", "ptc_add_instance", "ptc_add_instance_matrix", "ptc_set_camera", "ptc_scene_commit", "ptc_render",
     "ptc_frame_begin", "ptc_frame_add_samples", "ptc_frame_resolve", "ptc_sync", "ptc_read_radiance_rgba32f",
     "ptc_radiance_device_ptr", "ptc_write_radiance_rgba32f", "ptc_tonemap_rgba8", "ptc_get_stats",
     "ptc_debug_trace_closest", "ptc_debug_trace_any", "ptc_debug_get_flat_scene", "ptc_debug_get_bvh", "ptc_debug_get_counters",
@@ -78,6 +78,7 @@ def load_library():
     L.ptc_add_texture_rgba8.argtypes = [vp, u8p, C.c_int, C.c_int]
     L.ptc_add_mesh.argtypes = [vp, vp, C.c_uint32, u32p, C.c_uint32, C.c_int]
     L.ptc_add_instance.argtypes = [vp, C.c_int, fp, fp, fp]
+    L.ptc_add_instance_matrix.argtypes = [vp, C.c_int, fp]
     L.ptc_set_camera.argtypes = [vp, fp, fp, C.c_float, C.c_float]
     L.ptc_scene_commit.argtypes = [vp]
     L.ptc_render.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int]
@@ -141,7 +142,10 @@ class PathTracer:
             i = np.ascontiguousarray(me.indices, np.uint32)
             self._ck(L.ptc_add_mesh(h, v.ctypes.data, v.size, i.ctypes.data_as(C.POINTER(C.c_uint32)), i.size, me.material))
         for it in desc.instances:
-            self._ck(L.ptc_add_instance(h, it.mesh, _f(it.t)[1], _f(it.q_wxyz)[1], _f(it.s)[1]))
+            if getattr(it, "matrix", None) is not None:
+                self._ck(L.ptc_add_instance_matrix(h, it.mesh, _f(np.asarray(it.matrix, np.float32).reshape(16))[1]))
+            else:
+                self._ck(L.ptc_add_instance(h, it.mesh, _f(it.t)[1], _f(it.q_wxyz)[1], _f(it.s)[1]))
         c = desc.camera
         self._ck(L.ptc_set_camera(h, _f(c.position)[1], _f(c.target)[1], c.fov_y, c.aspect))
         self._ck(L.ptc_scene_commit(h))

@@ -180,9 +180,10 @@ class MeshDesc:
 @dataclasses.dataclass
 class InstanceDesc:
     mesh: int
-    t: Sequence[float]
-    q_wxyz: Sequence[float]
-    s: Sequence[float]
+    t: Sequence[float] = (0.0, 0.0, 0.0)
+    q_wxyz: Sequence[float] = (1.0, 0.0, 0.0, 0.0)
+    s: Sequence[float] = (1.0, 1.0, 1.0)
+    matrix: Optional[Sequence[float]] = None  # 16 floats, column-major (glm layout); overrides t/q/s when given
 
 
 @dataclasses.dataclass

@@ -1,0 +1,146 @@
+"""glTF 2.0 / GLB loader without a GPU: a PTC_DEVICE_NONE context is filled from files that the
+test writes itself (the reference's asset assets/models/test_scene.glb is stripped: .MISSING_LARGE_BLOBS), and the
+flattened scene must equal the one obtained by handing the same SceneDesc straight to the C-ABI."""
+import base64
+import json
+import math
+import os
+import struct
+
+import numpy as np
+import pytest
+
+
+def _flat(pbr, desc):
+    return pbr.PathTracer(pbr.DEVICE_NONE).load_scene(desc).flat_scene()
+
+
+def _flat_glb(pbr, path, **kw):
+    pt = pbr.PathTracer(pbr.DEVICE_NONE)
+    info = pbr.gltf.load_into(pt, path, **kw)
+    return pt.flat_scene(), info, pt
+
+
+@pytest.mark.parametrize("name,kw", [("cornell", {}), ("sphere10k", {}), ("two_tris_sphere", {}), ("atrium", {"scale": 0.05})])
+@pytest.mark.parametrize("index_type,interleaved", [("auto", False), ("u32", True)])
+def test_glb_round_trip_is_bit_exact(pbr, tmp_path, name, kw, index_type, interleaved):
+    d = pbr.scenes.by_name(name, **kw)
+    p = str(tmp_path / "scene.glb")
+    pbr.gltf.write_glb(d, p, index_type=index_type, interleaved=interleaved)
+    (v1, i1, m1), (n, lo, hi), pt = _flat_glb(pbr, p, camera=d.camera)
+    v2, i2, m2 = _flat(pbr, d)
+    assert n == d.n_triangles
+    assert np.array_equal(v1.view(np.uint32), v2.view(np.uint32)) and np.array_equal(i1, i2) and np.array_equal(m1, m2)
+    assert np.allclose(lo, v2[:, :3].min(0), atol=1e-5) and np.allclose(hi, v2[:, :3].max(0), atol=1e-5)
+    assert pt.stats()["n_emitters"] == pbr.PathTracer(pbr.DEVICE_NONE).load_scene(d).stats()["n_emitters"]
+
+
+def _tri_mesh(pbr):
+    v = np.zeros(3, pbr.scene.MESH_VERTEX)
+    v["position"] = [(0, 0, 0), (1, 0, 0), (0, 1, 0)]
+    v["normal"] = (0, 0, 1)
+    v["tangent"] = (1, 0, 0, 1)
+    v["texCoords"] = [(0, 0), (1, 0), (0, 1)]
+    return pbr.scene.MeshDesc(v, np.array([0, 1, 2], np.uint32), 0)
+
+
+def test_node_hierarchy_composition(pbr, tmp_path):
+    sc = pbr.scene
+    d = sc.SceneDesc([sc.Material()], [_tri_mesh(pbr)], [sc.InstanceDesc(0)], sc.CameraDesc((0, 0, 5), (0, 0, 0), 1.0, 1.0))
+    c, s_ = math.cos(math.pi / 4), math.sin(math.pi / 4)   # 90° about +y, glTF rotation order (x,y,z,w)
+    M = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, -2, 1]  # column-major translate(0,0,-2)
+    nodes = [
+        {"name": "root", "translation": [1, 2, 3], "scale": [2, 2, 2], "children": [1, 2]},
+        {"name": "rotated", "rotation": [0, s_, 0, c], "mesh": 0, "children": [3]},
+        {"name": "by_matrix", "matrix": M, "mesh": 0},
+        {"name": "leaf", "translation": [0.5, 0, 0], "mesh": 0},
+    ]
+    p = str(tmp_path / "h.glb")
+    pbr.gltf.write_glb(d, p, nodes=(nodes, [0]))
+    (v, idx, _), (n, _, _), _ = _flat_glb(pbr, p, camera=d.camera)
+    assert n == 3 and v.shape[0] == 9
+    P = v[:, :3].reshape(3, 3, 3)                                     # emission order: children before the node (post-order): leaf, rotated, by_matrix
+    local = np.array([(0, 0, 0), (1, 0, 0), (0, 1, 0)], np.float64)
+    Ry = np.array([[0, 0, 1], [0, 1, 0], [-1, 0, 0]], np.float64)    # +x → -z
+    root = lambda q: 2.0 * q + np.array([1, 2, 3])
+    assert np.allclose(P[0], root((local + [0.5, 0, 0]) @ Ry.T), atol=1e-5)   # leaf: root · rotated · translate(0.5,0,0)
+    assert np.allclose(P[1], root(local @ Ry.T), atol=1e-5)
+    assert np.allclose(P[2], root(local + [0, 0, -2]), atol=1e-5)
+    N = v[:, 3:6].reshape(3, 3, 3)
+    assert np.allclose(N[1], [[1, 0, 0]] * 3, atol=1e-6)             # +z normal rotated to +x
+    # the reference quirk: each node with its local transform only (PbrRenderSystem.cpp:444-446)
+    (v2, _, _), _, _ = _flat_glb(pbr, p, camera=d.camera, compose_parents=False)
+    P2 = v2[:, :3].reshape(3, 3, 3)
+    assert np.allclose(P2[0], local + [0.5, 0, 0], atol=1e-6) and np.allclose(P2[1], local @ Ry.T, atol=1e-6)
+
+
+def _write_gltf(tmp_path, doc, bins=()):
+    for name, data in bins:
+        (tmp_path / name).write_bytes(data)
+    p = tmp_path / "a.gltf"
+    p.write_text(json.dumps(doc))
+    return str(p)
+
+
+def test_defaults_external_buffers_and_normalized_accessors(pbr, tmp_path):
+    pos = np.array([(0, 0, 0), (2, 0, 0), (0, 2, 0), (2, 0, 0), (2, 2, 0), (0, 2, 0)], "<f4")   # unindexed: 2 triangles
+    uv8 = np.array([(0, 0), (255, 0), (0, 255), (255, 0), (255, 255), (0, 255)], np.uint8)         # normalized UNSIGNED_BYTE
+    uv16 = (uv8.astype(np.uint16) * 257).astype("<u2")
+    pad = b"\x00" * ((4 - uv8.nbytes % 4) % 4)
+    bin0 = pos.tobytes()
+    bin1 = uv8.tobytes() + pad + uv16.tobytes()
+    doc = {
+        "asset": {"version": "2.0"},
+        "buffers": [{"uri": "geo.bin", "byteLength": len(bin0)}, {"uri": "data:application/octet-stream;base64," + base64.b64encode(bin1).decode(), "byteLength": len(bin1)}],
+        "bufferViews": [{"buffer": 0, "byteLength": len(bin0)}, {"buffer": 1, "byteLength": uv8.nbytes, "byteStride": 2},
+                        {"buffer": 1, "byteOffset": uv8.nbytes + len(pad), "byteLength": uv16.nbytes}],
+        "accessors": [{"bufferView": 0, "componentType": 5126, "count": 6, "type": "VEC3"},
+                      {"bufferView": 1, "componentType": 5121, "normalized": True, "count": 6, "type": "VEC2"},
+                      {"bufferView": 2, "componentType": 5123, "normalized": True, "count": 6, "type": "VEC2"}],
+        "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "TEXCOORD_0": 1}}]},          # no normals/tangents/indices/material/mode
+                   {"primitives": [{"attributes": {"POSITION": 0, "TEXCOORD_0": 2}, "material": 0}]}],
+        "materials": [{"pbrMetallicRoughness": {"baseColorFactor": [0.5, 0.25, 1, 1], "roughnessFactor": 0.4}, "emissiveFactor": [1, 0.5, 0.25],
+                       "extensions": {"KHR_materials_emissive_strength": {"emissiveStrength": 8}}}],
+        "nodes": [{"mesh": 0}, {"mesh": 1, "translation": [0, 0, -1]}],
+        "scenes": [{"nodes": [0, 1]}],
+    }
+    p = _write_gltf(tmp_path, doc, [("geo.bin", bin0)])
+    (v, idx, mats), (n, lo, hi), pt = _flat_glb(pbr, p)
+    assert n == 4 and np.array_equal(idx.reshape(-1), np.arange(12))              # GenerateMeshIndices
+    assert np.allclose(v[:6, 3:6], [[0, 0, 1]] * 6)                               # generated normals: +z for CCW in the xy-plane
+    assert np.allclose(np.einsum("ij,ij->i", v[:6, 3:6], v[:6, 6:9]), 0, atol=1e-6) and np.allclose(v[:6, 9], 1)   # generated tangents ⟂ n, w = +1
+    exp_uv = uv8.astype(np.float32) / np.float32(255)
+    assert np.array_equal(v[:6, 10:12], exp_uv) and np.array_equal(v[6:, 10:12], exp_uv)   # 255-normalised == 65535-normalised here
+    assert list(mats) == [1, 1, 0, 0]                                              # default material appended after the file's materials
+    assert pt.stats()["n_emitters"] == 2                                           # emissive strength 8 × factor
+    assert np.allclose(lo, (0, 0, -1)) and np.allclose(hi, (2, 2, 0))
+
+
+@pytest.mark.parametrize("mutate,msg", [
+    (lambda d: d["meshes"][0]["primitives"][0]["attributes"].pop("POSITION"), "POSITION"),
+    (lambda d: d["meshes"][0]["primitives"][0].update(mode=1), "mode 1"),
+    (lambda d: d["accessors"][0].update(count=7), "exceeds"),
+    (lambda d: d["asset"].update(version="1.0"), "2.x"),
+    (lambda d: d["scenes"][0].update(nodes=[5]), "node index"),
+    (lambda d: d["nodes"][0].update(children=[0]), "too deep"),
+    (lambda d: d["accessors"][0].update(sparse={"count": 1}), "sparse"),
+])
+def test_loader_errors_are_reported(pbr, tmp_path, mutate, msg):
+    pos = np.array([(0, 0, 0), (1, 0, 0), (0, 1, 0)], "<f4")
+    doc = {"asset": {"version": "2.0"}, "buffers": [{"uri": "data:application/octet-stream;base64," + base64.b64encode(pos.tobytes()).decode(), "byteLength": 36}],
+           "bufferViews": [{"buffer": 0, "byteLength": 36}], "accessors": [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"}],
+           "meshes": [{"primitives": [{"attributes": {"POSITION": 0}}]}], "nodes": [{"mesh": 0}], "scenes": [{"nodes": [0]}]}
+    mutate(doc)
+    p = _write_gltf(tmp_path, doc)
+    with pytest.raises(pbr.PtcError, match=msg):
+        _flat_glb(pbr, p)
+
+
+def test_broken_containers(pbr, tmp_path):
+    for name, data, msg in [("x.glb", b"glTF" + struct.pack("<II", 1, 12), "version 1"), ("y.glb", b"glTF" + struct.pack("<II", 2, 9999), "length"),
+                            ("z.gltf", b"{ not json", "JSON"), ("w.gltf", b'{"asset": {"version": "2.0"}}', "no scenes")]:
+        (tmp_path / name).write_bytes(data)
+        with pytest.raises(pbr.PtcError, match=msg):
+            _flat_glb(pbr, str(tmp_path / name))
+    with pytest.raises(pbr.PtcError, match="cannot open"):
+        _flat_glb(pbr, str(tmp_path / "missing.glb"))

@@ -269,3 +269,27 @@ def test_cpp_host_cli(gpu, ora, tmp_path):
     assert np.array_equal(ldr, ora.tonemap_rgba8(ref)[..., :3])
     bad = subprocess.run([exe, "--scene", "nope"], capture_output=True, text=True, timeout=60)
     assert bad.returncode == 1 and "unknown scene" in bad.stderr
+
+
+def test_gltf_loaded_scene_renders_identically(gpu, ora, tmp_path):
+    """§8f-1: a scene that went through the GLB writer and the C++ glTF loader renders bit for bit like the same
+    SceneDesc handed to the C-ABI directly (and like the oracle); the CLI takes the same file."""
+    import subprocess
+
+    d = gpu.scenes.sphere_scene(32, 17)
+    p = str(tmp_path / "s.glb")
+    gpu.gltf.write_glb(d, p)
+    pt = gpu.PathTracer(0)
+    n, lo, hi = gpu.gltf.load_into(pt, p, camera=d.camera)
+    assert n == d.n_triangles
+    a = pt.render(96, 96, 4, seed=9, max_bounces=4)
+    ref = ora.Oracle().load_scene(d).render(96, 96, 4, seed=9, max_bounces=4)
+    assert _bits_equal(a, ref)
+    exe = os.path.join(os.path.dirname(gpu.ptc.LIB_PATH), "ptc_render")
+    out = str(tmp_path / "g.pfm")
+    cam = d.camera
+    r = subprocess.run([exe, "--gltf", p, "--width", "96", "--height", "96", "--spp", "4", "--seed", "9", "--bounces", "4", "--out", out,
+                        "--cam-pos", *map(str, cam.position), "--cam-target", *map(str, cam.target), "--fov", "45"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    img = np.frombuffer(open(out, "rb").read().split(b"-1.0\n", 1)[1], "<f4").reshape(96, 96, 3)[::-1]
+    assert rel_l2(np.ascontiguousarray(img), ref[..., :3]) <= TOL          # the CLI rounds fov from degrees in float: not bit-identical inputs
