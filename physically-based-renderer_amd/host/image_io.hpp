@@ -1,0 +1,75 @@
+// image_io.hpp — dependency-free image writers for the offline renderer: PFM for the fp32 radiance
+// buffer, PNG (8-bit RGBA, stored-deflate: no compression library needed) for the tonemapped output that the
+// reference only ever presents to a swapchain (src/gltf_viewer/App.cpp:384-393).
+#pragma once
+#include <cstdint>
+#include <fstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace pbr::image {
+
+// rgba: w*h*4 floats, row 0 = top (y-down like the HdrImage); PFM stores rows bottom-up, RGB, little endian (-1.0)
+inline void write_pfm(const std::string& path, const float* rgba, int w, int h) {
+  std::ofstream f(path, std::ios::binary);
+  if (!f) throw std::runtime_error("cannot write " + path);
+  f << "PF\n" << w << " " << h << "\n-1.0\n";
+  for (int y = h - 1; y >= 0; --y)
+    for (int x = 0; x < w; ++x) f.write(reinterpret_cast<const char*>(&rgba[((std::size_t)y * w + x) * 4]), 12);
+}
+
+namespace detail {
+inline std::uint32_t crc32(const std::uint8_t* p, std::size_t n, std::uint32_t crc = 0) {
+  static std::uint32_t table[256];
+  static bool init = false;
+  if (!init) {
+    for (std::uint32_t i = 0; i < 256; ++i) { std::uint32_t c = i; for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1; table[i] = c; }
+    init = true;
+  }
+  crc = ~crc;
+  for (std::size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
+  return ~crc;
+}
+inline void be32(std::vector<std::uint8_t>& v, std::uint32_t x) { v.push_back((std::uint8_t)(x >> 24)); v.push_back((std::uint8_t)(x >> 16)); v.push_back((std::uint8_t)(x >> 8)); v.push_back((std::uint8_t)x); }
+inline void chunk(std::vector<std::uint8_t>& out, const char type[4], const std::vector<std::uint8_t>& data) {
+  be32(out, (std::uint32_t)data.size());
+  const std::size_t start = out.size();
+  out.insert(out.end(), type, type + 4);
+  out.insert(out.end(), data.begin(), data.end());
+  be32(out, crc32(&out[start], out.size() - start));
+}
+}  // namespace detail
+
+// rgba8: w*h*4 bytes, row 0 = top.  PNG colour type 6 (RGBA), 8 bits, filter 0, zlib stream of stored blocks.
+inline void write_png(const std::string& path, const std::uint8_t* rgba8, int w, int h) {
+  using namespace detail;
+  std::vector<std::uint8_t> raw;
+  raw.reserve((std::size_t)h * ((std::size_t)w * 4 + 1));
+  for (int y = 0; y < h; ++y) { raw.push_back(0); raw.insert(raw.end(), rgba8 + (std::size_t)y * w * 4, rgba8 + (std::size_t)(y + 1) * w * 4); }
+  std::vector<std::uint8_t> z{0x78, 0x01};
+  std::uint32_t a = 1, b = 0;                                   // Adler-32 of the raw stream
+  for (std::uint8_t c : raw) { a = (a + c) % 65521u; b = (b + a) % 65521u; }
+  for (std::size_t p = 0; p < raw.size() || p == 0;) {
+    const std::size_t n = raw.size() - p < 65535 ? raw.size() - p : 65535;
+    z.push_back(p + n >= raw.size() ? 1 : 0);                   // BFINAL, BTYPE = 00 (stored)
+    z.push_back((std::uint8_t)(n & 0xFF)); z.push_back((std::uint8_t)(n >> 8));
+    z.push_back((std::uint8_t)(~n & 0xFF)); z.push_back((std::uint8_t)((~n >> 8) & 0xFF));
+    z.insert(z.end(), raw.begin() + (long)p, raw.begin() + (long)(p + n));
+    p += n;
+    if (n == 0) break;
+  }
+  be32(z, (b << 16) | a);
+  std::vector<std::uint8_t> out{0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+  std::vector<std::uint8_t> ihdr;
+  be32(ihdr, (std::uint32_t)w); be32(ihdr, (std::uint32_t)h);
+  ihdr.insert(ihdr.end(), {8, 6, 0, 0, 0});
+  chunk(out, "IHDR", ihdr);
+  chunk(out, "IDAT", z);
+  chunk(out, "IEND", {});
+  std::ofstream f(path, std::ios::binary);
+  if (!f) throw std::runtime_error("cannot write " + path);
+  f.write(reinterpret_cast<const char*>(out.data()), (std::streamsize)out.size());
+}
+
+}  // namespace pbr::image

@@ -1,9 +1,10 @@
 // ptc_render — dependency-free C++17 offline renderer over the C-ABI (include/ptc.h).
 //   ptc_render (--scene cornell|sphere | --gltf file.glb [--cam-pos x y z --cam-target x y z --fov deg]) --width W --height H
-//              --spp N --seed S --bounces B [--raster] --out image.pfm [--ppm image.ppm]
+//              --spp N --seed S --bounces B [--raster] --out image.pfm [--png image.png] [--ppm image.ppm]
 // Without --cam-* a glTF scene is framed from its bounding box (the reference ignores glTF cameras and injects its own).
 // The scenes are the procedural stand-ins of BASELINE configs 1 and 2 (the reference's assets are stripped).
 #include "gltf_loader.hpp"
+#include "image_io.hpp"
 #include "pbr_pt.hpp"
 
 #include <cmath>
@@ -96,7 +97,7 @@ void buildSphere(pbr::PathTraceRenderSystem& rs, float aspect) {
 }  // namespace
 
 int main(int argc, char** argv) {
-  std::string scene = "cornell", out = "out.pfm", ppm, gltf;
+  std::string scene = "cornell", out = "out.pfm", ppm, png, gltf;
   float camPos[3] = {0, 0, 0}, camTarget[3] = {0, 0, -1}, fovDeg = 60.0f;
   bool haveCam = false;
   int w = 256, h = 256, spp = 64, bounces = 8, device = 0, integrator = PTC_INTEGRATOR_PATH;
@@ -111,7 +112,7 @@ int main(int argc, char** argv) {
     else if (a == "--cam-pos") { for (float& v : camPos) v = (float)std::atof(next()); haveCam = true; }
     else if (a == "--cam-target") { for (float& v : camTarget) v = (float)std::atof(next()); }
     else if (a == "--fov") fovDeg = (float)std::atof(next());
-    else if (a == "--out") out = next(); else if (a == "--ppm") ppm = next(); else if (a == "--raster") integrator = PTC_INTEGRATOR_RASTER_COMPAT;
+    else if (a == "--out") out = next(); else if (a == "--png") png = next(); else if (a == "--ppm") ppm = next(); else if (a == "--raster") integrator = PTC_INTEGRATOR_RASTER_COMPAT;
     else { std::cerr << "unknown argument " << a << "\n"; return 2; }
   }
   try {
@@ -133,10 +134,8 @@ int main(int argc, char** argv) {
     } else if (scene == "cornell") buildCornell(rs); else if (scene == "sphere") buildSphere(rs, (float)w / h); else throw std::runtime_error("unknown scene " + scene);
     const std::vector<float> img = rs.render(w, h, spp, seed, bounces, integrator);
     const ptc_stats st = rs.stats();
-    std::ofstream f(out, std::ios::binary);                       // PFM stores rows bottom-up
-    f << "PF\n" << w << " " << h << "\n-1.0\n";
-    for (int y = h - 1; y >= 0; --y)
-      for (int x = 0; x < w; ++x) f.write(reinterpret_cast<const char*>(&img[((std::size_t)y * w + x) * 4]), 12);
+    pbr::image::write_pfm(out, img.data(), w, h);
+    if (!png.empty()) { const std::vector<std::uint8_t> ldr = rs.tonemap(); pbr::image::write_png(png, ldr.data(), w, h); }
     if (!ppm.empty()) {
       const std::vector<std::uint8_t> ldr = rs.tonemap();
       std::ofstream g(ppm, std::ios::binary);

@@ -251,8 +251,8 @@ def test_cpp_host_cli(gpu, ora, tmp_path):
 
     exe = os.path.join(os.path.dirname(gpu.ptc.LIB_PATH), "ptc_render")
     assert os.path.exists(exe), "ptc_render not built"
-    out, ppm = str(tmp_path / "c.pfm"), str(tmp_path / "c.ppm")
-    r = subprocess.run([exe, "--scene", "cornell", "--width", "96", "--height", "64", "--spp", "8", "--seed", "5", "--bounces", "4", "--out", out, "--ppm", ppm],
+    out, ppm, png = str(tmp_path / "c.pfm"), str(tmp_path / "c.ppm"), str(tmp_path / "c.png")
+    r = subprocess.run([exe, "--scene", "cornell", "--width", "96", "--height", "64", "--spp", "8", "--seed", "5", "--bounces", "4", "--out", out, "--ppm", ppm, "--png", png],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     info = json.loads(r.stdout.strip().splitlines()[-1])
@@ -267,6 +267,9 @@ def test_cpp_host_cli(gpu, ora, tmp_path):
     assert _bits_equal(np.ascontiguousarray(img), np.ascontiguousarray(ref[..., :3]))
     ldr = np.frombuffer(open(ppm, "rb").read().split(b"255\n", 1)[1], np.uint8).reshape(64, 96, 3)
     assert np.array_equal(ldr, ora.tonemap_rgba8(ref)[..., :3])
+    from PIL import Image                                                      # the stored-deflate PNG writer (host/image_io.hpp)
+
+    assert np.array_equal(np.asarray(Image.open(png)), ora.tonemap_rgba8(ref))
     bad = subprocess.run([exe, "--scene", "nope"], capture_output=True, text=True, timeout=60)
     assert bad.returncode == 1 and "unknown scene" in bad.stderr
 
