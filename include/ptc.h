@@ -136,6 +136,11 @@ int ptc_add_instance_matrix(ptc_ctx*, int mesh, const float model[16]);
 int ptc_set_camera(ptc_ctx*, const float pos[3], const float target[3], float fov_y,
                    float aspect);
 
+/* Lat-long environment light (BASELINE config 5; no counterpart in the reference, which has no lights): w*h RGB
+ * fp32 texels, row 0 = +y, u = atan2(d.z, d.x)/(2 pi) + 1/2, piecewise-constant radiance, importance-sampled by
+ * luminance x sin(theta).  rgb == NULL removes it.  Call before ptc_scene_commit. */
+int ptc_set_env_latlong_rgb32f(ptc_ctx*, const float* rgb, int w, int h);
+
 /* Flatten instances to world space (geometry_pass/vertex.glsl:25-36), build + flatten the LBVH,
  * build the emitter CDF, upload everything to HBM. */
 int ptc_scene_commit(ptc_ctx*);

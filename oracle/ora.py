@@ -51,6 +51,10 @@ def lib():
         L.ora_scene_begin.argtypes = [vp]
         L.ora_add_material.argtypes = [vp, fp, C.c_float, C.c_float, fp, C.c_int, C.c_int, C.c_int]
         L.ora_add_mesh.argtypes = [vp, vp, C.c_uint32, u32p, C.c_uint32, C.c_int]
+        L.ora_add_texture_rgba8.argtypes = [vp, u8p, C.c_int, C.c_int]
+        L.ora_set_env_latlong_rgb32f.argtypes = [vp, fp, C.c_int, C.c_int]
+        L.ora_atan2f.argtypes = [C.c_float, C.c_float]
+        L.ora_atan2f.restype = C.c_float
         L.ora_add_instance.argtypes = [vp, C.c_int, fp, fp, fp]
         L.ora_add_instance_matrix.argtypes = [vp, C.c_int, fp]
         L.ora_set_camera.argtypes = [vp, fp, fp, C.c_float, C.c_float]
@@ -112,6 +116,13 @@ class Oracle:
     def load_scene(self, desc):
         L, h = self._L, self._h
         self._ck(L.ora_scene_begin(h))
+        for t in getattr(desc, "textures", []):
+            t = np.ascontiguousarray(t, np.uint8)
+            self._ck(L.ora_add_texture_rgba8(h, t.ctypes.data_as(C.POINTER(C.c_uint8)), t.shape[1], t.shape[0]))
+        env = getattr(desc, "env", None)
+        if env is not None:
+            e = np.ascontiguousarray(env, np.float32)
+            self._ck(L.ora_set_env_latlong_rgb32f(h, e.ctypes.data_as(C.POINTER(C.c_float)), e.shape[1], e.shape[0]))
         for m in desc.materials:
             _, b = _f(m.base_color)
             _, e = _f(m.emissive)

@@ -154,6 +154,22 @@ static inline float pt_pow(float x, float y) {
 }
 float ora_powf(float x, float y) { return pt_pow(x, y); }
 
+/* atan2(y, x) in (-pi, pi]: octant reduction + odd minimax polynomial on [0,1] (max error ~1e-5 rad).  Only the
+ * lat-long environment lookup uses it, where 1e-5 rad is a few thousandths of a texel. */
+static inline float pt_atan2(float y, float x) {
+  float ax = fabsf(x), ay = fabsf(y);
+  float mx = fmax2(ax, ay), mn = fmin2(ax, ay);
+  if (!(mx > 0.0f)) return 0.0f;
+  float a = mn / mx, a2 = a * a;
+  float p = fmaf(a2, fmaf(a2, fmaf(a2, fmaf(a2, fmaf(a2, -0.01172120f, 0.05265332f), -0.11643287f), 0.19354346f), -0.33262347f), 0.99997726f);
+  float r = a * p;
+  if (ay > ax) r = ORA_HALF_PI - r;
+  if (x < 0.0f) r = ORA_PI - r;
+  if (y < 0.0f) r = -r;
+  return r;
+}
+float ora_atan2f(float y, float x) { return pt_atan2(y, x); }
+
 /* ------------------------------------------------------------------------------------------ */
 /* scene containers                                                                            */
 typedef struct { float position[3], normal[3], tangent[4], texcoord[2]; } vert48; /* R1 */
@@ -197,6 +213,7 @@ struct ora_ctx {
   /* committed */
   int committed;
   vert48* wv; uint32_t n_wv;           /* world-space vertices  */
+  float* wbt;                          /* world-space bitangent per vertex, 3 floats (vertex.glsl:35) */
   uint32_t* widx; uint32_t n_tris;     /* 3 per triangle        */
   int32_t* tri_mat;
   /* BVH (triangles in sorted order) */
@@ -207,6 +224,8 @@ struct ora_ctx {
   int32_t* prim_light;                 /* original prim id → light index or -1 */
   light_t* lights; float* cdf; uint32_t n_lights;
   float scene_lo[3], scene_hi[3]; float ray_eps;
+  /* lat-long environment light: radiance texels, pmf, row-marginal and per-row conditional cdfs */
+  float* env_px; int env_w, env_h; float* env_pmf; float* env_marg; float* env_cond; int env_ok;
   ora_stats stats;
 };
 
@@ -220,15 +239,17 @@ ora_ctx* ora_create(void) {
   return c;
 }
 static void free_committed(ora_ctx* c) {
-  free(c->wv); free(c->widx); free(c->tri_mat); free(c->order); free(c->tv0); free(c->te1); free(c->te2);
+  free(c->wv); free(c->wbt); free(c->widx); free(c->tri_mat); free(c->order); free(c->tv0); free(c->te1); free(c->te2);
   free(c->nodes); free(c->wnodes); free(c->prim_light); free(c->lights); free(c->cdf);
-  c->wv = NULL; c->widx = NULL; c->tri_mat = NULL; c->order = NULL; c->tv0 = c->te1 = c->te2 = NULL;
+  c->wv = NULL; c->wbt = NULL; c->widx = NULL; c->tri_mat = NULL; c->order = NULL; c->tv0 = c->te1 = c->te2 = NULL;
   c->nodes = NULL; c->wnodes = NULL; c->prim_light = NULL; c->lights = NULL; c->cdf = NULL; c->committed = 0;
 }
 static void free_description(ora_ctx* c) {
   for (int i = 0; i < c->n_meshes; ++i) { free(c->meshes[i].v); free(c->meshes[i].idx); }
   for (int i = 0; i < c->n_texs; ++i) free(c->texs[i].px);
   free(c->meshes); free(c->mats); free(c->insts); free(c->texs);
+  free(c->env_px); free(c->env_pmf); free(c->env_marg); free(c->env_cond);
+  c->env_px = c->env_pmf = c->env_marg = c->env_cond = NULL; c->env_w = c->env_h = 0; c->env_ok = 0;
   c->meshes = NULL; c->mats = NULL; c->insts = NULL; c->texs = NULL;
   c->n_meshes = c->n_mats = c->n_insts = c->n_texs = 0;
 }
@@ -240,7 +261,6 @@ int ora_add_material(ora_ctx* c, const float base[4], float metallic, float roug
                      const float emissive[3], int tc, int tn, int tmr) {
   if (!base || !emissive) return fail(c, "add_material: null pointer");
   if (tc >= c->n_texs || tn >= c->n_texs || tmr >= c->n_texs) return fail(c, "add_material: texture id out of range");
-  if (tc >= 0 || tn >= 0 || tmr >= 0) return fail(c, "add_material: textures are not implemented in this round");
   c->mats = (material_t*)realloc(c->mats, sizeof(material_t) * (size_t)(c->n_mats + 1));
   material_t* m = &c->mats[c->n_mats];
   memcpy(m->base, base, 16); m->metallic = metallic; m->roughness = roughness;
@@ -286,6 +306,45 @@ int ora_set_camera(ora_ctx* c, const float pos[3], const float target[3], float 
   if (!pos || !target) return fail(c, "set_camera: null pointer");
   memcpy(c->cam_pos, pos, 12); memcpy(c->cam_target, target, 12); c->cam_fov = fov; c->cam_aspect = aspect;
   c->have_cam = 1; return 0;
+}
+
+/* Lat-long environment map: w*h RGB texels, row 0 = +y (up), u = atan2(d.z, d.x)/(2pi) + 0.5.  Piecewise-constant
+ * radiance; sampled proportionally to luminance x sin(theta_row) (row marginal + per-row conditional cdf). */
+int ora_set_env_latlong_rgb32f(ora_ctx* c, const float* px, int w, int h) {
+  free(c->env_px); free(c->env_pmf); free(c->env_marg); free(c->env_cond);
+  c->env_px = c->env_pmf = c->env_marg = c->env_cond = NULL; c->env_w = c->env_h = 0; c->env_ok = 0;
+  if (!px) return 0;
+  if (w <= 0 || h <= 0) return fail(c, "set_env: bad size");
+  size_t n = (size_t)w * h;
+  c->env_px = (float*)malloc(12 * n); memcpy(c->env_px, px, 12 * n);
+  c->env_pmf = (float*)malloc(4 * n); c->env_cond = (float*)malloc(4 * n); c->env_marg = (float*)malloc(4 * (size_t)h);
+  c->env_w = w; c->env_h = h;
+  float* rowsum = (float*)malloc(4 * (size_t)h);
+  float total = 0.0f;
+  for (int y = 0; y < h; ++y) {
+    float sr = (float)sin(3.14159265358979323846 * ((double)y + 0.5) / (double)h);
+    float run = 0.0f;
+    for (int x = 0; x < w; ++x) {
+      const float* t = &c->env_px[((size_t)y * w + x) * 3];
+      float f = luminance(V3(t[0], t[1], t[2])) * sr;
+      if (!(f > 0.0f)) f = 0.0f;
+      c->env_pmf[(size_t)y * w + x] = f;
+      run += f;
+      c->env_cond[(size_t)y * w + x] = run;
+    }
+    rowsum[y] = run; total += run;
+    for (int x = 0; x < w; ++x) c->env_cond[(size_t)y * w + x] = run > 0.0f ? c->env_cond[(size_t)y * w + x] / run : (float)(x + 1) / (float)w;
+    c->env_cond[(size_t)y * w + (w - 1)] = 1.0f;
+  }
+  if (total > 0.0f) {
+    float run = 0.0f;
+    for (int y = 0; y < h; ++y) { run += rowsum[y]; c->env_marg[y] = run / total; }
+    c->env_marg[h - 1] = 1.0f;
+    for (size_t i = 0; i < n; ++i) c->env_pmf[i] = c->env_pmf[i] / total;
+    c->env_ok = 1;
+  }
+  free(rowsum);
+  return 0;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -514,6 +573,7 @@ int ora_scene_commit(ora_ctx* c) {
   for (int i = 0; i < c->n_insts; ++i) { nv += c->meshes[c->insts[i].mesh].nv; nt += c->meshes[c->insts[i].mesh].ni / 3; }
   if (nt >= (1u << 28)) return fail(c, "scene_commit: too many triangles");
   c->wv = (vert48*)malloc(sizeof(vert48) * nv); c->n_wv = (uint32_t)nv;
+  c->wbt = (float*)malloc(12 * nv);
   c->widx = (uint32_t*)malloc(12u * nt); c->tri_mat = (int32_t*)malloc(4u * nt); c->n_tris = (uint32_t)nt;
   uint32_t vb = 0, tb = 0;
   for (int i = 0; i < c->n_insts; ++i) {
@@ -529,6 +589,8 @@ int ora_scene_commit(ora_ctx* c) {
       d->position[0] = p.x; d->position[1] = p.y; d->position[2] = p.z;
       d->normal[0] = n.x; d->normal[1] = n.y; d->normal[2] = n.z;
       d->tangent[0] = t.x; d->tangent[1] = t.y; d->tangent[2] = t.z; d->tangent[3] = s->tangent[3];
+      v3 bt = normalize3(mat3_mul(N, vscale(cross3(n0, t0), s->tangent[3])));   /* vertex.glsl:35 */
+      c->wbt[(size_t)(vb + k) * 3 + 0] = bt.x; c->wbt[(size_t)(vb + k) * 3 + 1] = bt.y; c->wbt[(size_t)(vb + k) * 3 + 2] = bt.z;
       d->texcoord[0] = s->texcoord[0]; d->texcoord[1] = s->texcoord[1];
     }
     for (uint32_t k = 0; k < m->ni / 3; ++k) {
@@ -641,7 +703,7 @@ int ora_get_bvh(ora_ctx* c, uint32_t* nn, uint32_t* nt, float* nodes, float* tri
   if (tris) for (uint32_t i = 0; i < c->n_tris; ++i) {
     float* o = tris + (size_t)i * 12; uint32_t p = c->order[i];
     const material_t* m = &c->mats[c->tri_mat[p]];
-    uint32_t cls = (m->metallic == 0.0f && m->roughness >= 1.0f) ? 0u : 1u;
+    uint32_t cls = (m->metallic == 0.0f && m->roughness >= 1.0f && m->tex_mr < 0) ? 0u : 1u;
     o[0] = c->tv0[i].x; o[1] = c->tv0[i].y; o[2] = c->tv0[i].z; memcpy(&o[3], &p, 4);
     o[4] = c->te1[i].x; o[5] = c->te1[i].y; o[6] = c->te1[i].z; memcpy(&o[7], &cls, 4);
     o[8] = c->te2[i].x; o[9] = c->te2[i].y; o[10] = c->te2[i].z; o[11] = 0.0f;
@@ -805,14 +867,12 @@ int ora_trace_any(ora_ctx* c, const float* o, const float* d, const float* tmax,
 /* P6: BSDF in the local frame of the shading normal (z = n).                                    */
 typedef struct { v3 cd, f0; float alpha; int ggx; } bsdf_t;
 
-static inline bsdf_t make_bsdf(const material_t* m) {
+static inline bsdf_t make_bsdf(v3 base, float mt, float roughness, int lambert_class) {
   bsdf_t b;
-  v3 base = V3(m->base[0], m->base[1], m->base[2]);
-  float mt = m->metallic;
-  b.ggx = !(mt == 0.0f && m->roughness >= 1.0f);      /* metallic 0 & roughness 1 → pure Lambert class */
+  b.ggx = !lambert_class;                              /* metallic 0 & roughness >= 1 & no mr texture → pure Lambert class */
   b.cd = vscale(base, 1.0f - mt);
   b.f0 = V3(fmaf(base.x, mt, 0.04f * (1.0f - mt)), fmaf(base.y, mt, 0.04f * (1.0f - mt)), fmaf(base.z, mt, 0.04f * (1.0f - mt)));
-  float a = m->roughness * m->roughness;
+  float a = roughness * roughness;
   b.alpha = fmax2(a, ORA_ALPHA_MIN);
   return b;
 }
@@ -915,28 +975,97 @@ typedef struct {
   uint64_t segments, shadow_rays, hits; trav_count closest, any;
 } path_count;
 
-typedef struct { v3 p, ng, ns; int front; const material_t* mat; } surf_t;
+typedef struct { v3 p, ng, ns; int front; const material_t* mat; float base[4]; float metallic, roughness; int lambert; } surf_t;
 
-static inline surf_t reconstruct(const ora_ctx* c, v3 d, const hit_t* h) {
+/* R7 sampler: the reference creates samplers with default create-info (gltf/Asset.cpp:116-117): NEAREST, REPEAT, no mips.
+ * RGBA8 UNORM texel → float /255 (image/pbr/image/LoadImage.cpp:27). */
+static inline void tex_fetch(const tex_t* t, float u, float v, float out[4]) {
+  float fu = u - floorf(u), fv = v - floorf(v);
+  int x = (int)(fu * (float)t->w), y = (int)(fv * (float)t->h);
+  if (x > t->w - 1) x = t->w - 1;
+  if (y > t->h - 1) y = t->h - 1;
+  const uint8_t* p = &t->px[((size_t)y * t->w + x) * 4];
+  for (int k = 0; k < 4; ++k) out[k] = (float)p[k] / 255.0f;
+}
+
+#define LERP3(fa, fb, fc, k) fmaf((fc)[k], v, fmaf((fb)[k], u, (fa)[k] * w))
+
+/* interpolated surface attributes at a hit; textures (base colour, normal map, metallic-roughness) applied */
+static inline surf_t reconstruct(const ora_ctx* c, v3 d, const hit_t* h, int two_sided_fixup) {
   surf_t s; uint32_t p = (uint32_t)h->prim;
-  const vert48* a = &c->wv[c->widx[p * 3 + 0]]; const vert48* b = &c->wv[c->widx[p * 3 + 1]]; const vert48* e = &c->wv[c->widx[p * 3 + 2]];
+  uint32_t i0 = c->widx[p * 3 + 0], i1 = c->widx[p * 3 + 1], i2 = c->widx[p * 3 + 2];
+  const vert48* a = &c->wv[i0]; const vert48* b = &c->wv[i1]; const vert48* e = &c->wv[i2];
   float u = h->u, v = h->v, w = 1.0f - u - v;
-  s.p = V3(fmaf(e->position[0], v, fmaf(b->position[0], u, a->position[0] * w)),
-           fmaf(e->position[1], v, fmaf(b->position[1], u, a->position[1] * w)),
-           fmaf(e->position[2], v, fmaf(b->position[2], u, a->position[2] * w)));
+  s.p = V3(LERP3(a->position, b->position, e->position, 0), LERP3(a->position, b->position, e->position, 1), LERP3(a->position, b->position, e->position, 2));
   v3 e1 = V3(b->position[0] - a->position[0], b->position[1] - a->position[1], b->position[2] - a->position[2]);
   v3 e2 = V3(e->position[0] - a->position[0], e->position[1] - a->position[1], e->position[2] - a->position[2]);
   s.ng = normalize3(cross3(e1, e2));
-  s.ns = normalize3(V3(fmaf(e->normal[0], v, fmaf(b->normal[0], u, a->normal[0] * w)),
-                       fmaf(e->normal[1], v, fmaf(b->normal[1], u, a->normal[1] * w)),
-                       fmaf(e->normal[2], v, fmaf(b->normal[2], u, a->normal[2] * w))));
+  v3 ni = V3(LERP3(a->normal, b->normal, e->normal, 0), LERP3(a->normal, b->normal, e->normal, 1), LERP3(a->normal, b->normal, e->normal, 2));
+  const material_t* m = &c->mats[c->tri_mat[p]];
+  s.mat = m;
+  memcpy(s.base, m->base, 16); s.metallic = m->metallic; s.roughness = m->roughness;
+  s.lambert = (m->metallic == 0.0f && m->roughness >= 1.0f && m->tex_mr < 0);
+  s.ns = normalize3(ni);
+  if (m->tex_color >= 0 || m->tex_normal >= 0 || m->tex_mr >= 0) {
+    float tu = LERP3(a->texcoord, b->texcoord, e->texcoord, 0), tv = LERP3(a->texcoord, b->texcoord, e->texcoord, 1);
+    float t4[4];
+    if (m->tex_color >= 0) { tex_fetch(&c->texs[m->tex_color], tu, tv, t4); for (int k = 0; k < 4; ++k) s.base[k] = m->base[k] * t4[k]; }   /* fragment.glsl:30 */
+    if (m->tex_mr >= 0) { tex_fetch(&c->texs[m->tex_mr], tu, tv, t4); s.roughness = m->roughness * t4[1]; s.metallic = m->metallic * t4[2]; }   /* glTF: G = roughness, B = metallic */
+    if (m->tex_normal >= 0) {                                                                                       /* fragment.glsl:24-27 */
+      tex_fetch(&c->texs[m->tex_normal], tu, tv, t4);
+      float nx = 2.0f * t4[0] - 1.0f, ny = 2.0f * t4[1] - 1.0f, nz = 2.0f * t4[2] - 1.0f;
+      v3 ti = V3(LERP3(a->tangent, b->tangent, e->tangent, 0), LERP3(a->tangent, b->tangent, e->tangent, 1), LERP3(a->tangent, b->tangent, e->tangent, 2));
+      const float* ba = &c->wbt[(size_t)i0 * 3]; const float* bb = &c->wbt[(size_t)i1 * 3]; const float* be = &c->wbt[(size_t)i2 * 3];
+      v3 bi = V3(LERP3(ba, bb, be, 0), LERP3(ba, bb, be, 1), LERP3(ba, bb, be, 2));
+      s.ns = normalize3(vfma(ti, nx, vfma(bi, ny, vscale(ni, nz))));
+    }
+  }
   v3 wo = vneg(d);
   s.front = dot3(s.ng, wo) > 0.0f;
-  if (dot3(s.ns, s.ng) < 0.0f) s.ns = vneg(s.ns);
-  if (!s.front) { s.ng = vneg(s.ng); s.ns = vneg(s.ns); }
-  if (!(dot3(s.ns, wo) > 0.0f)) s.ns = s.ng;
-  s.mat = &c->mats[c->tri_mat[p]];
+  if (two_sided_fixup) {
+    if (dot3(s.ns, s.ng) < 0.0f) s.ns = vneg(s.ns);
+    if (!s.front) { s.ng = vneg(s.ng); s.ns = vneg(s.ns); }
+    if (!(dot3(s.ns, wo) > 0.0f)) s.ns = s.ng;
+  }
   return s;
+}
+
+/* environment radiance, texel pmf and solid-angle pdf for a unit direction */
+static inline void env_lookup(const ora_ctx* c, v3 d, v3* Le, float* pdf) {
+  float u = pt_atan2(d.z, d.x) * (0.5f * ORA_INV_PI) + 0.5f;
+  float dy = fmin2(fmax2(d.y, -1.0f), 1.0f);
+  float st = sqrtf(fmax2(0.0f, 1.0f - dy * dy));
+  float vv = pt_atan2(st, dy) * ORA_INV_PI;
+  int x = (int)(u * (float)c->env_w), y = (int)(vv * (float)c->env_h);
+  if (x > c->env_w - 1) x = c->env_w - 1;
+  if (x < 0) x = 0;
+  if (y > c->env_h - 1) y = c->env_h - 1;
+  if (y < 0) y = 0;
+  const float* t = &c->env_px[((size_t)y * c->env_w + x) * 3];
+  *Le = V3(t[0], t[1], t[2]);
+  *pdf = c->env_ok ? (c->env_pmf[(size_t)y * c->env_w + x] * (float)c->env_w * (float)c->env_h) / (2.0f * ORA_PI * ORA_PI * fmax2(st, 1e-6f)) : 0.0f;
+}
+static inline uint32_t cdf_search(const float* cdf, uint32_t n, float r) {
+  uint32_t lo = 0, hi = n - 1;
+  while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (cdf[mid] > r) hi = mid; else lo = mid + 1; }
+  return lo;
+}
+/* importance-sample a direction from the environment: row by the marginal cdf, column by the row's conditional cdf,
+ * uniform inside the texel (the leftover of each random number) */
+static inline v3 env_sample(const ora_ctx* c, float r1, float r2) {
+  uint32_t y = cdf_search(c->env_marg, (uint32_t)c->env_h, r1);
+  float m0 = y ? c->env_marg[y - 1] : 0.0f, m1 = c->env_marg[y];
+  float xi_v = m1 > m0 ? (r1 - m0) / (m1 - m0) : 0.5f;
+  const float* cc = &c->env_cond[(size_t)y * c->env_w];
+  uint32_t x = cdf_search(cc, (uint32_t)c->env_w, r2);
+  float c0 = x ? cc[x - 1] : 0.0f, c1 = cc[x];
+  float xi_u = c1 > c0 ? (r2 - c0) / (c1 - c0) : 0.5f;
+  xi_u = fmin2(fmax2(xi_u, 0.0f), 0.999999f); xi_v = fmin2(fmax2(xi_v, 0.0f), 0.999999f);
+  float u = ((float)x + xi_u) / (float)c->env_w, vv = ((float)y + xi_v) / (float)c->env_h;
+  float s2, c2, st, ct;
+  sincos2pi(u, &s2, &c2);                 /* phi = 2 pi u - pi  →  cos phi = -cos(2 pi u), sin phi = -sin(2 pi u) */
+  sincos2pi(0.5f * vv, &st, &ct);         /* theta = pi v */
+  return V3(st * -c2, ct, st * -s2);
 }
 
 static v3 trace_path(const ora_ctx* c, const camera_t* cam, int w, int h, uint32_t px, uint32_t py, uint32_t sample,
@@ -949,38 +1078,66 @@ static v3 trace_path(const ora_ctx* c, const camera_t* cam, int w, int h, uint32
   v3 d = normalize3(vfma(cam->s, dvx, vfma(cam->u, dvy, cam->f)));
   v3 T = V3(1.0f, 1.0f, 1.0f), L = V3(0.0f, 0.0f, 0.0f);
   float prev_pdf = 0.0f;
+  /* light-kind selection probabilities for NEE: environment vs emissive triangles */
+  const int has_env = c->env_px && c->env_ok;
+  const float p_env = has_env ? (c->n_lights > 0 ? 0.5f : 1.0f) : 0.0f, p_area = 1.0f - p_env;
   for (int b = 0;; ++b) {
     pc->segments++;
     hit_t hit = trace_closest(c, o, d, 0.0f, ORA_T_INF, 0, &pc->closest);
-    if (hit.prim < 0) break;                                  /* background radiance = 0 */
+    if (hit.prim < 0) {                                       /* miss: environment radiance (0 without one), MIS vs env NEE */
+      if (c->env_px) {
+        v3 Le; float pe; env_lookup(c, d, &Le, &pe);
+        float wgt = 1.0f;
+        if (b > 0) { float pl = pe * p_env; float pb2 = prev_pdf * prev_pdf; wgt = pb2 / fmaf(pl, pl, pb2); }
+        L = V3(fmaf(T.x * Le.x, wgt, L.x), fmaf(T.y * Le.y, wgt, L.y), fmaf(T.z * Le.z, wgt, L.z));
+      }
+      break;
+    }
     pc->hits++;
-    surf_t s = reconstruct(c, d, &hit);
+    surf_t s = reconstruct(c, d, &hit, 1);
     v3 wo = vneg(d);
-    const material_t* m = s.mat;
     int li = c->prim_light[hit.prim];
     if (li >= 0 && s.front) {                                 /* emission, one-sided, MIS vs NEE */
       const light_t* lt = &c->lights[li];
       float wgt = 1.0f;
       if (b > 0) {
         float cosl = dot3(s.ng, wo);
-        float pl = (lt->pmf * (hit.t * hit.t)) / (lt->area * cosl);
+        float pl = ((lt->pmf * (hit.t * hit.t)) / (lt->area * cosl)) * p_area;
         float pb2 = prev_pdf * prev_pdf;
         wgt = pb2 / fmaf(pl, pl, pb2);
       }
       L = V3(fmaf(T.x * lt->Le.x, wgt, L.x), fmaf(T.y * lt->Le.y, wgt, L.y), fmaf(T.z * lt->Le.z, wgt, L.z));
     }
     if (b >= max_bounces) break;
-    bsdf_t bs = make_bsdf(m);
+    bsdf_t bs = make_bsdf(V3(s.base[0], s.base[1], s.base[2]), s.metallic, s.roughness, s.lambert);
     v3 tx, ty; onb(s.ns, &tx, &ty);
     v3 wol = V3(dot3(tx, wo), dot3(ty, wo), dot3(s.ns, wo));
     float ps = spec_prob(&bs, fmax2(wol.z, 1e-4f));
     v3 porg = vfma(s.ng, c->ray_eps, s.p);
     uint32_t rb = (uint32_t)b + 1u;
-    /* P7 next-event estimation */
-    if (c->n_lights > 0) {
+    /* P7 next-event estimation: one light sample per bounce, environment or emissive triangle */
+    int use_env = 0;
+    if (has_env) use_env = c->n_lights == 0 || rng_f(key, rb, 7) < p_env;
+    if (use_env) {
+      float r1 = rng_f(key, rb, 1), r2 = rng_f(key, rb, 2);
+      v3 wi = env_sample(c, r1, r2);
+      v3 wil = V3(dot3(tx, wi), dot3(ty, wi), dot3(s.ns, wi));
+      if (wil.z > 0.0f && dot3(s.ng, wi) > 0.0f) {
+        v3 Le; float pe; env_lookup(c, wi, &Le, &pe);
+        float pl = pe * p_env;
+        if (pl > 0.0f) {
+          v3 f; float pb; bsdf_eval(&bs, wol, wil, ps, &f, &pb);
+          float pl2 = pl * pl;
+          float wgt = pl2 / fmaf(pb, pb, pl2);
+          float k = (wil.z * wgt) / pl;
+          v3 contrib = V3(T.x * f.x * Le.x * k, T.y * f.y * Le.y * k, T.z * f.z * Le.z * k);
+          pc->shadow_rays++;
+          if (!trace_any(c, porg, wi, 0.0f, ORA_T_INF, &pc->any)) L = vadd(L, contrib);
+        }
+      }
+    } else if (c->n_lights > 0) {
       float u0 = rng_f(key, rb, 0), r1 = rng_f(key, rb, 1), r2 = rng_f(key, rb, 2);
-      uint32_t lo = 0, hi = c->n_lights - 1;
-      while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (c->cdf[mid] > u0) hi = mid; else lo = mid + 1; }
+      uint32_t lo = cdf_search(c->cdf, c->n_lights, u0);
       const light_t* lt = &c->lights[lo];
       float su = sqrtf(r1); float bu = su * (1.0f - r2), bv = su * r2;
       v3 y = vfma(lt->e2, bv, vfma(lt->e1, bu, lt->v0));
@@ -992,7 +1149,7 @@ static v3 trace_path(const ora_ctx* c, const camera_t* cam, int w, int h, uint32
         float cosl = -dot3(lt->ng, wi);
         v3 wil = V3(dot3(tx, wi), dot3(ty, wi), dot3(s.ns, wi));
         if (cosl > 0.0f && wil.z > 0.0f && dot3(s.ng, wi) > 0.0f) {
-          float pl = (lt->pmf * dist2) / (lt->area * cosl);
+          float pl = ((lt->pmf * dist2) / (lt->area * cosl)) * p_area;
           v3 f; float pb; bsdf_eval(&bs, wol, wil, ps, &f, &pb);
           float pl2 = pl * pl;
           float wgt = pl2 / fmaf(pb, pb, pl2);
@@ -1041,22 +1198,15 @@ static void raster_compat_pixel(const ora_ctx* c, const camera_t* cam, int w, in
   out[0] = out[1] = out[2] = out[3] = 0.0f;                  /* G-buffer clear → colour 0 */
   if (hit.prim < 0) return;
   pc->hits++;
-  uint32_t p = (uint32_t)hit.prim;
-  const vert48* a = &c->wv[c->widx[p * 3 + 0]]; const vert48* b = &c->wv[c->widx[p * 3 + 1]]; const vert48* e = &c->wv[c->widx[p * 3 + 2]];
-  float u = hit.u, v = hit.v, ww = 1.0f - u - v;
-  v3 P = V3(fmaf(e->position[0], v, fmaf(b->position[0], u, a->position[0] * ww)),
-            fmaf(e->position[1], v, fmaf(b->position[1], u, a->position[1] * ww)),
-            fmaf(e->position[2], v, fmaf(b->position[2], u, a->position[2] * ww)));
-  /* fragment.glsl:24-27 with the default flat normal texel (0.5,0.5,1): TBN·(0,0,1) = N */
-  v3 N = normalize3(V3(fmaf(e->normal[0], v, fmaf(b->normal[0], u, a->normal[0] * ww)),
-                       fmaf(e->normal[1], v, fmaf(b->normal[1], u, a->normal[1] * ww)),
-                       fmaf(e->normal[2], v, fmaf(b->normal[2], u, a->normal[2] * ww))));
-  const material_t* m = &c->mats[c->tri_mat[p]];
+  /* fragment.glsl:19-31: N = normalize(TBN * (texel*2-1)) (flat texel (0.5,0.5,1) without a normal map: N = normalize(interpolated
+   * normal)), albedo = color * texel */
+  surf_t sf = reconstruct(c, d, &hit, 0);
+  v3 P = sf.p, N = sf.ns;
   v3 V = normalize3(vsub(cam->pos, P));                      /* lighting.glsl:25 */
   v3 H = normalize3(vadd(V, V));                             /* L = V; BlinnPhong.lib.glsl:6 */
   float ndv = fmax2(dot3(N, V), 0.0f), ndh = fmax2(dot3(N, H), 0.0f);
   float s2 = ndh * ndh, s4 = s2 * s2, s8 = s4 * s4, s16 = s8 * s8, s32 = s16 * s16, spec = s32 * s32; /* pow(.,64) */
-  for (int k = 0; k < 4; ++k) out[k] = fmaf(m->base[k], ndv, spec);
+  for (int k = 0; k < 4; ++k) out[k] = fmaf(sf.base[k], ndv, spec);
 }
 
 typedef struct {

@@ -39,6 +39,7 @@ int ora_add_mesh(ora_ctx*, const void* verts48, uint32_t n_verts, const uint32_t
 int ora_add_instance(ora_ctx*, int mesh, const float t[3], const float q_wxyz[4], const float s[3]);
 int ora_add_instance_matrix(ora_ctx*, int mesh, const float model16[16]);
 int ora_set_camera(ora_ctx*, const float pos[3], const float target[3], float fov_y, float aspect);
+int ora_set_env_latlong_rgb32f(ora_ctx*, const float* rgb, int w, int h);   /* NULL clears */
 int ora_scene_commit(ora_ctx*);
 
 /* Renders into out_rgba (w*h*4 floats, y-down).  Pixels not owned by (tile_rank, tile_count)
@@ -67,6 +68,7 @@ void ora_make_camera(const float pos[3], const float target[3], float fov_y, flo
 void ora_tonemap_rgba8(const float* rgba, uint32_t n_pixels, uint8_t* out_rgba8);
 void ora_sincos2pi(float u, float* s, float* c);
 float ora_powf(float x, float y);
+float ora_atan2f(float y, float x);
 uint32_t ora_rng_u32(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t dim);
 /* tile ownership: owner rank of pixel (x,y) for a w×h frame split over tile_count ranks */
 int ora_tile_owner(int w, int h, int x, int y, int tile_count);

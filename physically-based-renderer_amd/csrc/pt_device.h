@@ -103,13 +103,27 @@ PT_DEV float pt_pow(float x, float y) {
   return pt_exp2(y * pt_log2(x));
 }
 
+// ---- atan2(y, x) in (-pi, pi]: octant reduction + odd minimax polynomial on [0,1] (max error ~1e-5 rad) --------
+PT_DEV float pt_atan2(float y, float x) {
+  const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+  const float mx = fmax2(ax, ay), mn = fmin2(ax, ay);
+  if (!(mx > 0.0f)) return 0.0f;
+  const float a = mn / mx, a2 = a * a;
+  const float p = pt_fma(a2, pt_fma(a2, pt_fma(a2, pt_fma(a2, pt_fma(a2, -0.01172120f, 0.05265332f), -0.11643287f), 0.19354346f), -0.33262347f), 0.99997726f);
+  float r = a * p;
+  if (ay > ax) r = PT_HALF_PI - r;
+  if (x < 0.0f) r = PT_PI - r;
+  if (y < 0.0f) r = -r;
+  return r;
+}
+
 // ---- P6: BSDF in the local frame of the shading normal (z = n) ---------------------------------
 struct bsdf_t { v3 cd, f0; float alpha; int ggx; };
 
-PT_DEV bsdf_t make_bsdf(v3 base, float metallic, float roughness) {
+PT_DEV bsdf_t make_bsdf(v3 base, float metallic, float roughness, bool lambert_class) {
   bsdf_t b;
   float mt = metallic;
-  b.ggx = !(mt == 0.0f && roughness >= 1.0f);
+  b.ggx = !lambert_class;
   b.cd = base * (1.0f - mt);
   float d = 0.04f * (1.0f - mt);
   b.f0 = V3(pt_fma(base.x, mt, d), pt_fma(base.y, mt, d), pt_fma(base.z, mt, d));

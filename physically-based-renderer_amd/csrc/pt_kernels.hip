@@ -452,6 +452,77 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_any(DevS
 }
 
 // =================================================================================================
+// R7 sampler: NEAREST, REPEAT, no mips (the reference creates its samplers with default create-info, gltf/Asset.cpp:116-117);
+// RGBA8 UNORM texel → float / 255.
+PT_DEV float4 tex_fetch(const DevScene& sc, int tex, float u, float v) {
+  const int4 ti = sc.tex_info[tex];
+  const float fu = u - __builtin_floorf(u), fv = v - __builtin_floorf(v);
+  int x = (int)(fu * (float)ti.y), y = (int)(fv * (float)ti.z);
+  if (x > ti.y - 1) x = ti.y - 1;
+  if (y > ti.z - 1) y = ti.z - 1;
+  const uint32_t p = sc.texels[(size_t)ti.x + (size_t)y * (size_t)ti.y + (size_t)x];
+  return make_float4((float)(p & 255u) / 255.0f, (float)((p >> 8) & 255u) / 255.0f, (float)((p >> 16) & 255u) / 255.0f, (float)(p >> 24) / 255.0f);
+}
+
+// Textured surface attributes of primitive `prim` at barycentrics (hu, hv): base colour × texel, metallic-roughness texel
+// (glTF: G = roughness, B = metallic), tangent-space normal map through the interpolated TBN (fragment.glsl:24-30).
+// ni = interpolated (un-normalised) vertex normal.  Updates base/metallic/roughness/ns in place.
+PT_DEV void apply_textures(const DevScene& sc, uint32_t prim, float hu, float hv, float hw, float4 M2, v3 ni, float base[4], float& metallic, float& roughness, v3& ns) {
+  const int tex_color = __float_as_int(M2.y), tex_normal = __float_as_int(M2.z), tex_mr = __float_as_int(M2.w);
+  const float4* tr = sc.shade_tex + (size_t)prim * 6;
+  const float4 t0 = tr[0], t1 = tr[1];
+  const float tu = pt_fma(t1.x, hv, pt_fma(t0.z, hu, t0.x * hw)), tv = pt_fma(t1.y, hv, pt_fma(t0.w, hu, t0.y * hw));
+  if (tex_color >= 0) { const float4 c = tex_fetch(sc, tex_color, tu, tv); base[0] = base[0] * c.x; base[1] = base[1] * c.y; base[2] = base[2] * c.z; base[3] = base[3] * c.w; }
+  if (tex_mr >= 0) { const float4 c = tex_fetch(sc, tex_mr, tu, tv); roughness = roughness * c.y; metallic = metallic * c.z; }
+  if (tex_normal >= 0) {
+    const float4 c = tex_fetch(sc, tex_normal, tu, tv);
+    const float nx = 2.0f * c.x - 1.0f, ny = 2.0f * c.y - 1.0f, nz = 2.0f * c.z - 1.0f;
+    const float4 t2 = tr[2], t3 = tr[3], t4 = tr[4], t5 = tr[5];
+    // tangents: a = (t1.z, t1.w, t2.x) b = (t2.y, t2.z, t2.w) c = (t3.x, t3.y, t3.z); bitangents: a = (t3.w, t4.x, t4.y) b = (t4.z, t4.w, t5.x) c = (t5.y, t5.z, t5.w)
+    const v3 ti = V3(pt_fma(t3.x, hv, pt_fma(t2.y, hu, t1.z * hw)), pt_fma(t3.y, hv, pt_fma(t2.z, hu, t1.w * hw)), pt_fma(t3.z, hv, pt_fma(t2.w, hu, t2.x * hw)));
+    const v3 bi = V3(pt_fma(t5.y, hv, pt_fma(t4.z, hu, t3.w * hw)), pt_fma(t5.z, hv, pt_fma(t4.w, hu, t4.x * hw)), pt_fma(t5.w, hv, pt_fma(t5.x, hu, t4.y * hw)));
+    ns = normalize3(vfma(ti, nx, vfma(bi, ny, ni * nz)));
+  }
+}
+
+// Lat-long environment: radiance and solid-angle pdf of a unit direction (piecewise-constant texels).
+PT_DEV void env_lookup(const DevScene& sc, v3 d, v3& Le, float& pdf) {
+  const float u = pt_atan2(d.z, d.x) * (0.5f * PT_INV_PI) + 0.5f;
+  const float dy = fmin2(fmax2(d.y, -1.0f), 1.0f);
+  const float st = pt_sqrt(fmax2(0.0f, 1.0f - dy * dy));
+  const float vv = pt_atan2(st, dy) * PT_INV_PI;
+  int x = (int)(u * (float)sc.env_w), y = (int)(vv * (float)sc.env_h);
+  if (x > sc.env_w - 1) x = sc.env_w - 1;
+  if (x < 0) x = 0;
+  if (y > sc.env_h - 1) y = sc.env_h - 1;
+  if (y < 0) y = 0;
+  const float4 t = sc.env[(size_t)y * (size_t)sc.env_w + (size_t)x];
+  Le = V3(t.x, t.y, t.z);
+  pdf = sc.env_ok ? (t.w * (float)sc.env_w * (float)sc.env_h) / (2.0f * PT_PI * PT_PI * fmax2(st, 1e-6f)) : 0.0f;
+}
+PT_DEV uint32_t cdf_search(const float* cdf, uint32_t n, float r) {
+  uint32_t lo = 0, hi = n - 1u;
+  while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cdf[mid] > r) hi = mid; else lo = mid + 1u; }
+  return lo;
+}
+// Importance-sample the environment: row by the marginal cdf, column by the row's conditional cdf, uniform inside the texel.
+PT_DEV v3 env_sample(const DevScene& sc, float r1, float r2) {
+  const uint32_t y = cdf_search(sc.env_marg, (uint32_t)sc.env_h, r1);
+  const float m0 = y ? sc.env_marg[y - 1u] : 0.0f, m1 = sc.env_marg[y];
+  float xi_v = m1 > m0 ? (r1 - m0) / (m1 - m0) : 0.5f;
+  const float* cc = sc.env_cond + (size_t)y * (size_t)sc.env_w;
+  const uint32_t x = cdf_search(cc, (uint32_t)sc.env_w, r2);
+  const float c0 = x ? cc[x - 1u] : 0.0f, c1 = cc[x];
+  float xi_u = c1 > c0 ? (r2 - c0) / (c1 - c0) : 0.5f;
+  xi_u = fmin2(fmax2(xi_u, 0.0f), 0.999999f); xi_v = fmin2(fmax2(xi_v, 0.0f), 0.999999f);
+  const float u = ((float)x + xi_u) / (float)sc.env_w, vv = ((float)y + xi_v) / (float)sc.env_h;
+  float s2, c2, st, ct;
+  sincos2pi(u, s2, c2);             // phi = 2 pi u - pi: cos phi = -cos(2 pi u), sin phi = -sin(2 pi u)
+  sincos2pi(0.5f * vv, st, ct);     // theta = pi v
+  return V3(st * -c2, ct, st * -s2);
+}
+
+// =================================================================================================
 // P9 + P5–P8 shading.
 // Front end (P9): a 512-thread block takes a window of 512 consecutive (ray, hit) slots and sorts the
 // surviving paths by material class through LDS — per-wave ballot + mbcnt prefix, per-block prefix over
@@ -468,7 +539,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DevScene sc, DevFrame fr,
   // small scenes-wide tables staged once per block: emitter records + power cdf, materials
   __shared__ float4 s_light[SHADE_LDS_LIGHTS * 5];
   __shared__ float s_cdf[SHADE_LDS_LIGHTS];
-  __shared__ float4 s_mat[SHADE_LDS_MATS * 2];
+  __shared__ float4 s_mat[SHADE_LDS_MATS * 3];
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
   const bool lds_lights = sc.n_lights <= SHADE_LDS_LIGHTS, lds_mats = sc.n_mats <= SHADE_LDS_MATS;
@@ -477,10 +548,14 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DevScene sc, DevFrame fr,
     for (uint32_t i = threadIdx.x; i < sc.n_lights; i += SHADE_BLOCK) s_cdf[i] = sc.cdf[i];
   }
   if (lds_mats)
-    for (uint32_t i = threadIdx.x; i < sc.n_mats * 2u; i += SHADE_BLOCK) s_mat[i] = sc.mats[(i >> 1) * 3u + (i & 1u)];
+    for (uint32_t i = threadIdx.x; i < sc.n_mats * 3u; i += SHADE_BLOCK) s_mat[i] = sc.mats[i];
   __syncthreads();
   const float4* lights = lds_lights ? s_light : sc.lights;
   const float* cdf = lds_lights ? s_cdf : sc.cdf;
+  const float4* mats = lds_mats ? s_mat : sc.mats;
+  // light-kind selection probabilities for NEE: environment vs emissive triangles
+  const bool has_env = sc.env_w > 0, env_nee = has_env && sc.env_ok != 0;
+  const float p_env = env_nee ? (sc.n_lights > 0u ? 0.5f : 1.0f) : 0.0f, p_area = 1.0f - p_env;
   const RayQ rin = q.ray[qi], rout = q.ray[qi ^ 1];
   const uint32_t n = q.cnt[CNT_RAYS];
   const uint32_t n_windows = (n + SHADE_BLOCK - 1u) / SHADE_BLOCK;
@@ -493,9 +568,10 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DevScene sc, DevFrame fr,
       if (i < n) {
         const int pc = __float_as_int(q.hit[i].y);
         if (pc >= 0) cls = (pc >> HIT_CLASS_SHIFT) & 1;
+        else if (has_env) cls = 2;                                       // a miss is shaded only when there is an environment
       }
     }
-    const uint64_t m0 = __ballot(cls == 0), m1 = __ballot(cls == 1);
+    const uint64_t m0 = __ballot(cls == 0), m1 = __ballot(cls >= 1);   // misses queue up behind the GGX group
     if (lane == 0) { s_cnt[0][wave] = (uint32_t)__popcll(m0); s_cnt[1][wave] = (uint32_t)__popcll(m1); }
     s_idx[threadIdx.x] = 0xffffu;
     __syncthreads();
@@ -508,7 +584,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DevScene sc, DevFrame fr,
     }
     const uint32_t start1 = (tot0 + 63u) & ~63u;                       // GGX group starts on a wave boundary
     if (cls == 0) s_idx[off0 + mbcnt64(m0)] = (uint16_t)threadIdx.x;
-    else if (cls == 1) {
+    else if (cls >= 1) {
       // the padding may push the tail of the GGX group past the block: those (< 64) items fold back into
       // the padding gap behind the Lambert group (only that one wave is then mixed)
       uint32_t p = start1 + off1 + mbcnt64(m1);
@@ -532,6 +608,14 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DevScene sc, DevFrame fr,
       const float prev_pdf = Cq.y;
       const uint32_t path = __float_as_uint(Cq.z), key = __float_as_uint(Cq.w);
       const float ht = H.x, hu = H.z, hv = H.w;
+      if (__float_as_int(H.y) < 0) {                                   // miss: environment radiance, MIS against env NEE
+        v3 Le; float pe; env_lookup(sc, d, Le, pe);
+        float wgt = 1.0f;
+        if (b > 0u) { const float pl = pe * p_env; const float pb2 = prev_pdf * prev_pdf; wgt = pb2 / pt_fma(pl, pl, pb2); }
+        float4 L = q.lpath[path];
+        L.x = pt_fma(T.x * Le.x, wgt, L.x); L.y = pt_fma(T.y * Le.y, wgt, L.y); L.z = pt_fma(T.z * Le.z, wgt, L.z);
+        q.lpath[path] = L;
+      } else {
       const uint32_t prim = (uint32_t)__float_as_int(H.y) & ((1u << HIT_CLASS_SHIFT) - 1u);
       // ---- P5 surface reconstruction from the primitive's shading record (five 16-byte loads) ----
       const float4* rec = sc.shade + (size_t)prim * 5;
@@ -541,14 +625,20 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DevScene sc, DevFrame fr,
       const float hw = 1.0f - hu - hv;
       const v3 P = V3(pt_fma(Pc.x, hv, pt_fma(Pb.x, hu, Pa.x * hw)), pt_fma(Pc.y, hv, pt_fma(Pb.y, hu, Pa.y * hw)), pt_fma(Pc.z, hv, pt_fma(Pb.z, hu, Pa.z * hw)));
       v3 ng = normalize3(cross3(Pb - Pa, Pc - Pa));
-      v3 ns = normalize3(V3(pt_fma(Nc.x, hv, pt_fma(Nb.x, hu, Na.x * hw)), pt_fma(Nc.y, hv, pt_fma(Nb.y, hu, Na.y * hw)), pt_fma(Nc.z, hv, pt_fma(Nb.z, hu, Na.z * hw))));
+      const v3 ni = V3(pt_fma(Nc.x, hv, pt_fma(Nb.x, hu, Na.x * hw)), pt_fma(Nc.y, hv, pt_fma(Nb.y, hu, Na.y * hw)), pt_fma(Nc.z, hv, pt_fma(Nb.z, hu, Na.z * hw)));
+      v3 ns = normalize3(ni);
+      const int mat = __float_as_int(r0.w);
+      const float4 M0 = mats[mat * 3 + 0], M1 = mats[mat * 3 + 1], M2 = mats[mat * 3 + 2];
+      float base[4] = {M0.x, M0.y, M0.z, M2.x};
+      float metallic = M0.w, roughness = M1.w;
+      const bool lambert = metallic == 0.0f && roughness >= 1.0f && __float_as_int(M2.w) < 0;
+      if (__float_as_int(M2.y) >= 0 || __float_as_int(M2.z) >= 0 || __float_as_int(M2.w) >= 0)
+        apply_textures(sc, prim, hu, hv, hw, M2, ni, base, metallic, roughness, ns);
       const v3 wo = -d;
       const bool front = dot3(ng, wo) > 0.0f;
       if (dot3(ns, ng) < 0.0f) ns = -ns;
       if (!front) { ng = -ng; ns = -ns; }
       if (!(dot3(ns, wo) > 0.0f)) ns = ng;
-      const int mat = __float_as_int(r0.w);
-      const float4 M0 = lds_mats ? s_mat[mat * 2 + 0] : sc.mats[mat * 3 + 0], M1 = lds_mats ? s_mat[mat * 2 + 1] : sc.mats[mat * 3 + 1];
       // ---- emission (one-sided), MIS against next-event estimation ----
       const int li = __float_as_int(r1.w);
       if (li >= 0 && front) {
@@ -556,7 +646,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DevScene sc, DevFrame fr,
         float wgt = 1.0f;
         if (b > 0u) {
           const float cosl = dot3(ng, wo);
-          const float pl = (l1.w * (ht * ht)) / (l0.w * cosl);
+          const float pl = ((l1.w * (ht * ht)) / (l0.w * cosl)) * p_area;
           const float pb2 = prev_pdf * prev_pdf;
           wgt = pb2 / pt_fma(pl, pl, pb2);
         }
@@ -565,17 +655,36 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DevScene sc, DevFrame fr,
         q.lpath[path] = L;
       }
       if ((int)b < fr.max_bounces) {
-        const bsdf_t bs = make_bsdf(V3(M0.x, M0.y, M0.z), M0.w, M1.w);
+        const bsdf_t bs = make_bsdf(V3(base[0], base[1], base[2]), metallic, roughness, lambert);
         v3 tx, ty; onb(ns, tx, ty);
         const v3 wol = V3(dot3(tx, wo), dot3(ty, wo), dot3(ns, wo));
         const float ps = spec_prob(bs, fmax2(wol.z, 1e-4f));
         const v3 porg = vfma(ng, sc.ray_eps, P);
         const uint32_t rb = b + 1u;
-        // ---- P7 next-event estimation ----
-        if (sc.n_lights > 0u) {
+        // ---- P7 next-event estimation: one light sample per bounce, environment or emissive triangle ----
+        bool use_env = false;
+        if (env_nee) use_env = sc.n_lights == 0u || rng_f(key, rb, 7) < p_env;
+        if (use_env) {
+          const float r1 = rng_f(key, rb, 1), r2 = rng_f(key, rb, 2);
+          const v3 wi = env_sample(sc, r1, r2);
+          const v3 wil = V3(dot3(tx, wi), dot3(ty, wi), dot3(ns, wi));
+          if (wil.z > 0.0f && dot3(ng, wi) > 0.0f) {
+            v3 Le; float pe; env_lookup(sc, wi, Le, pe);
+            const float pl = pe * p_env;
+            if (pl > 0.0f) {
+              v3 f; float pb; bsdf_eval(bs, wol, wil, ps, f, pb);
+              const float pl2 = pl * pl;
+              const float wgt = pl2 / pt_fma(pb, pb, pl2);
+              const float k = (wil.z * wgt) / pl;
+              has_shadow = true;
+              sA = make_float4(porg.x, porg.y, porg.z, wi.x);
+              sB = make_float4(wi.y, wi.z, PT_T_INF, __uint_as_float(path));
+              sC = make_float4(T.x * f.x * Le.x * k, T.y * f.y * Le.y * k, T.z * f.z * Le.z * k, 0.0f);
+            }
+          }
+        } else if (sc.n_lights > 0u) {
           const float u0 = rng_f(key, rb, 0), r1 = rng_f(key, rb, 1), r2 = rng_f(key, rb, 2);
-          uint32_t lo = 0, hi = sc.n_lights - 1u;
-          while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cdf[mid] > u0) hi = mid; else lo = mid + 1u; }
+          const uint32_t lo = cdf_search(cdf, sc.n_lights, u0);
           const float4 l0 = lights[lo * 5 + 0], l1 = lights[lo * 5 + 1], l2 = lights[lo * 5 + 2], l3 = lights[lo * 5 + 3], l4 = lights[lo * 5 + 4];
           const float su = pt_sqrt(r1);
           const float bu = su * (1.0f - r2), bv = su * r2;
@@ -588,7 +697,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DevScene sc, DevFrame fr,
             const float cosl = -dot3(V3(l3.x, l3.y, l3.z), wi);
             const v3 wil = V3(dot3(tx, wi), dot3(ty, wi), dot3(ns, wi));
             if (cosl > 0.0f && wil.z > 0.0f && dot3(ng, wi) > 0.0f) {
-              const float pl = (l1.w * dist2) / (l0.w * cosl);
+              const float pl = ((l1.w * dist2) / (l0.w * cosl)) * p_area;
               v3 f; float pb; bsdf_eval(bs, wol, wil, ps, f, pb);
               const float pl2 = pl * pl;
               const float wgt = pl2 / pt_fma(pb, pb, pl2);
@@ -635,6 +744,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DevScene sc, DevFrame fr,
           oD = rb;
         }
       }
+      }   // hit
     }
     // ---- back end: compaction, ballot + mbcnt prefix per wave, LDS prefix per block, one atomic per queue ----
     const uint64_t ms = __ballot(has_shadow), ma = __ballot(alive);
@@ -698,14 +808,19 @@ __global__ __launch_bounds__(256) void k_shade_raster(DevScene sc, DevCamera cam
     const float4* rec = sc.shade + (size_t)prim * 5;
     const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4];
     const v3 P = V3(pt_fma(r2.x, hv, pt_fma(r1.x, hu, r0.x * hw)), pt_fma(r2.y, hv, pt_fma(r1.y, hu, r0.y * hw)), pt_fma(r2.z, hv, pt_fma(r1.z, hu, r0.z * hw)));
-    const v3 N = normalize3(V3(pt_fma(r4.y, hv, pt_fma(r3.z, hu, r2.w * hw)), pt_fma(r4.z, hv, pt_fma(r3.w, hu, r3.x * hw)), pt_fma(r4.w, hv, pt_fma(r4.x, hu, r3.y * hw))));
+    const v3 ni = V3(pt_fma(r4.y, hv, pt_fma(r3.z, hu, r2.w * hw)), pt_fma(r4.z, hv, pt_fma(r3.w, hu, r3.x * hw)), pt_fma(r4.w, hv, pt_fma(r4.x, hu, r3.y * hw)));
+    v3 N = normalize3(ni);
     const int mat = __float_as_int(r0.w);
-    const float4 M0 = sc.mats[mat * 3 + 0], M2 = sc.mats[mat * 3 + 2];
+    const float4 M0 = sc.mats[mat * 3 + 0], M1 = sc.mats[mat * 3 + 1], M2 = sc.mats[mat * 3 + 2];
+    float base[4] = {M0.x, M0.y, M0.z, M2.x};
+    float metallic = M0.w, roughness = M1.w;
+    if (__float_as_int(M2.y) >= 0 || __float_as_int(M2.z) >= 0 || __float_as_int(M2.w) >= 0)
+      apply_textures(sc, (uint32_t)prim, hu, hv, hw, M2, ni, base, metallic, roughness, N);
     const v3 V = normalize3(V3(cam.pos[0], cam.pos[1], cam.pos[2]) - P);
     const v3 Hh = normalize3(V + V);
     const float ndv = fmax2(dot3(N, V), 0.0f), ndh = fmax2(dot3(N, Hh), 0.0f);
     const float s2 = ndh * ndh, s4 = s2 * s2, s8 = s4 * s4, s16 = s8 * s8, s32 = s16 * s16, spec = s32 * s32;
-    o = make_float4(pt_fma(M0.x, ndv, spec), pt_fma(M0.y, ndv, spec), pt_fma(M0.z, ndv, spec), pt_fma(M2.x, ndv, spec));
+    o = make_float4(pt_fma(base[0], ndv, spec), pt_fma(base[1], ndv, spec), pt_fma(base[2], ndv, spec), pt_fma(base[3], ndv, spec));
   }
   accum[j] = o;
 }

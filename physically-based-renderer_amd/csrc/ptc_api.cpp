@@ -39,7 +39,8 @@ struct ptc_ctx {
   std::vector<HostMaterial> mats;
   std::vector<HostMesh> meshes;
   std::vector<HostInstance> insts;
-  std::vector<std::vector<uint8_t>> texs;
+  std::vector<HostTexture> texs;
+  HostEnv env;
   float cam_pos[3]{}, cam_target[3]{}, cam_fov = 0, cam_aspect = 1;
   bool have_cam = false;
   // committed scene
@@ -212,7 +213,7 @@ int run_batch(ptc_ctx* c, int l, uint32_t first_sample, uint32_t n_samples) {
     for (int b = 0; b <= c->fr.max_bounces; ++b) {
       { ScopedSpan t(c, st, 0); pt_launch_trace_closest(st, c->cfg, sc, q, b & 1, false); c->stats.launches_trace_closest++; }
       { ScopedSpan t(c, st, 2); pt_launch_shade(st, c->cfg, sc, c->fr, q, b & 1); }
-      if (b < c->fr.max_bounces && sc.n_lights > 0) {
+      if (b < c->fr.max_bounces && (sc.n_lights > 0 || sc.env_ok)) {
         ScopedSpan t(c, st, 1); pt_launch_trace_any(st, c->cfg, sc, q, nullptr); c->stats.launches_trace_any++;
       }
       pt_launch_advance(st, q);
@@ -316,7 +317,7 @@ int ptc_scene_begin(ptc_ctx* c) {
     HIP_TRY(c, hipSetDevice(c->device));
     { int rs = sync_all_lanes(c); if (rs) return rs; }
   }
-  c->mats.clear(); c->meshes.clear(); c->insts.clear(); c->texs.clear();
+  c->mats.clear(); c->meshes.clear(); c->insts.clear(); c->texs.clear(); c->env = HostEnv{};
   c->have_cam = false; c->committed = false; c->in_frame = false;
   free_all(c->scene_allocs);
   return PTC_OK;
@@ -328,7 +329,6 @@ int ptc_add_material(ptc_ctx* c, const float base_color[4], float metallic, floa
   if (!base_color || !emissive) return fail(c, PTC_E_ARG, "add_material: null pointer");
   const int nt = (int)c->texs.size();
   if (tex_color >= nt || tex_normal >= nt || tex_mr >= nt) return fail(c, PTC_E_ARG, "add_material: texture id out of range");
-  if (tex_color >= 0 || tex_normal >= 0 || tex_mr >= 0) return fail(c, PTC_E_ARG, "add_material: textures are not implemented in this round");
   HostMaterial m;
   std::memcpy(m.base, base_color, 16); m.metallic = metallic; m.roughness = roughness; std::memcpy(m.emissive, emissive, 12);
   m.tex_color = tex_color; m.tex_normal = tex_normal; m.tex_mr = tex_mr;
@@ -339,7 +339,9 @@ int ptc_add_material(ptc_ctx* c, const float base_color[4], float metallic, floa
 int ptc_add_texture_rgba8(ptc_ctx* c, const uint8_t* px, int w, int h) {
   if (!c) return PTC_E_ARG;
   if (!px || w <= 0 || h <= 0) return fail(c, PTC_E_ARG, "add_texture: bad argument");
-  c->texs.emplace_back(px, px + (size_t)w * h * 4);
+  HostTexture t;
+  t.px.assign(px, px + (size_t)w * h * 4); t.w = w; t.h = h;
+  c->texs.push_back(std::move(t));
   return (int)c->texs.size() - 1;
 }
 
@@ -389,12 +391,20 @@ int ptc_set_camera(ptc_ctx* c, const float pos[3], const float target[3], float 
   return PTC_OK;
 }
 
+int ptc_set_env_latlong_rgb32f(ptc_ctx* c, const float* rgb, int w, int h) {
+  if (!c) return PTC_E_ARG;
+  if (!rgb) { c->env = HostEnv{}; return PTC_OK; }
+  if (w <= 0 || h <= 0 || (uint64_t)w * (uint64_t)h > (1u << 28)) return fail(c, PTC_E_ARG, "set_env: bad size");
+  c->env.rgb.assign(rgb, rgb + (size_t)w * h * 3); c->env.w = w; c->env.h = h;
+  return PTC_OK;
+}
+
 int ptc_scene_commit(ptc_ctx* c) {
   if (!c) return PTC_E_ARG;
   if (!c->have_cam) return fail(c, PTC_E_STATE, "scene_commit: no camera");
   if (c->device >= 0) HIP_TRY(c, hipSetDevice(c->device));
   const auto t0 = std::chrono::steady_clock::now();
-  const std::string e = ptc_build_scene(c->mats, c->meshes, c->insts, c->nodelet_budget, c->built);
+  const std::string e = ptc_build_scene(c->mats, c->meshes, c->insts, c->texs, c->env, c->nodelet_budget, c->built);
   if (!e.empty()) return fail(c, PTC_E_STATE, e);
   ptc_make_camera(c->cam_pos, c->cam_target, c->cam_fov, c->cam_aspect, c->cam);
   if (c->device < 0) {   // description-only context: nothing to upload
@@ -417,8 +427,15 @@ int ptc_scene_commit(ptc_ctx* c) {
     rc |= dev_upload(c, c->scene_allocs, &p, B.lights); d.lights = (const float4*)p;
     rc |= dev_upload(c, c->scene_allocs, &d.cdf, B.cdf);
     rc |= dev_upload(c, c->scene_allocs, &p, B.shade); d.shade = (const float4*)p;
+    rc |= dev_upload(c, c->scene_allocs, &p, B.shade_tex); d.shade_tex = (const float4*)p;
+    rc |= dev_upload(c, c->scene_allocs, &d.texels, B.texels);
+    { const int32_t* ti = nullptr; rc |= dev_upload(c, c->scene_allocs, &ti, B.tex_info); d.tex_info = (const int4*)ti; }
+    rc |= dev_upload(c, c->scene_allocs, &p, B.env); d.env = (const float4*)p;
+    rc |= dev_upload(c, c->scene_allocs, &d.env_marg, B.env_marg);
+    rc |= dev_upload(c, c->scene_allocs, &d.env_cond, B.env_cond);
   }
   if (rc) { free_all(c->scene_allocs); return PTC_E_DEVICE; }
+  d.env_w = B.env_w; d.env_h = B.env_h; d.env_ok = B.env_ok;
   d.n_lights = B.n_lights; d.n_mats = (uint32_t)c->mats.size(); d.n_nodelets = B.n_nodelets; d.ray_eps = B.ray_eps;
   c->dsc = d;
   { int rc2 = configure_launch(c); if (rc2) { free_all(c->scene_allocs); return rc2; } }

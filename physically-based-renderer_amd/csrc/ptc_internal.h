@@ -13,7 +13,14 @@ struct DevScene {
   const float4* tris;         // 3 × float4 per triangle record (48 B): (v0,prim) (e1,class) (e2,-), grouped by owning node
   const float4* shade;        // 5 × float4 per original primitive id (80 B): the three R1 vertex records de-indexed to what
                               // shading reads: (Pa,mat) (Pb,light) (Pc,Na.x) (Na.yz,Nb.xy) (Nb.z,Nc.xyz)
-  const float4* mats;         // 3 × float4 per material: (base.rgb, metallic) (emissive.rgb, roughness) (base.a,-,-,-)
+  const float4* mats;         // 3 × float4 per material: (base.rgb, metallic) (emissive.rgb, roughness) (base.a, tex_color, tex_normal, tex_mr)
+  const float4* shade_tex;    // 6 × float4 per primitive, only when a material has a texture: uv ×3, world tangent ×3, world bitangent ×3
+  const uint32_t* texels;     // all RGBA8 textures back to back
+  const int4* tex_info;       // per texture: (offset into texels, width, height, 0)
+  const float4* env;          // lat-long environment: (radiance.rgb, texel pmf) per texel, row 0 = +y
+  const float* env_marg;      // row cdf (env_h)
+  const float* env_cond;      // per-row column cdf (env_w × env_h)
+  int env_w, env_h, env_ok;   // env_ok: the map has non-zero power, i.e. it can be importance-sampled
   const float4* lights;       // 5 × float4 per emitter: (v0,area) (e1,pmf) (e2,-) (ng,-) (Le,-)
   const float* cdf;           // emitter power cdf
   uint32_t n_lights;
@@ -76,6 +83,8 @@ void pt_launch_tonemap(hipStream_t, const float4* radiance, uint32_t* rgba8, int
 // ---- host-side scene build (ptc_scene.cpp) ----------------------------------------------------------
 struct HostMaterial { float base[4]; float metallic, roughness; float emissive[3]; int tex_color, tex_normal, tex_mr; };
 struct HostVertex { float position[3], normal[3], tangent[4], texcoord[2]; };
+struct HostTexture { std::vector<uint8_t> px; int w, h; };
+struct HostEnv { std::vector<float> rgb; int w = 0, h = 0; };
 struct HostMesh { std::vector<HostVertex> v; std::vector<uint32_t> idx; int material; };
 struct HostInstance { int mesh; float m[16]; };   // column-major model matrix
 
@@ -85,6 +94,11 @@ struct HostBuilt {
   std::vector<int32_t> tri_mat;
   std::vector<int32_t> prim_light;
   std::vector<float> shade;      // 20 floats per primitive (see DevScene::shade)
+  std::vector<float> shade_tex;  // 24 floats per primitive, empty when no material is textured
+  std::vector<uint32_t> texels;  // RGBA8 texels of all textures
+  std::vector<int32_t> tex_info; // 4 ints per texture
+  std::vector<float> env, env_marg, env_cond;   // 4 floats per texel; cdfs
+  int env_w = 0, env_h = 0, env_ok = 0;
   std::vector<float> nodes;      // 12 words per 4-wide node
   std::vector<float> tris;       // 12 floats per triangle record (node order)
   std::vector<float> mats;       // 12 floats per material
@@ -96,7 +110,7 @@ struct HostBuilt {
 
 // returns empty string on success, else the error text
 std::string ptc_build_scene(const std::vector<HostMaterial>&, const std::vector<HostMesh>&, const std::vector<HostInstance>&,
-                            uint32_t nodelet_budget, HostBuilt& out);
+                            const std::vector<HostTexture>&, const HostEnv&, uint32_t nodelet_budget, HostBuilt& out);
 void ptc_trs_to_matrix(const float t[3], const float q_wxyz[4], const float s[3], float m16[16]);
 void ptc_make_camera(const float pos[3], const float target[3], float fov, float aspect, DevCamera& cam);
 // pixels owned by (rank,count) in tile-Morton order

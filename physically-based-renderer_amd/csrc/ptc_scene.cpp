@@ -184,13 +184,15 @@ void ptc_owned_pixels(int w, int h, int tile_rank, int tile_count, std::vector<u
 }
 
 std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::vector<HostMesh>& meshes,
-                            const std::vector<HostInstance>& insts, uint32_t nodelet_budget, HostBuilt& B) {
+                            const std::vector<HostInstance>& insts, const std::vector<HostTexture>& texs, const HostEnv& env,
+                            uint32_t nodelet_budget, HostBuilt& B) {
   if (insts.empty()) return "scene_commit: no instances";
   uint64_t nv = 0, nt = 0;
   for (const auto& in : insts) { nv += meshes[(size_t)in.mesh].v.size(); nt += meshes[(size_t)in.mesh].idx.size() / 3; }
   if (nt >= (1u << 28)) return "scene_commit: too many triangles";
   B = HostBuilt();
   B.wverts.resize(nv);
+  std::vector<float> wbt(nv * 3);   // world bitangent per vertex (vertex.glsl:35)
   B.widx.resize(nt * 3);
   B.tri_mat.resize(nt);
   // ---- flatten ----------------------------------------------------------------------------------
@@ -208,6 +210,14 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
       mul_n(M.n, s.tangent, d.tangent);
       fnormalize(d.tangent);
       d.tangent[3] = s.tangent[3];
+      {
+        float cr[3], sc3[3], bt[3];
+        fcross(s.normal, s.tangent, cr);
+        sc3[0] = cr[0] * s.tangent[3]; sc3[1] = cr[1] * s.tangent[3]; sc3[2] = cr[2] * s.tangent[3];
+        mul_n(M.n, sc3, bt);
+        fnormalize(bt);
+        wbt[(size_t)(vb + k) * 3 + 0] = bt[0]; wbt[(size_t)(vb + k) * 3 + 1] = bt[1]; wbt[(size_t)(vb + k) * 3 + 2] = bt[2];
+      }
       d.texcoord[0] = s.texcoord[0];
       d.texcoord[1] = s.texcoord[1];
     }
@@ -259,7 +269,7 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
     const float* b = B.wverts[B.widx[p * 3 + 1]].position;
     const float* c = B.wverts[B.widx[p * 3 + 2]].position;
     const HostMaterial& hm = mats[(size_t)B.tri_mat[p]];
-    const uint32_t cls = (hm.metallic == 0.0f && hm.roughness >= 1.0f) ? 0u : 1u;
+    const uint32_t cls = (hm.metallic == 0.0f && hm.roughness >= 1.0f && hm.tex_mr < 0) ? 0u : 1u;
     o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; std::memcpy(&o[3], &p, 4);
     o[4] = b[0] - a[0]; o[5] = b[1] - a[1]; o[6] = b[2] - a[2]; std::memcpy(&o[7], &cls, 4);
     o[8] = c[0] - a[0]; o[9] = c[1] - a[1]; o[10] = c[2] - a[2]; o[11] = 0.0f;
@@ -460,7 +470,7 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
     const HostMaterial& m = mats[i];
     o[0] = m.base[0]; o[1] = m.base[1]; o[2] = m.base[2]; o[3] = m.metallic;
     o[4] = m.emissive[0]; o[5] = m.emissive[1]; o[6] = m.emissive[2]; o[7] = m.roughness;
-    o[8] = m.base[3]; o[9] = 0.0f; o[10] = 0.0f; o[11] = 0.0f;
+    o[8] = m.base[3]; std::memcpy(&o[9], &m.tex_color, 4); std::memcpy(&o[10], &m.tex_normal, 4); std::memcpy(&o[11], &m.tex_mr, 4);
   }
   // ---- emitters (original primitive order), power pmf / cdf ----------------------------------------------
   B.prim_light.assign(n, -1);
@@ -508,6 +518,66 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
     o[8] = c.position[0]; o[9] = c.position[1]; o[10] = c.position[2]; o[11] = a.normal[0];
     o[12] = a.normal[1]; o[13] = a.normal[2]; o[14] = b.normal[0]; o[15] = b.normal[1];
     o[16] = b.normal[2]; o[17] = c.normal[0]; o[18] = c.normal[1]; o[19] = c.normal[2];
+  }
+  // ---- textured materials: uv / tangent / bitangent of the three vertices per primitive, texel store -----------
+  bool any_tex = false;
+  for (const auto& m : mats) any_tex = any_tex || m.tex_color >= 0 || m.tex_normal >= 0 || m.tex_mr >= 0;
+  if (any_tex) {
+    B.shade_tex.resize((size_t)n * 24);
+    for (uint32_t p = 0; p < n; ++p) {
+      float* o = &B.shade_tex[(size_t)p * 24];
+      for (int c = 0; c < 3; ++c) {
+        const uint32_t vi = B.widx[p * 3 + (uint32_t)c];
+        const HostVertex& v = B.wverts[vi];
+        o[c * 2 + 0] = v.texcoord[0]; o[c * 2 + 1] = v.texcoord[1];
+        for (int k = 0; k < 3; ++k) { o[6 + c * 3 + k] = v.tangent[k]; o[15 + c * 3 + k] = wbt[(size_t)vi * 3 + (size_t)k]; }
+      }
+    }
+  }
+  for (const auto& t : texs) {
+    const int32_t info[4] = {(int32_t)B.texels.size(), t.w, t.h, 0};
+    B.tex_info.insert(B.tex_info.end(), info, info + 4);
+    const size_t np = (size_t)t.w * (size_t)t.h;
+    for (size_t i = 0; i < np; ++i) {
+      uint32_t u; std::memcpy(&u, &t.px[i * 4], 4);
+      B.texels.push_back(u);
+    }
+  }
+  if (B.texels.empty()) B.texels.push_back(0u);
+  if (B.tex_info.empty()) B.tex_info.assign(4, 0);
+  // ---- environment light: radiance + pmf per texel, row-marginal and per-row conditional cdfs ---------------
+  B.env_w = env.w; B.env_h = env.h; B.env_ok = 0;
+  if (env.w > 0 && env.h > 0) {
+    const int w = env.w, hgt = env.h;
+    const size_t np = (size_t)w * (size_t)hgt;
+    B.env.resize(np * 4); B.env_cond.resize(np); B.env_marg.resize((size_t)hgt);
+    std::vector<float> rowsum((size_t)hgt);
+    float totalw = 0.0f;
+    for (int y = 0; y < hgt; ++y) {
+      const float sr = (float)std::sin(3.14159265358979323846 * ((double)y + 0.5) / (double)hgt);
+      float runw = 0.0f;
+      for (int x = 0; x < w; ++x) {
+        const float* t = &env.rgb[((size_t)y * w + x) * 3];
+        float f = fmaf(t[2], 0.0722f, fmaf(t[1], 0.7152f, t[0] * 0.2126f)) * sr;
+        if (!(f > 0.0f)) f = 0.0f;
+        float* o = &B.env[((size_t)y * w + x) * 4];
+        o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = f;
+        runw += f;
+        B.env_cond[(size_t)y * w + x] = runw;
+      }
+      rowsum[(size_t)y] = runw; totalw += runw;
+      for (int x = 0; x < w; ++x) B.env_cond[(size_t)y * w + x] = runw > 0.0f ? B.env_cond[(size_t)y * w + x] / runw : (float)(x + 1) / (float)w;
+      B.env_cond[(size_t)y * w + (size_t)(w - 1)] = 1.0f;
+    }
+    if (totalw > 0.0f) {
+      float runw = 0.0f;
+      for (int y = 0; y < hgt; ++y) { runw += rowsum[(size_t)y]; B.env_marg[(size_t)y] = runw / totalw; }
+      B.env_marg[(size_t)hgt - 1] = 1.0f;
+      for (size_t i = 0; i < np; ++i) B.env[i * 4 + 3] = B.env[i * 4 + 3] / totalw;
+      B.env_ok = 1;
+    } else {
+      for (size_t i = 0; i < np; ++i) B.env[i * 4 + 3] = 0.0f;
+    }
   }
   if (!B.cdf.empty()) B.cdf.back() = 1.0f;
   if (B.cdf.empty()) B.cdf.push_back(1.0f);

@@ -280,5 +280,104 @@ def two_triangles_and_sphere() -> SceneDesc:
     return SceneDesc(mats, meshes, inst, cam, "two_tris_sphere")
 
 
+
+
+# ----------------------------------------------------------------------------------------------
+# Config 5: textures + image-based environment light (all procedural and seeded: the reference's
+# assets/textures/rusty_metal_grid_{diff,nor_gl}_1k.png are stripped from the checkout).
+def _value_noise(size: int, seed: int, octaves: int = 4) -> np.ndarray:
+    """Tileable value noise in [0,1], size × size (REPEAT-safe: lattice wraps)."""
+    rng = np.random.default_rng(seed)
+    out = np.zeros((size, size), np.float64)
+    amp, total = 1.0, 0.0
+    for o in range(octaves):
+        cells = 4 << o
+        lat = rng.random((cells, cells))
+        t = np.arange(size) * cells / size
+        i0 = np.floor(t).astype(int) % cells
+        i1 = (i0 + 1) % cells
+        f = t - np.floor(t)
+        f = f * f * (3 - 2 * f)
+        a = lat[i0][:, i0] * (1 - f)[None, :] + lat[i0][:, i1] * f[None, :]
+        b = lat[i1][:, i0] * (1 - f)[None, :] + lat[i1][:, i1] * f[None, :]
+        out += amp * (a * (1 - f)[:, None] + b * f[:, None])
+        total += amp
+        amp *= 0.5
+    return out / total
+
+
+def texture_albedo(size: int = 256, seed: int = 5) -> np.ndarray:
+    n1, n2 = _value_noise(size, seed), _value_noise(size, seed + 1)
+    rgb = np.stack([0.55 + 0.4 * n1, 0.35 + 0.4 * n2, 0.25 + 0.3 * n1 * n2], -1)
+    grid = ((np.arange(size) // max(1, size // 8)) % 2)[:, None] ^ ((np.arange(size) // max(1, size // 8)) % 2)[None, :]
+    rgb *= (0.75 + 0.25 * grid)[..., None]
+    return np.concatenate([np.clip(rgb * 255 + 0.5, 0, 255).astype(np.uint8), np.full((size, size, 1), 255, np.uint8)], -1)
+
+
+def texture_normal(size: int = 256, seed: int = 6, strength: float = 2.0) -> np.ndarray:
+    h = _value_noise(size, seed)
+    dx = (np.roll(h, -1, 1) - np.roll(h, 1, 1)) * 0.5 * size / 64.0 * strength
+    dy = (np.roll(h, -1, 0) - np.roll(h, 1, 0)) * 0.5 * size / 64.0 * strength
+    n = np.stack([-dx, -dy, np.ones_like(h)], -1)
+    n /= np.linalg.norm(n, axis=-1, keepdims=True)
+    return np.concatenate([np.clip((n * 0.5 + 0.5) * 255 + 0.5, 0, 255).astype(np.uint8), np.full((size, size, 1), 255, np.uint8)], -1)
+
+
+def texture_metal_rough(size: int = 256, seed: int = 7) -> np.ndarray:
+    r = 0.15 + 0.75 * _value_noise(size, seed)
+    m = (_value_noise(size, seed + 1, 2) > 0.55).astype(np.float64)
+    z = np.zeros_like(r)
+    return np.clip(np.stack([z, r, m, z + 1.0], -1) * 255 + 0.5, 0, 255).astype(np.uint8)   # glTF: G = roughness, B = metallic
+
+
+def analytic_sky(w: int = 64, h: int = 32, sun_dir=(0.4, 0.7, 0.3), sun_radiance: float = 60.0) -> np.ndarray:
+    """Lat-long RGB32F sky (row 0 = +y): horizon-to-zenith gradient, dark ground, and a small bright sun (which is what makes
+    importance sampling necessary)."""
+    v = (np.arange(h) + 0.5) / h
+    u = (np.arange(w) + 0.5) / w
+    th = np.pi * v[:, None]
+    ph = 2 * np.pi * u[None, :] - np.pi
+    d = np.stack([np.sin(th) * np.cos(ph), np.cos(th) * np.ones_like(ph), np.sin(th) * np.sin(ph)], -1)
+    up = np.clip(d[..., 1], 0, 1)
+    sky = np.stack([0.35 + 0.25 * (1 - up), 0.5 + 0.25 * (1 - up), 0.9 - 0.2 * (1 - up)], -1) * (0.6 + 0.8 * up[..., None])
+    ground = np.array([0.12, 0.10, 0.08])
+    img = np.where((d[..., 1] > 0)[..., None], sky, ground[None, None, :])
+    s = np.asarray(sun_dir, np.float64)
+    s /= np.linalg.norm(s)
+    img = img + (np.einsum("ijk,k->ij", d, s) > np.cos(np.radians(6.0)))[..., None] * sun_radiance * np.array([1.0, 0.9, 0.7])
+    return img.astype(np.float32)
+
+
+def textured_atrium(scale: float = 1.0, tex_size: int = 1024, env_size=(2048, 1024), keep_panels: bool = True) -> SceneDesc:
+    """Config 5: the atrium with albedo / normal / metallic-roughness textures on floor, columns and arches, its ceiling opened to an
+    analytic-sky environment map (the emissive panels stay unless keep_panels=False: both light kinds are then sampled)."""
+    d = atrium(scale)
+    d.name = "textured_atrium"
+    d.textures = [texture_albedo(tex_size, 5), texture_normal(tex_size, 6), texture_metal_rough(tex_size, 7)]
+    for k in (1, 2, 3):                               # floor, columns, arches
+        d.materials[k].tex_color, d.materials[k].tex_normal = 0, 1
+    d.materials[3].tex_mr = 2
+    d.materials[3].metallic, d.materials[3].roughness = 1.0, 1.0
+    d.env = analytic_sky(env_size[0], env_size[1])
+    # open the roof: drop the ceiling patch (mesh 1) and, optionally, the emissive panels
+    drop = {1} | (set() if keep_panels else {i for i, m in enumerate(d.meshes) if m.material == 5})
+    d.instances = [it for it in d.instances if it.mesh not in drop]
+    return d
+
+
+def textured_objects() -> SceneDesc:
+    """Small textured + environment-lit test scene: a textured ground, a normal-mapped sphere with a metallic-roughness map and a
+    plain diffuse sphere under the analytic sky; no emissive triangles (environment NEE only)."""
+    d = sphere_scene(48, 25)
+    d.name = "textured_objects"
+    d.textures = [texture_albedo(64, 5), texture_normal(64, 6), texture_metal_rough(64, 7)]
+    d.materials[0] = Material((1.0, 1.0, 1.0, 1.0), 1.0, 1.0, (0, 0, 0), 0, 1, 2)       # big sphere: all three maps
+    d.materials[1] = Material((0.9, 0.9, 0.9, 1.0), 0.0, 1.0, (0, 0, 0), 0, -1, -1)     # ground: albedo map only (stays Lambert class)
+    d.materials[3] = Material((0.2, 0.3, 0.8, 0.5), 0.0, 0.5, (0, 0, 0), -1, 1, -1)     # small spheres: normal map only
+    d.instances = [it for it in d.instances if it.mesh != 2]                            # no emissive quad
+    d.env = analytic_sky(64, 32)
+    return d
+
 def by_name(name: str, **kw) -> SceneDesc:
-    return {"cornell": cornell_box, "sphere10k": sphere_scene, "atrium": atrium, "two_tris_sphere": two_triangles_and_sphere}[name](**kw)
+    return {"cornell": cornell_box, "sphere10k": sphere_scene, "atrium": atrium, "two_tris_sphere": two_triangles_and_sphere,
+            "textured_objects": textured_objects, "textured_atrium": textured_atrium}[name](**kw)

@@ -52,6 +52,9 @@ DIGEST_CASES = {
     "sphere10k_192x192x8_seed2": ("sphere10k", {}, 192, 192, 8, 2, 8),
     "atrium_small_160x90x4_seed3": ("atrium", {"scale": 0.05}, 160, 90, 4, 3, 8),
     "atrium_full_240x135x2_seed3": ("atrium", {}, 240, 135, 2, 3, 8),
+    # config 5 geometry at test size: textures (albedo / normal / metal-rough) + lat-long environment light (+ emissive panels)
+    "textured_objects_128x128x8_seed5": ("textured_objects", {}, 128, 128, 8, 5, 6),
+    "textured_atrium_small_160x90x4_seed5": ("textured_atrium", {"scale": 0.05, "tex_size": 128, "env_size": (128, 64)}, 160, 90, 4, 5, 8),
 }
 
 

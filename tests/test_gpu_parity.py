@@ -48,6 +48,10 @@ CASES = [
     ("atrium", {"scale": 0.05}, 160, 90, 4, 3, 8),  # config 3 at reduced tessellation
     ("atrium", {}, 240, 135, 2, 3, 8),            # config 3 geometry, 249,936 tris
     ("two_tris_sphere", {}, 64, 64, 2, 5, 3),     # no emitters: NEE disabled, background 0
+    # config 5: RGBA8 NEAREST/REPEAT textures (albedo, tangent-space normal map, metal-rough) + lat-long env light
+    ("textured_objects", {}, 128, 128, 8, 5, 6),                                                          # environment NEE only
+    ("textured_atrium", {"scale": 0.05, "tex_size": 128, "env_size": (128, 64)}, 160, 90, 4, 5, 8),      # env + emissive panels
+    ("textured_atrium", {"scale": 0.05, "tex_size": 64, "env_size": (64, 32), "keep_panels": False}, 120, 68, 4, 6, 4),
 ]
 
 
@@ -65,7 +69,8 @@ def test_path_tracer_image_and_counters(gpu, ora, name, kw, w, h, spp, seed, mb)
     assert sg["seconds_trace_closest"] > 0 and sg["launches_trace_closest"] == mb + 1
 
 
-@pytest.mark.parametrize("name,kw,w,h", [("two_tris_sphere", {}, 64, 64), ("atrium", {"scale": 0.05}, 160, 90), ("sphere10k", {}, 101, 67)])
+@pytest.mark.parametrize("name,kw,w,h", [("two_tris_sphere", {}, 64, 64), ("atrium", {"scale": 0.05}, 160, 90), ("sphere10k", {}, 101, 67),
+                                         ("textured_objects", {}, 96, 96), ("textured_atrium", {"scale": 0.05, "tex_size": 128, "env_size": (64, 32)}, 160, 90)])
 def test_raster_compat(gpu, ora, name, kw, w, h):
     pt, o = _pair(gpu, ora, gpu.scenes.by_name(name, **kw))
     g = pt.render(w, h, 1, integrator=gpu.INTEGRATOR_RASTER_COMPAT)

@@ -1,0 +1,96 @@
+"""Textures and the environment light (BASELINE config 5) in the oracle: closed-form checks of the new estimator
+pieces, on the CPU.  (GPU-vs-oracle bit parity of the same scenes is in test_gpu_parity.py.)"""
+import math
+
+import numpy as np
+import pytest
+
+
+def _plane_scene(pbr, material, textures=(), env=None, uv_scale=1.0):
+    sc = pbr.scene
+    v, i = pbr.scenes._quad((-50, 0, 50), (50, 0, 50), (50, 0, -50), (-50, 0, -50))      # normal +y
+    v["texCoords"] = v["texCoords"] * uv_scale
+    return sc.SceneDesc([material], [sc.MeshDesc(v, i, 0)], [sc.InstanceDesc(0)], sc.CameraDesc((0, 3, 0), (0, 0, -0.001), 0.6, 1.0),
+                        textures=list(textures), env=env)
+
+
+def test_atan2_accuracy(ora):
+    rng = np.random.default_rng(0)
+    for y, x in rng.normal(0, 1, (4000, 2)):
+        assert abs(ora.lib().ora_atan2f(float(y), float(x)) - math.atan2(np.float32(y), np.float32(x))) < 2e-5
+    assert ora.lib().ora_atan2f(0.0, 0.0) == 0.0 and abs(ora.lib().ora_atan2f(0.0, -1.0) - math.pi) < 1e-6
+
+
+def test_constant_environment_on_a_diffuse_plane(ora, pbr):
+    """Radiance 1 from every direction on an infinite-ish Lambert plane of albedo rho (convex: no interreflection) gives exactly rho;
+    NEE and BSDF sampling are combined by MIS, so this checks pdfs and weights of both environment strategies."""
+    env = np.ones((16, 32, 3), np.float32)
+    rho = 0.6
+    d = _plane_scene(pbr, pbr.scene.Material((rho, rho, rho, 1.0), 0.0, 1.0), env=env)
+    img = ora.Oracle().load_scene(d).render(32, 32, 64, seed=1, max_bounces=4)
+    assert abs(float(img[..., :3].mean()) - rho) < 0.01
+    # a GGX dielectric plane under the same furnace stays <= 1 and > the diffuse part
+    d2 = _plane_scene(pbr, pbr.scene.Material((rho, rho, rho, 1.0), 0.0, 0.4), env=env)
+    m2 = float(ora.Oracle().load_scene(d2).render(32, 32, 64, seed=1, max_bounces=4)[..., :3].mean())
+    assert rho - 0.02 < m2 < 1.05
+
+
+def test_small_bright_sun_needs_and_gets_importance_sampling(ora, pbr):
+    """A 6-degree sun carrying most of the power: the estimate at 64 spp is already within a few % of the 1024 spp one
+    (BSDF sampling alone would be far noisier), and equals the analytic irradiance of the map."""
+    env = pbr.scenes.analytic_sky(128, 64)
+    d = _plane_scene(pbr, pbr.scene.Material((0.5, 0.5, 0.5, 1.0), 0.0, 1.0), env=env)
+    o = ora.Oracle().load_scene(d)
+    a = o.render(24, 24, 64, seed=3, max_bounces=1)[..., :3].mean((0, 1))
+    b = o.render(24, 24, 1024, seed=4, max_bounces=1)[..., :3].mean((0, 1))
+    assert np.allclose(a, b, rtol=0.05)
+    # analytic: E = sum over texels of L * cos(theta) * d_omega (upper hemisphere), radiance = rho/pi * E
+    h, w = env.shape[:2]
+    th = np.pi * (np.arange(h) + 0.5) / h
+    dom = (2 * np.pi / w) * (np.pi / h) * np.sin(th)
+    E = (env * (np.clip(np.cos(th), 0, None) * dom)[:, None, None]).sum((0, 1))
+    assert np.allclose(b, 0.5 / np.pi * E, rtol=0.04)
+
+
+def test_base_colour_texture_nearest_repeat(ora, pbr):
+    """2x2 texture, NEAREST/REPEAT (the reference's default sampler, gltf/Asset.cpp:116-117): under a constant environment each
+    visible texel shows base_color_factor * texel, and uv outside [0,1) wraps."""
+    tex = np.array([[[255, 0, 0, 255], [0, 255, 0, 255]], [[0, 0, 255, 255], [255, 255, 255, 255]]], np.uint8)
+    env = np.ones((8, 16, 3), np.float32)
+    mat = pbr.scene.Material((0.5, 1.0, 1.0, 1.0), 0.0, 1.0, (0, 0, 0), 0, -1, -1)
+    d = _plane_scene(pbr, mat, [tex], env, uv_scale=3.0)                      # uv in [0,3): the 2x2 pattern repeats three times
+    img = ora.Oracle().load_scene(d).render(48, 48, 16, seed=2, max_bounces=2)[..., :3]
+    cols = {tuple(np.round(c, 2)) for c in img.reshape(-1, 3)[::7]}
+    expect = [(0.5, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0), (0.5, 1.0, 1.0)]
+    for e in expect:
+        assert any(np.allclose(c, e, atol=0.08) for c in cols), e
+    flat = img.reshape(-1, 3)
+    ok = sum(any(np.allclose(p, e, atol=0.12) for e in expect) for p in flat[::5])
+    assert ok > 0.9 * len(flat[::5])                                          # every pixel is one of the four texel colours (pixel-footprint mixing aside)
+
+
+def test_normal_map_tilts_the_shading_normal(ora, pbr):
+    """Raster-compat (fragment.glsl:24-27): with a constant tangent-space normal (sx, 0, sqrt(1-sx^2)) the shaded N·V changes as
+    TBN * texel predicts; a flat (0.5,0.5,1) texel reproduces the untextured result bit for bit."""
+    flat = np.full((4, 4, 4), (128, 128, 255, 255), np.uint8)                 # not exactly (0,0,1): 128/255*2-1 = 0.0039
+    exact = np.full((2, 2, 4), (255, 255, 255, 255), np.uint8)
+    base = pbr.scene.Material((0.8, 0.8, 0.8, 1.0), 0.0, 1.0)
+    r0 = ora.Oracle().load_scene(_plane_scene(pbr, base)).render(16, 16, 1, integrator=1)
+    white = pbr.scene.Material((0.8, 0.8, 0.8, 1.0), 0.0, 1.0, (0, 0, 0), 0, -1, -1)
+    r1 = ora.Oracle().load_scene(_plane_scene(pbr, white, [exact])).render(16, 16, 1, integrator=1)
+    assert np.array_equal(r0, r1)                                            # albedo * 1.0 and no normal map: identical
+    nm = pbr.scene.Material((0.8, 0.8, 0.8, 1.0), 0.0, 1.0, (0, 0, 0), -1, 0, -1)
+    r2 = ora.Oracle().load_scene(_plane_scene(pbr, nm, [flat])).render(16, 16, 1, integrator=1)
+    assert np.abs(r2 - r0).max() < 0.1 and not np.array_equal(r2, r0)   # 128/255*2-1 = 0.004: almost, not exactly, flat (pow(.,64) amplifies)
+    tilt = np.full((2, 2, 4), (230, 128, 200, 255), np.uint8)
+    r3 = ora.Oracle().load_scene(_plane_scene(pbr, nm, [tilt])).render(16, 16, 1, integrator=1)
+    assert np.abs(r3 - r0).max() > 0.15
+
+
+def test_environment_argument_errors(ora, pbr):
+    o = ora.Oracle()
+    L = ora.lib()
+    assert L.ora_set_env_latlong_rgb32f(o._h, np.zeros(3, np.float32).ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_float)), 0, 1) < 0
+    pt = pbr.PathTracer(pbr.DEVICE_NONE)
+    with pytest.raises(pbr.PtcError, match="texture id out of range"):
+        pt.load_scene(_plane_scene(pbr, pbr.scene.Material((1, 1, 1, 1), 0.0, 1.0, (0, 0, 0), 3, -1, -1)))
