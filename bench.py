@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--max-bounces", type=int, default=8)
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--scene-scale", type=float, default=1.0, help="atrium tessellation scale (1.0 = 249,936 triangles)")
+    ap.add_argument("--workload", choices=["atrium", "textured"], default="atrium",
+                    help="atrium = BASELINE configs[2]/[3] (the metric's configuration); textured = configs[4]: the same atrium with 1024^2 "
+                         "albedo/normal/metal-rough textures and a 2048x1024 environment light")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the bounded CPU-baseline render")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -69,7 +72,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    desc = scenes.atrium(args.scene_scale)
+    desc = scenes.atrium(args.scene_scale) if args.workload == "atrium" else scenes.textured_atrium(args.scene_scale)
     desc.camera.aspect = args.width / args.height
     pt = pbr_amd.PathTracer(local_rank).load_scene(desc)
     K, W, S = args.steps, args.warmup, args.spp_per_step
@@ -144,7 +147,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"procedural atrium {desc.n_triangles} tris (BASELINE configs[2]/[3]), {args.width}x{args.height}, {S * K} spp = {K} steps x {S} spp, max_bounces {args.max_bounces}, seed {args.seed}",
+                "workload": (f"procedural atrium {desc.n_triangles} tris (BASELINE configs[2]/[3])" if args.workload == "atrium" else
+                             f"textured atrium {desc.n_triangles} tris + 1024^2 albedo/normal/metal-rough textures + 2048x1024 env light (BASELINE configs[4])")
+                            + f", {args.width}x{args.height}, {S * K} spp = {K} steps x {S} spp, max_bounces {args.max_bounces}, seed {args.seed}",
                 "paths": paths,
                 "sharding": f"32x32 tiles over {world} rank(s), RCCL reduce to rank 0" if world > 1 else "single GPU",
             },

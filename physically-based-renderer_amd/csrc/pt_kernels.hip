@@ -24,10 +24,14 @@
 #define TRACE_MIN_WAVES 7         // waves per SIMD the register allocator must leave room for (launch bounds)
 #endif
 #define TRACE_WAVES (TRACE_BLOCK / 64)
+#ifndef TRACE_CHUNK
 #define TRACE_CHUNK 512u          // rays per work-fetch atomic
+#endif
+#ifndef TRACE_REFILL_IDLE
 #define TRACE_REFILL_IDLE 16      // refill as soon as this many lanes are idle
+#endif
 #ifndef TRACE_NODE_MIN
-#define TRACE_NODE_MIN 20         // leave the node loop when fewer lanes than this are still at interior nodes
+#define TRACE_NODE_MIN 36         // leave the node loop when fewer lanes than this are still at interior nodes
 #endif                            // while others wait at a leaf (keeps both phases well populated)
 #define SHADE_BLOCK 512
 #define SHADE_WAVES (SHADE_BLOCK / 64)
@@ -100,15 +104,23 @@ __global__ __launch_bounds__(256) void k_raygen(DevCamera cam, DevFrame fr, DevQ
 // (8-byte entries, stride 64 lanes: ds_read/write_b64 is conflict-free at every mix of depths), deeper
 // entries — rare — go to a global overflow slab laid out [wave][depth][lane].
 struct WStack {
-  uint2* lds; uint2* ovf; int sp; int L;
-  PT_DEV void init(uint2* lds_base, uint2* ovf_base, int l) { lds = lds_base; ovf = ovf_base; sp = 0; L = l; }
+  typedef unsigned int ux2 __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) ux2 lds_u2;
+  typedef __attribute__((address_space(1))) ux2 glb_u2;
+  lds_u2* lds; glb_u2* ovf; int sp; int L;
+  PT_DEV void init(uint2* lds_base, uint2* ovf_base, int l) { lds = (lds_u2*)lds_base; ovf = (glb_u2*)ovf_base; sp = 0; L = l; }
   PT_DEV void reset() { sp = 0; }
   PT_DEV void push(int code, uint32_t key) {
-    const uint2 e = make_uint2((uint32_t)code, key & 0xfffffffcu);
-    if (sp < L) lds[sp * 64] = e; else ovf[(sp - L) * 64] = e;
+    const ux2 e = {(unsigned int)code, key & 0xfffffffcu};
+    if (sp < L) lds[sp * 64] = e; else ovf[(sp - L) * 64] = e;      // explicit address spaces: ds_write_b64 / global_store_dwordx2
     ++sp;
   }
-  PT_DEV uint2 pop() { --sp; return sp < L ? lds[sp * 64] : ovf[(sp - L) * 64]; }
+  PT_DEV uint2 pop() {
+    --sp;
+    ux2 e;
+    if (sp < L) e = lds[sp * 64]; else e = ovf[(sp - L) * 64];      // ds_read_b64 / global_load_dwordx2, never FLAT
+    return make_uint2(e.x, e.y);
+  }
   PT_DEV bool empty() const { return sp == 0; }
 };
 
@@ -142,8 +154,21 @@ struct WideHit { float tn[4], tf[4]; int code[4]; bool used[4]; };
 
 template <bool NODELETS>
 PT_DEV WideHit wide_decode(const DevScene& sc, const float4* lds_nodes, int cur, const ray_t& r, const Octant& oc) {
-  const float4* p = (NODELETS && (uint32_t)cur < sc.n_nodelets) ? lds_nodes + (size_t)cur * 3 : sc.nodes + (size_t)cur * 3;
-  const float4 f0 = p[0], f1 = p[1], f2 = p[2];
+  // two explicit address spaces (a single pointer that may be LDS or global would compile to FLAT loads, which occupy both
+  // the LDS and the vector-memory pipe and wait on both counters)
+  // Two explicit address spaces: a pointer that may be LDS or global compiles to FLAT loads, which occupy both the LDS and the
+  // vector-memory pipe and wait on both counters.
+  typedef float fx4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) const fx4 lds_f4;
+  typedef __attribute__((address_space(1))) const fx4 glb_f4;
+  fx4 f0, f1, f2;
+  if (NODELETS && (uint32_t)cur < sc.n_nodelets) {
+    lds_f4* p = (lds_f4*)lds_nodes + (uint32_t)cur * 3u;          // ds_read_b128 × 3
+    f0 = p[0]; f1 = p[1]; f2 = p[2];
+  } else {
+    glb_f4* p = (glb_f4*)sc.nodes + (size_t)cur * 3;               // global_load_dwordx4 × 3
+    f0 = p[0]; f1 = p[1]; f2 = p[2];
+  }
   const uint32_t ew = __float_as_uint(f0.w);
   // plane distance = fma(q, 2^(e-127)·inv, fma(org, inv, -ood))
   const float ax = __uint_as_float((ew & 255u) << 23) * r.inv.x, ay = __uint_as_float(((ew >> 8) & 255u) << 23) * r.inv.y,

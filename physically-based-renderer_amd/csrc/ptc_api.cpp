@@ -31,7 +31,7 @@ struct ptc_ctx {
   hipStream_t stream = nullptr;
   std::string err;
   LaunchCfg cfg{};
-  uint32_t nodelet_budget = 200;  // wide nodes staged in LDS (breadth-first top of the tree, 48 B each: 9.4 KB)
+  uint32_t nodelet_budget = 85;   // wide nodes staged in LDS: the top four levels (1+4+16+64) of the tree, 48 B each = 4 KB
   size_t max_batch_paths = (size_t)1 << 27;   // paths in flight over all lanes: large batches amortise launch tails (sized for 288 GB of HBM:
                                               // 184 B per path -> 24.7 GB of queues at 1080p x 32 spp x 2 lanes)
   bool timing = true;
@@ -169,7 +169,7 @@ int configure_launch(ptc_ctx* c) {
   // 3·(depth+1) entries.  `stack_lds` of them live in LDS (8 B each, 512 B per level and wave), the rest in
   // a global overflow slab.  LDS per block = nodelets·48 B + waves·stack_lds·512 B.
   const int need = 3 * ((int)c->built.max_depth + 1);
-  int l = 8;    // measured on MI355X: 5 blocks/CU (VGPR-bound), each 8 x 2 KB of stack + 200 nodelets, beats deeper LDS stacks
+  int l = 10;   // stack entries per lane kept in LDS (2 KB per entry and block); measured: 8..12 equal, deeper loses occupancy
   if (const char* e = std::getenv("PTC_STACK_LDS")) { int v = std::atoi(e); if (v >= 1 && v <= 64) l = v; }
   if (l > need) l = need;
   c->cfg.stack_lds = l;
