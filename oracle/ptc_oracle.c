@@ -423,31 +423,11 @@ void ora_make_camera(const float pos[3], const float target[3], float fov, float
 }
 
 /* ------------------------------------------------------------------------------------------ */
-/* P2: LBVH.  30-bit Morton of the triangle-AABB centre normalised to the centroid bounds; keys   */
-/* made unique with the primitive id; the binary radix tree over the sorted keys; subtrees of    */
-/* <= ORA_LEAF_MAX triangles collapse into one leaf.                                              */
-static inline uint32_t expand10(uint32_t v) {
-  v &= 0x3ffu;
-  v = (v | (v << 16)) & 0x030000FFu;
-  v = (v | (v << 8)) & 0x0300F00Fu;
-  v = (v | (v << 4)) & 0x030C30C3u;
-  v = (v | (v << 2)) & 0x09249249u;
-  return v;
-}
-static inline uint32_t quant10(float c, float lo, float ext) {
-  float n = (c - lo) / ext;
-  float q = n * 1024.0f;
-  if (!(q > 0.0f)) q = 0.0f;
-  if (q > 1023.0f) q = 1023.0f;
-  return (uint32_t)q;
-}
-static int cmp_u64(const void* a, const void* b) {
-  uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b;
-  return x < y ? -1 : (x > y ? 1 : 0);
-}
+/* P2: BVH.  Top-down binned-SAH binary tree over the triangle boxes (sah_split below), ranges of  */
+/* <= ORA_LEAF_MAX triangles are leaves; then the 4-wide collapse and the 8-bit quantisation.      */
 static inline int32_t leaf_code(uint32_t first, uint32_t count) { return (int32_t)~(first | ((count - 1u) << 28)); }
 
-typedef struct { ora_ctx* c; const uint64_t* keys; const float* tlo; const float* thi; uint32_t next; uint32_t depth_max; } build_t;
+typedef struct { ora_ctx* c; const float* tlo; const float* thi; uint32_t next; uint32_t depth_max; } build_t;
 
 static void range_box(build_t* b, uint32_t lo, uint32_t hi, float blo[3], float bhi[3]) {
   for (int k = 0; k < 3; ++k) { blo[k] = INFINITY; bhi[k] = -INFINITY; }
@@ -459,22 +439,69 @@ static void range_box(build_t* b, uint32_t lo, uint32_t hi, float blo[3], float 
     }
   }
 }
-/* Split [lo,hi] at the highest differing key bit: returns last index of the lower half. */
-static uint32_t find_split(const uint64_t* keys, uint32_t lo, uint32_t hi) {
-  uint64_t diff = keys[lo] ^ keys[hi];
-  int bit = 63 - __builtin_clzll(diff);
-  uint64_t mask = 1ull << bit;
-  /* keys sorted: those with bit==0 (given equal higher bits) come first; binary search the boundary */
-  uint32_t a = lo, z = hi; /* keys[a] has bit 0, keys[z] has bit 1 */
-  while (z - a > 1) { uint32_t m = a + (z - a) / 2; if (keys[m] & mask) z = m; else a = m; }
-  return a;
+/* Binned surface-area split of order[lo..hi]: per axis, ORA_SAH_BINS equal bins over the range's centroid bounds,
+ * cost(split) = half_area(L)*nL + half_area(R)*nR, minimum over axes and bin boundaries (ties: lowest axis, then
+ * lowest boundary); order[lo..hi] is then partitioned STABLY (left = bin <= boundary).  When all centroids
+ * coincide the range is cut at its middle index.  Returns the last index of the left part. */
+#define ORA_SAH_BINS 32
+static inline float half_area(const float lo[3], const float hi[3]);
+static uint32_t sah_split(build_t* b, uint32_t lo, uint32_t hi) {
+  uint32_t* ord = b->c->order;
+  float cl[3] = {INFINITY, INFINITY, INFINITY}, ch[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (uint32_t i = lo; i <= hi; ++i) {
+    uint32_t p = ord[i];
+    for (int k = 0; k < 3; ++k) { float ctr = 0.5f * (b->tlo[p * 3 + k] + b->thi[p * 3 + k]); cl[k] = fmin2(cl[k], ctr); ch[k] = fmax2(ch[k], ctr); }
+  }
+  float best = INFINITY; int best_axis = -1, best_bin = 0;
+  for (int k = 0; k < 3; ++k) {
+    if (!(ch[k] > cl[k])) continue;
+    float scale = (float)ORA_SAH_BINS / (ch[k] - cl[k]);
+    uint32_t cnt[ORA_SAH_BINS]; float blo[ORA_SAH_BINS][3], bhi[ORA_SAH_BINS][3];
+    for (int j = 0; j < ORA_SAH_BINS; ++j) { cnt[j] = 0; for (int a = 0; a < 3; ++a) { blo[j][a] = INFINITY; bhi[j][a] = -INFINITY; } }
+    for (uint32_t i = lo; i <= hi; ++i) {
+      uint32_t p = ord[i];
+      int j = (int)((0.5f * (b->tlo[p * 3 + k] + b->thi[p * 3 + k]) - cl[k]) * scale);
+      if (j > ORA_SAH_BINS - 1) j = ORA_SAH_BINS - 1;
+      cnt[j]++;
+      for (int a = 0; a < 3; ++a) { blo[j][a] = fmin2(blo[j][a], b->tlo[p * 3 + a]); bhi[j][a] = fmax2(bhi[j][a], b->thi[p * 3 + a]); }
+    }
+    float rarea[ORA_SAH_BINS]; uint32_t rcnt[ORA_SAH_BINS];
+    { float rl[3] = {INFINITY, INFINITY, INFINITY}, rh[3] = {-INFINITY, -INFINITY, -INFINITY}; uint32_t rc = 0;
+      for (int j = ORA_SAH_BINS - 1; j >= 1; --j) {
+        rc += cnt[j];
+        for (int a = 0; a < 3; ++a) { rl[a] = fmin2(rl[a], blo[j][a]); rh[a] = fmax2(rh[a], bhi[j][a]); }
+        rcnt[j] = rc; rarea[j] = rc ? half_area(rl, rh) : 0.0f;
+      } }
+    float ll[3] = {INFINITY, INFINITY, INFINITY}, lh[3] = {-INFINITY, -INFINITY, -INFINITY}; uint32_t lc = 0;
+    for (int j = 0; j < ORA_SAH_BINS - 1; ++j) {
+      lc += cnt[j];
+      for (int a = 0; a < 3; ++a) { ll[a] = fmin2(ll[a], blo[j][a]); lh[a] = fmax2(lh[a], bhi[j][a]); }
+      if (lc == 0 || rcnt[j + 1] == 0) continue;
+      float cost = half_area(ll, lh) * (float)lc + rarea[j + 1] * (float)rcnt[j + 1];
+      if (cost < best) { best = cost; best_axis = k; best_bin = j; }
+    }
+  }
+  if (best_axis < 0) return lo + (hi - lo) / 2;
+  {
+    int k = best_axis; float scale = (float)ORA_SAH_BINS / (ch[k] - cl[k]);
+    uint32_t n = hi - lo + 1, nl = 0, nr = 0;
+    uint32_t* tmp = (uint32_t*)malloc(4u * n);
+    for (uint32_t i = lo; i <= hi; ++i) {
+      uint32_t p = ord[i];
+      int j = (int)((0.5f * (b->tlo[p * 3 + k] + b->thi[p * 3 + k]) - cl[k]) * scale);
+      if (j > ORA_SAH_BINS - 1) j = ORA_SAH_BINS - 1;
+      if (j <= best_bin) ord[lo + nl++] = p; else tmp[nr++] = p;
+    }
+    memcpy(&ord[lo + nl], tmp, 4u * nr);
+    free(tmp);
+    return lo + nl - 1;
+  }
 }
-/* Emit the interior node covering [lo,hi] (count > LEAF_MAX); returns its index. Iterative-safe depth
- * (<= 64+log) so plain recursion is fine. */
+/* Emit the interior node covering [lo,hi] (count > LEAF_MAX); returns its index. */
 static int32_t build_node(build_t* b, uint32_t lo, uint32_t hi, uint32_t depth) {
   uint32_t me = b->next++;
   if (depth > b->depth_max) b->depth_max = depth;
-  uint32_t split = find_split(b->keys, lo, hi);
+  uint32_t split = sah_split(b, lo, hi);
   node_t tmp; memset(&tmp, 0, sizeof tmp);
   range_box(b, lo, split, tmp.lo0, tmp.hi0);
   range_box(b, split + 1, hi, tmp.lo1, tmp.hi1);
@@ -602,44 +629,23 @@ int ora_scene_commit(ora_ctx* c) {
     vb += m->nv; tb += m->ni / 3;
   }
   uint32_t n = c->n_tris;
-  /* triangle boxes, centroid bounds */
+  /* triangle boxes, scene bounds */
   float* tlo = (float*)malloc(12u * n); float* thi = (float*)malloc(12u * n);
-  float cb_lo[3] = {INFINITY, INFINITY, INFINITY}, cb_hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (int k = 0; k < 3; ++k) { c->scene_lo[k] = INFINITY; c->scene_hi[k] = -INFINITY; }
   for (uint32_t p = 0; p < n; ++p) {
     for (int k = 0; k < 3; ++k) {
       float a = c->wv[c->widx[p * 3 + 0]].position[k], b = c->wv[c->widx[p * 3 + 1]].position[k], d = c->wv[c->widx[p * 3 + 2]].position[k];
       float lo = fmin2(fmin2(a, b), d), hi = fmax2(fmax2(a, b), d);
       tlo[p * 3 + k] = lo; thi[p * 3 + k] = hi;
-      float ctr = 0.5f * (lo + hi);
-      cb_lo[k] = fmin2(cb_lo[k], ctr); cb_hi[k] = fmax2(cb_hi[k], ctr);
       c->scene_lo[k] = fmin2(c->scene_lo[k], lo); c->scene_hi[k] = fmax2(c->scene_hi[k], hi);
     }
   }
-  float ext[3];
-  for (int k = 0; k < 3; ++k) { ext[k] = cb_hi[k] - cb_lo[k]; if (!(ext[k] > 1e-30f)) ext[k] = 1e-30f; }
   float diag = fmax2(fmax2(c->scene_hi[0] - c->scene_lo[0], c->scene_hi[1] - c->scene_lo[1]), c->scene_hi[2] - c->scene_lo[2]);
   c->ray_eps = 1e-4f * fmax2(diag, 1e-6f);
-  uint64_t* keys = (uint64_t*)malloc(8u * n);
-  for (uint32_t p = 0; p < n; ++p) {
-    uint32_t qx = quant10(0.5f * (tlo[p * 3 + 0] + thi[p * 3 + 0]), cb_lo[0], ext[0]);
-    uint32_t qy = quant10(0.5f * (tlo[p * 3 + 1] + thi[p * 3 + 1]), cb_lo[1], ext[1]);
-    uint32_t qz = quant10(0.5f * (tlo[p * 3 + 2] + thi[p * 3 + 2]), cb_lo[2], ext[2]);
-    uint32_t morton = (expand10(qx) << 2) | (expand10(qy) << 1) | expand10(qz);
-    keys[p] = ((uint64_t)morton << 32) | p;
-  }
-  qsort(keys, n, 8, cmp_u64);
   c->order = (uint32_t*)malloc(4u * n);
-  c->tv0 = (v3*)malloc(sizeof(v3) * n); c->te1 = (v3*)malloc(sizeof(v3) * n); c->te2 = (v3*)malloc(sizeof(v3) * n);
-  for (uint32_t i = 0; i < n; ++i) {
-    uint32_t p = (uint32_t)(keys[i] & 0xffffffffu); c->order[i] = p;
-    const float* a = c->wv[c->widx[p * 3 + 0]].position; const float* b = c->wv[c->widx[p * 3 + 1]].position; const float* d = c->wv[c->widx[p * 3 + 2]].position;
-    c->tv0[i] = V3(a[0], a[1], a[2]);
-    c->te1[i] = V3(b[0] - a[0], b[1] - a[1], b[2] - a[2]);
-    c->te2[i] = V3(d[0] - a[0], d[1] - a[1], d[2] - a[2]);
-  }
+  for (uint32_t i = 0; i < n; ++i) c->order[i] = i;      /* initial order: original primitive order */
   c->nodes = (node_t*)calloc(n > 1 ? n : 1, sizeof(node_t));
-  build_t b = {c, keys, tlo, thi, 0, 0};
+  build_t b = {c, tlo, thi, 0, 0};
   if (n == 1) {                 /* a single triangle: both children are that leaf */
     node_t r; memset(&r, 0, sizeof r);
     range_box(&b, 0, 0, r.lo0, r.hi0); range_box(&b, 0, 0, r.lo1, r.hi1);
@@ -649,9 +655,17 @@ int ora_scene_commit(ora_ctx* c) {
     build_node(&b, 0, n - 1, 0);
   }
   c->n_nodes = b.next; c->max_depth = b.depth_max;
+  c->tv0 = (v3*)malloc(sizeof(v3) * n); c->te1 = (v3*)malloc(sizeof(v3) * n); c->te2 = (v3*)malloc(sizeof(v3) * n);
+  for (uint32_t i = 0; i < n; ++i) {
+    uint32_t p = c->order[i];
+    const float* a = c->wv[c->widx[p * 3 + 0]].position; const float* bq = c->wv[c->widx[p * 3 + 1]].position; const float* d = c->wv[c->widx[p * 3 + 2]].position;
+    c->tv0[i] = V3(a[0], a[1], a[2]);
+    c->te1[i] = V3(bq[0] - a[0], bq[1] - a[1], bq[2] - a[2]);
+    c->te2[i] = V3(d[0] - a[0], d[1] - a[1], d[2] - a[2]);
+  }
   c->wnodes = (wnode_t*)calloc(c->n_nodes, sizeof(wnode_t));
   { uint32_t next = 0, maxd = 0; widen(c, 0, 0, &next, &maxd); c->n_wnodes = next; c->wdepth = maxd; }
-  free(keys); free(tlo); free(thi);
+  free(tlo); free(thi);
   /* P7: emitter table in original primitive order, power pmf/cdf */
   c->prim_light = (int32_t*)malloc(4u * n);
   uint32_t nl = 0;

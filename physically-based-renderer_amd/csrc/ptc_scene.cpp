@@ -64,57 +64,6 @@ inline void mul_n(const float N[9], const float v[3], float o[3]) {
   o[2] = N[2] * v[0] + N[5] * v[1] + N[8] * v[2];
 }
 
-inline uint32_t spread10(uint32_t v) {
-  v &= 0x3ffu;
-  v = (v | (v << 16)) & 0x030000FFu;
-  v = (v | (v << 8)) & 0x0300F00Fu;
-  v = (v | (v << 4)) & 0x030C30C3u;
-  v = (v | (v << 2)) & 0x09249249u;
-  return v;
-}
-inline uint32_t quantize10(float c, float lo, float ext) {
-  float q = ((c - lo) / ext) * 1024.0f;
-  if (!(q > 0.0f)) q = 0.0f;
-  if (q > 1023.0f) q = 1023.0f;
-  return (uint32_t)q;
-}
-
-// ---- binary radix tree over sorted unique 64-bit keys (Karras 2012) ------------------------------
-struct RadixNode { uint32_t lo, hi; int32_t left, right; };  // child >= 0: internal index; < 0: ~leaf position
-
-inline int delta(const std::vector<uint64_t>& k, int64_t i, int64_t j) {
-  if (j < 0 || j >= (int64_t)k.size()) return -1;
-  return __builtin_clzll(k[(size_t)i] ^ k[(size_t)j]);
-}
-
-void build_radix_tree(const std::vector<uint64_t>& k, std::vector<RadixNode>& out) {
-  const int64_t n = (int64_t)k.size();
-  out.resize((size_t)(n - 1));
-  for (int64_t i = 0; i < n - 1; ++i) {   // every internal node is independent (GPU-ready formulation)
-    const int d = delta(k, i, i + 1) - delta(k, i, i - 1) >= 0 ? 1 : -1;
-    const int dmin = delta(k, i, i - d);
-    int64_t lmax = 2;
-    while (delta(k, i, i + lmax * d) > dmin) lmax *= 2;
-    int64_t l = 0;
-    for (int64_t t = lmax / 2; t >= 1; t /= 2)
-      if (delta(k, i, i + (l + t) * d) > dmin) l += t;
-    const int64_t j = i + l * d;
-    const int dnode = delta(k, i, j);
-    int64_t s = 0;
-    for (int64_t t = (l + 1) / 2;; t = (t + 1) / 2) {
-      if (delta(k, i, i + (s + t) * d) > dnode) s += t;
-      if (t == 1) break;
-    }
-    const int64_t gamma = i + s * d + std::min(d, 0);
-    RadixNode r;
-    r.lo = (uint32_t)std::min(i, j);
-    r.hi = (uint32_t)std::max(i, j);
-    r.left = (r.lo == (uint32_t)gamma) ? ~(int32_t)gamma : (int32_t)gamma;
-    r.right = (r.hi == (uint32_t)gamma + 1u) ? ~(int32_t)(gamma + 1) : (int32_t)(gamma + 1);
-    out[(size_t)i] = r;
-  }
-}
-
 struct Box { float lo[3], hi[3]; };
 inline Box empty_box() {
   Box b;
@@ -124,6 +73,110 @@ inline Box empty_box() {
 inline void grow(Box& b, const Box& o) {
   for (int k = 0; k < 3; ++k) { b.lo[k] = o.lo[k] < b.lo[k] ? o.lo[k] : b.lo[k]; b.hi[k] = o.hi[k] > b.hi[k] ? o.hi[k] : b.hi[k]; }
 }
+
+// ---- binary tree by top-down binned surface-area splits -------------------------------------------------
+// SplitNode covers positions [lo,hi] of `ord`; child >= 0: node index; < 0: ~position of a single triangle.
+// Per range: kSahBins equal bins over the centroid bounds on each axis, cost = half_area(L)·nL + half_area(R)·nR,
+// minimum over (axis, boundary) with ties to the lowest axis then boundary, STABLE partition; coincident
+// centroids → cut at the middle index.  Ranges of <= kLeafMax triangles are not split by cost (they become the
+// wide tree's leaves) and are only chained down to single positions for the box pass.
+struct SplitNode { uint32_t lo, hi; int32_t left, right; };
+constexpr int kSahBins = 32;
+
+inline float box_half_area(const Box& b) {
+  const float ex = b.hi[0] - b.lo[0], ey = b.hi[1] - b.lo[1], ez = b.hi[2] - b.lo[2];
+  return ex * ey + ey * ez + ez * ex;
+}
+
+void build_split_tree(const std::vector<Box>& tbox, std::vector<uint32_t>& ord, std::vector<SplitNode>& out) {
+  const uint32_t n = (uint32_t)ord.size();
+  std::vector<float> ctr((size_t)n * 3);
+  for (uint32_t p = 0; p < n; ++p)
+    for (int k = 0; k < 3; ++k) ctr[(size_t)p * 3 + k] = 0.5f * (tbox[p].lo[k] + tbox[p].hi[k]);
+  std::vector<uint32_t> right_part(n);
+  out.clear();
+  out.reserve(n);
+  struct Work { uint32_t lo, hi; int32_t node; };
+  std::vector<Work> todo;
+  out.push_back({0, n - 1, 0, 0});
+  todo.push_back({0, n - 1, 0});
+  struct Bin { Box box; uint32_t count; };
+  while (!todo.empty()) {
+    const Work w = todo.back();
+    todo.pop_back();
+    const uint32_t count = w.hi - w.lo + 1u;
+    uint32_t last_left;   // last position of the left part
+    if (count <= (uint32_t)kLeafMax && w.node != 0) {
+      last_left = w.lo;   // a leaf range: chain, no reordering
+    } else {
+      float cl[3], ch[3];
+      for (int k = 0; k < 3; ++k) { cl[k] = std::numeric_limits<float>::infinity(); ch[k] = -cl[k]; }
+      for (uint32_t i = w.lo; i <= w.hi; ++i) {
+        const float* c = &ctr[(size_t)ord[i] * 3];
+        for (int k = 0; k < 3; ++k) { cl[k] = cl[k] < c[k] ? cl[k] : c[k]; ch[k] = ch[k] > c[k] ? ch[k] : c[k]; }
+      }
+      float best_cost = std::numeric_limits<float>::infinity();
+      int best_axis = -1, best_bin = 0;
+      for (int k = 0; k < 3; ++k) {
+        if (!(ch[k] > cl[k])) continue;
+        const float scale = (float)kSahBins / (ch[k] - cl[k]);
+        Bin bins[kSahBins];
+        for (Bin& b : bins) { b.box = empty_box(); b.count = 0; }
+        for (uint32_t i = w.lo; i <= w.hi; ++i) {
+          const uint32_t p = ord[i];
+          int j = (int)((ctr[(size_t)p * 3 + k] - cl[k]) * scale);
+          j = j > kSahBins - 1 ? kSahBins - 1 : j;
+          bins[j].count++;
+          grow(bins[j].box, tbox[p]);
+        }
+        float suffix_area[kSahBins];
+        uint32_t suffix_count[kSahBins];
+        Box acc = empty_box();
+        uint32_t cnt = 0;
+        for (int j = kSahBins - 1; j >= 1; --j) {
+          cnt += bins[j].count;
+          grow(acc, bins[j].box);
+          suffix_count[j] = cnt;
+          suffix_area[j] = cnt ? box_half_area(acc) : 0.0f;
+        }
+        acc = empty_box();
+        cnt = 0;
+        for (int j = 0; j + 1 < kSahBins; ++j) {
+          cnt += bins[j].count;
+          grow(acc, bins[j].box);
+          if (cnt == 0 || suffix_count[j + 1] == 0) continue;
+          const float cost = box_half_area(acc) * (float)cnt + suffix_area[j + 1] * (float)suffix_count[j + 1];
+          if (cost < best_cost) { best_cost = cost; best_axis = k; best_bin = j; }
+        }
+      }
+      if (best_axis < 0) {
+        last_left = w.lo + (w.hi - w.lo) / 2;
+      } else {
+        const float scale = (float)kSahBins / (ch[best_axis] - cl[best_axis]);
+        uint32_t nl = 0, nr = 0;
+        for (uint32_t i = w.lo; i <= w.hi; ++i) {
+          const uint32_t p = ord[i];
+          int j = (int)((ctr[(size_t)p * 3 + best_axis] - cl[best_axis]) * scale);
+          j = j > kSahBins - 1 ? kSahBins - 1 : j;
+          if (j <= best_bin) ord[w.lo + nl++] = p; else right_part[nr++] = p;
+        }
+        std::copy(right_part.begin(), right_part.begin() + nr, ord.begin() + w.lo + nl);
+        last_left = w.lo + nl - 1;
+      }
+    }
+    auto link = [&](uint32_t lo, uint32_t hi) -> int32_t {
+      if (lo == hi) return ~(int32_t)lo;
+      const int32_t id = (int32_t)out.size();
+      out.push_back({lo, hi, 0, 0});
+      todo.push_back({lo, hi, id});
+      return id;
+    };
+    const int32_t l = link(w.lo, last_left), r = link(last_left + 1, w.hi);
+    out[(size_t)w.node].left = l;
+    out[(size_t)w.node].right = r;
+  }
+}
+
 inline int32_t leaf_code(uint32_t first, uint32_t count) { return (int32_t) ~(first | ((count - 1u) << 28)); }
 
 }  // namespace
@@ -231,9 +284,9 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
   }
   const uint32_t n = (uint32_t)nt;
   B.n_tris = n;
-  // ---- triangle boxes, Morton keys ----------------------------------------------------------------
+  // ---- triangle boxes, scene bounds ------------------------------------------------------------------
   std::vector<Box> tbox(n);
-  Box cb = empty_box(), sb = empty_box();
+  Box sb = empty_box();
   for (uint32_t p = 0; p < n; ++p) {
     Box b = empty_box();
     for (int c = 0; c < 3; ++c) {
@@ -242,29 +295,16 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
     }
     tbox[p] = b;
     grow(sb, b);
-    Box c1;
-    for (int k = 0; k < 3; ++k) c1.lo[k] = c1.hi[k] = 0.5f * (b.lo[k] + b.hi[k]);
-    grow(cb, c1);
   }
-  float ext[3];
-  for (int k = 0; k < 3; ++k) { ext[k] = cb.hi[k] - cb.lo[k]; if (!(ext[k] > 1e-30f)) ext[k] = 1e-30f; }
   float diag = sb.hi[0] - sb.lo[0];
   if (sb.hi[1] - sb.lo[1] > diag) diag = sb.hi[1] - sb.lo[1];
   if (sb.hi[2] - sb.lo[2] > diag) diag = sb.hi[2] - sb.lo[2];
   B.ray_eps = 1e-4f * (diag > 1e-6f ? diag : 1e-6f);
-  std::vector<uint64_t> keys(n);
-  for (uint32_t p = 0; p < n; ++p) {
-    const Box& b = tbox[p];
-    const uint32_t qx = quantize10(0.5f * (b.lo[0] + b.hi[0]), cb.lo[0], ext[0]);
-    const uint32_t qy = quantize10(0.5f * (b.lo[1] + b.hi[1]), cb.lo[1], ext[1]);
-    const uint32_t qz = quantize10(0.5f * (b.lo[2] + b.hi[2]), cb.lo[2], ext[2]);
-    const uint32_t morton = (spread10(qx) << 2) | (spread10(qy) << 1) | spread10(qz);
-    keys[p] = ((uint64_t)morton << 32) | p;
-  }
-  std::sort(keys.begin(), keys.end());
+  std::vector<uint32_t> ord(n);        // position in BVH order → original primitive id (partitioned by the build)
+  for (uint32_t p = 0; p < n; ++p) ord[p] = p;
   // triangle record of sorted position i: (v0, prim id) (e1, class) (e2, 0); emitted below in node order
   auto tri_record = [&](uint32_t i, float* o) {
-    const uint32_t p = (uint32_t)(keys[i] & 0xffffffffu);
+    const uint32_t p = ord[i];
     const float* a = B.wverts[B.widx[p * 3 + 0]].position;
     const float* b = B.wverts[B.widx[p * 3 + 1]].position;
     const float* c = B.wverts[B.widx[p * 3 + 2]].position;
@@ -275,7 +315,7 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
     o[8] = c[0] - a[0]; o[9] = c[1] - a[1]; o[10] = c[2] - a[2]; o[11] = 0.0f;
   };
   // ---- hierarchy --------------------------------------------------------------------------------------
-  // Binary radix tree (Karras) → subtrees of <= kLeafMax triangles collapse into leaves → 4-wide collapse,
+  // Binary tree by binned surface-area splits → ranges of <= kLeafMax triangles are leaves → 4-wide collapse,
   // greedy by surface area: a node starts from its two binary children and keeps replacing the interior
   // child with the largest half-area (ties: lowest slot) by that child's two children, in place, until it
   // has 4 children or only leaves are left.
@@ -291,25 +331,21 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
   // Layout: breadth-first until `nodelet_budget` nodes exist (the trace kernels stage those in LDS), then
   // depth-first, always allocating a node's children as one block.
   struct WChild { bool leaf; uint32_t lo, hi; int32_t radix; Box box; };
-  std::vector<RadixNode> radix;
+  std::vector<SplitNode> radix;
   std::vector<Box> radix_box;
   auto range_box = [&](uint32_t lo, uint32_t hi) {
     Box b = empty_box();
-    for (uint32_t i = lo; i <= hi; ++i) grow(b, tbox[(uint32_t)(keys[i] & 0xffffffffu)]);
+    for (uint32_t i = lo; i <= hi; ++i) grow(b, tbox[ord[i]]);
     return b;
   };
   auto child_of = [&](int32_t link) {
     WChild c;
     if (link < 0) { c.leaf = true; c.lo = c.hi = (uint32_t)~link; c.radix = -1; c.box = range_box(c.lo, c.hi); return c; }
-    const RadixNode& r = radix[(size_t)link];
+    const SplitNode& r = radix[(size_t)link];
     c.lo = r.lo; c.hi = r.hi; c.radix = link;
     c.leaf = (r.hi - r.lo + 1u) <= (uint32_t)kLeafMax;
     c.box = radix_box[(size_t)link];
     return c;
-  };
-  auto half_area = [](const Box& b) {
-    const float ex = b.hi[0] - b.lo[0], ey = b.hi[1] - b.lo[1], ez = b.hi[2] - b.lo[2];
-    return ex * ey + ey * ez + ez * ex;
   };
   struct Wide { WChild kid[4]; int n; };
   auto expand = [&](int32_t r) {
@@ -321,11 +357,11 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
       int best = -1; float besta = 0.0f;
       for (int i = 0; i < w.n; ++i) {
         if (w.kid[i].leaf) continue;
-        const float a = half_area(w.kid[i].box);
+        const float a = box_half_area(w.kid[i].box);
         if (best < 0 || a > besta) { best = i; besta = a; }
       }
       if (best < 0) break;
-      const RadixNode& rn = radix[(size_t)w.kid[best].radix];
+      const SplitNode& rn = radix[(size_t)w.kid[best].radix];
       for (int j = w.n; j > best + 1; --j) w.kid[j] = w.kid[j - 1];
       const WChild l = child_of(rn.left), rr = child_of(rn.right);
       w.kid[best] = l; w.kid[best + 1] = rr;
@@ -374,18 +410,18 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
     for (int k = 0; k < 2; ++k) { w.kid[k].leaf = true; w.kid[k].lo = w.kid[k].hi = 0; w.kid[k].radix = -1; w.kid[k].box = range_box(0, 0); }
     order.push_back({-1, 0}); wide.push_back(w); child_base.push_back(1);
   } else {
-    build_radix_tree(keys, radix);
+    build_split_tree(tbox, ord, radix);
     // boxes of all radix nodes, bottom-up (iterative post-order)
     radix_box.assign(radix.size(), empty_box());
     {
       std::vector<std::pair<int32_t, int>> stk{{0, 0}};
       while (!stk.empty()) {
         auto& top = stk.back();
-        const RadixNode& r = radix[(size_t)top.first];
+        const SplitNode& r = radix[(size_t)top.first];
         if (top.second == 0) { top.second = 1; if (r.left >= 0) { stk.push_back({r.left, 0}); continue; } }
         if (top.second == 1) { top.second = 2; if (r.right >= 0) { stk.push_back({r.right, 0}); continue; } }
-        Box b = r.left < 0 ? tbox[(uint32_t)(keys[(size_t)~r.left] & 0xffffffffu)] : radix_box[(size_t)r.left];
-        grow(b, r.right < 0 ? tbox[(uint32_t)(keys[(size_t)~r.right] & 0xffffffffu)] : radix_box[(size_t)r.right]);
+        Box b = r.left < 0 ? tbox[ord[(size_t)~r.left]] : radix_box[(size_t)r.left];
+        grow(b, r.right < 0 ? tbox[ord[(size_t)~r.right]] : radix_box[(size_t)r.right]);
         radix_box[(size_t)top.first] = b;
         stk.pop_back();
       }

@@ -162,9 +162,10 @@ def test_edge_cases(gpu, ora):
 
 
 def test_deep_tree_uses_stack_overflow(gpu, ora):
-    """A deep LBVH (one far triangle per Morton bit + 6000 coincident triangles whose keys differ only in the
-    primitive id: binary depth 40, 4-wide depth 18) traversed with only 2 stack entries in LDS, so that most
-    pushes go through the global overflow slab — still bit-exact, path tracer and raster-compat alike."""
+    """6000 coincident triangles (every box overlaps every other: a ray through them enters all children of
+    all nodes, 3 pushes per visit) plus triangles at exponentially spaced distances, traversed with only 2
+    stack entries in LDS and with the default stack, so that most pushes go through the global overflow slab —
+    still bit-exact, path tracer and raster-compat alike.  The second camera sits in front of the cluster."""
     sc = gpu.scene
     cents = [(1024.0, 1024.0, 1024.0)]
     for k in range(10):
@@ -178,18 +179,22 @@ def test_deep_tree_uses_stack_overflow(gpu, ora):
     v = np.zeros(3 * n, sc.MESH_VERTEX)
     v["position"], v["normal"], v["tangent"] = pos, (0, 0, 1), (1, 0, 0, 1)
     emis = sc.Material((0.6, 0.6, 0.6, 1), 0.0, 1.0, (1.0, 1.0, 1.0))
-    d = sc.SceneDesc([emis], [sc.MeshDesc(v, np.arange(3 * n, dtype=np.uint32), 0)], [sc.InstanceDesc(0, (0, 0, 0), (1, 0, 0, 0), (1, 1, 1))],
-                     sc.CameraDesc((0.0, 0.0, 3.0), (0, 0, 0), 0.2, 1.0))
-    os.environ["PTC_STACK_LDS"] = "2"
-    try:
-        pt, o = _pair(gpu, ora, d)
-    finally:
-        del os.environ["PTC_STACK_LDS"]
-    assert pt.stats()["bvh_max_depth"] >= 15 and pt.stats()["bvh_max_depth"] == o.stats()["bvh_max_depth"]
-    for integ, spp in ((1, 1), (0, 2)):
-        g, c2 = pt.render(64, 64, spp, seed=2, max_bounces=2, integrator=integ), o.render(64, 64, spp, seed=2, max_bounces=2, integrator=integ)
-        assert _bits_equal(g, c2)
-        assert pt.stats()["node_visits_closest"] == o.stats()["node_visits_closest"] and pt.stats()["node_visits_any"] == o.stats()["node_visits_any"]
+    for cam_z, stack_lds in ((3.0, "2"), (0.9, "2"), (0.9, None)):
+        d = sc.SceneDesc([emis], [sc.MeshDesc(v, np.arange(3 * n, dtype=np.uint32), 0)], [sc.InstanceDesc(0, (0, 0, 0), (1, 0, 0, 0), (1, 1, 1))],
+                         sc.CameraDesc((0.0, 0.0, cam_z), (0, 0, 0), 0.2, 1.0))
+        if stack_lds:
+            os.environ["PTC_STACK_LDS"] = stack_lds
+        try:
+            pt, o = _pair(gpu, ora, d)
+        finally:
+            os.environ.pop("PTC_STACK_LDS", None)
+        assert pt.stats()["bvh_max_depth"] >= 10 and pt.stats()["bvh_max_depth"] == o.stats()["bvh_max_depth"]
+        for integ, spp in ((1, 1), (0, 2)):
+            g, c2 = pt.render(64, 64, spp, seed=2, max_bounces=2, integrator=integ), o.render(64, 64, spp, seed=2, max_bounces=2, integrator=integ)
+            assert _bits_equal(g, c2)
+            assert pt.stats()["node_visits_closest"] == o.stats()["node_visits_closest"] and pt.stats()["node_visits_any"] == o.stats()["node_visits_any"]
+            if cam_z < 1.0:
+                assert o.stats()["tri_tests_closest"] > 6000 * 500      # the cluster really is traversed exhaustively
 
 
 def test_sharding_and_batching_do_not_change_bits(gpu):
