@@ -189,6 +189,13 @@ int ptc_debug_trace_any(ptc_ctx*, const float* origins, const float* dirs, const
 int ptc_debug_get_flat_scene(ptc_ctx*, uint32_t* n_verts, uint32_t* n_tris, ptc_vertex* verts,
                              uint32_t* indices, int32_t* tri_material);
 
+/* The scene description as received (valid from ptc_scene_begin on, committed or not): number of materials and
+ * textures; material i as 12 values (base rgba, metallic, roughness, emissive rgb as floats; tex_color, tex_normal,
+ * tex_mr as ints); texture i's size and, when rgba is non-NULL, its w*h*4 bytes. */
+int ptc_debug_get_description(ptc_ctx*, int* n_materials, int* n_textures);
+int ptc_debug_get_material(ptc_ctx*, int index, float out_factors[9], int out_textures[3]);
+int ptc_debug_get_texture(ptc_ctx*, int index, int* w, int* h, uint8_t* rgba);
+
 /* Raw device counter array of the current frame (segments, shadow rays, hits, node/triangle counts, then the
  * loop-iteration diagnostics a -DPT_DIAG build fills).  Returns the number of counters the library keeps. */
 int ptc_debug_get_counters(ptc_ctx*, uint64_t* out, int n);

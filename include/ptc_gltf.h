@@ -2,7 +2,11 @@
  *
  * Replaces, for the path tracer, gltf::Loader::loadAsset + Asset::loadScene
  * (src/pbr_engine/gltf/pbr/gltf/Loader.hpp:20-21, Asset.hpp:76-78): reads a .gltf / .glb file and issues the
- * ptc_add_material / ptc_add_mesh / ptc_add_instance_matrix calls of include/ptc.h on `ctx`.
+ * ptc_add_texture_rgba8 / ptc_add_material / ptc_add_mesh / ptc_add_instance_matrix calls of include/ptc.h on `ctx`.
+ * Images (Asset::loadImage2D, Asset.cpp:121-133; bufferView, file URI or base64 data URI) are decoded to RGBA8 like
+ * image::loadImage2D does (LoadImage.cpp:56-73: 4 channels of 8 bits whatever the file holds); PNG only — the reference
+ * decodes with its vendored stb_image, which is not part of this library.  Samplers are ignored: the reference creates
+ * default samplers (NEAREST, REPEAT) whatever the asset says (Asset.cpp:116-117).
  * Call between ptc_scene_begin and ptc_scene_commit; the camera stays the caller's (the reference ignores glTF
  * cameras too and injects its own, Asset.cpp:262-265).  Host-only: works on a PTC_DEVICE_NONE context.
  */
@@ -19,6 +23,12 @@ extern "C" {
  * Returns the number of triangles instanced (>= 0) or a negative PTC_E_* code. */
 long long ptc_gltf_load(ptc_ctx* ctx, const char* path, int scene_index, int compose_parents, float bbox6[6],
                         char* err, int err_len);
+
+/* PNG file image (any colour type / bit depth / interlacing) → w*h*4 bytes RGBA8, row 0 on top; the decoder the loader
+ * uses for glTF images (replaces stbi_load_from_memory(..., STBI_rgb_alpha), LoadImage.cpp:56-73).  out may be NULL to
+ * query the size only.  Returns 0 or a negative PTC_E_* code with the text in err. */
+int ptc_png_decode_rgba8(const unsigned char* data, unsigned long long n, unsigned char* out, unsigned long long out_capacity,
+                         int* w, int* h, char* err, int err_len);
 
 #ifdef __cplusplus
 }

@@ -688,6 +688,32 @@ int ptc_debug_get_flat_scene(ptc_ctx* c, uint32_t* n_verts, uint32_t* n_tris, pt
   return PTC_OK;
 }
 
+int ptc_debug_get_description(ptc_ctx* c, int* n_materials, int* n_textures) {
+  if (!c) return PTC_E_ARG;
+  if (n_materials) *n_materials = (int)c->mats.size();
+  if (n_textures) *n_textures = (int)c->texs.size();
+  return PTC_OK;
+}
+
+int ptc_debug_get_material(ptc_ctx* c, int index, float out_factors[9], int out_textures[3]) {
+  if (!c) return PTC_E_ARG;
+  if (index < 0 || (size_t)index >= c->mats.size() || !out_factors || !out_textures) return fail(c, PTC_E_ARG, "debug_get_material: bad argument");
+  const HostMaterial& m = c->mats[(size_t)index];
+  std::memcpy(out_factors, m.base, 16); out_factors[4] = m.metallic; out_factors[5] = m.roughness; std::memcpy(out_factors + 6, m.emissive, 12);
+  out_textures[0] = m.tex_color; out_textures[1] = m.tex_normal; out_textures[2] = m.tex_mr;
+  return PTC_OK;
+}
+
+int ptc_debug_get_texture(ptc_ctx* c, int index, int* w, int* h, uint8_t* rgba) {
+  if (!c) return PTC_E_ARG;
+  if (index < 0 || (size_t)index >= c->texs.size()) return fail(c, PTC_E_ARG, "debug_get_texture: bad argument");
+  const HostTexture& t = c->texs[(size_t)index];
+  if (w) *w = t.w;
+  if (h) *h = t.h;
+  if (rgba) std::memcpy(rgba, t.px.data(), t.px.size());
+  return PTC_OK;
+}
+
 int ptc_debug_get_counters(ptc_ctx* c, uint64_t* out, int n) {
   if (!c) return PTC_E_ARG;
   if (c->device < 0) return fail(c, PTC_E_DEVICE, "this context has no device (PTC_DEVICE_NONE): the call needs a gfx950 GPU; there is no CPU path");

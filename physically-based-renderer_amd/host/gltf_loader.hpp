@@ -4,13 +4,19 @@
 //   gltf::Loader::loadAsset   src/pbr_engine/gltf/pbr/gltf/Loader.cpp:10-32   options LoadExternalBuffers |
 //                             DecomposeNodeMatrices | GenerateMeshIndices (:19-21)
 //   Asset::loadPrimitive      src/pbr_engine/gltf/pbr/gltf/Asset.cpp:162-208   POSITION, NORMAL, TANGENT, TEXCOORD_0, indices
-//   Asset::loadMaterial       Asset.cpp:135-160                                  baseColorFactor (+ here metallic, roughness, emissive)
+//   Asset::loadMaterial       Asset.cpp:135-160                                  baseColorFactor, baseColorTexture, normalTexture
+//                                                                                (+ here metallic, roughness, emissive, metallicRoughnessTexture)
+//   Asset::loadImage2D        Asset.cpp:121-133, ImageDataSourceVisitor :58-101  images from a bufferView or a URI, decoded to RGBA8
+//                                                                                (LoadImage.cpp:56-73); samplers are default-constructed
+//                                                                                (:116-117: NEAREST, REPEAT) whatever the asset says
 //   Asset::loadNode/loadScene Asset.cpp:236-273                                  TRS per node, quaternion (w,x,y,z)
 // Deliberate deviations: indices are u32 (reference truncates to u16); missing NORMAL / TANGENT /
 // TEXCOORD_0 / indices / material get defaults instead of throwing; parent transforms are composed (the reference
 // draws each node with its local TRS — `compose_parents = false` reproduces that); objects are keyed by index.
 #pragma once
 #include <ptc.h>
+
+#include "png_decode.hpp"
 
 #include <array>
 #include <cmath>
@@ -136,10 +142,12 @@ private:
 };
 
 // ---- flat result ------------------------------------------------------------------------------------
-struct Material { float base_color[4] = {1, 1, 1, 1}; float metallic = 1.0f, roughness = 1.0f; float emissive[3] = {0, 0, 0}; };
+struct Material { float base_color[4] = {1, 1, 1, 1}; float metallic = 1.0f, roughness = 1.0f; float emissive[3] = {0, 0, 0}; int tex_color = -1, tex_normal = -1, tex_mr = -1; };   // tex_*: index into FlatScene::textures
+struct Texture { int w = 0, h = 0; std::vector<std::uint8_t> rgba; };
 struct Primitive { std::vector<ptc_vertex> vertices; std::vector<std::uint32_t> indices; int material = 0; };
 struct Instance { int primitive; std::array<float, 16> model; };   // column-major
 struct FlatScene {
+  std::vector<Texture> textures;        // decoded images, one per glTF image that a material references (first-use order)
   std::vector<Material> materials;      // glTF materials in index order, plus a trailing default one if any primitive needs it
   std::vector<Primitive> primitives;    // one per glTF mesh primitive, mesh order then primitive order
   std::vector<Instance> instances;      // scene traversal order (depth-first, children before the node's own mesh — Scene.cpp:77-82)
@@ -326,6 +334,45 @@ inline FlatScene load(const std::string& path, int scene_index = -1, bool compos
   using namespace detail;
   const Doc d = open(path);
   FlatScene out;
+  // ---- images (Asset::loadImage2D): decoded on first use by a material, cached by image index ----
+  const std::string dir = dir_of(path);
+  std::vector<int> image_slot(d.root.array("images").size(), -1);
+  auto texture_of = [&](const JValue* info) -> int {
+    if (!info) return -1;
+    if (info->integer("texCoord", 0) != 0) throw std::runtime_error("only TEXCOORD_0 is supported (textureInfo.texCoord != 0)");
+    const long ti = info->integer("index", -1);
+    const auto& textures = d.root.array("textures");
+    if (ti < 0 || (size_t)ti >= textures.size()) throw std::runtime_error("texture index out of range");
+    const long ii = textures[(size_t)ti].integer("source", -1);
+    if (ii < 0 || (size_t)ii >= image_slot.size()) throw std::runtime_error("texture without a valid image source");
+    if (image_slot[(size_t)ii] >= 0) return image_slot[(size_t)ii];
+    const JValue& img = d.root.array("images")[(size_t)ii];
+    std::vector<std::uint8_t> owned;
+    const std::uint8_t* bytes = nullptr; size_t nbytes = 0;
+    if (const JValue* bv = img.get("bufferView")) {
+      const auto& views = d.root.array("bufferViews");
+      if (bv->type != JValue::Num || bv->num < 0 || (size_t)bv->num >= views.size()) throw std::runtime_error("image bufferView out of range");
+      const JValue& v = views[(size_t)bv->num];
+      const long bi = v.integer("buffer", -1), off = v.integer("byteOffset", 0), len = v.integer("byteLength", 0);
+      if (bi < 0 || (size_t)bi >= d.buffers.size() || off < 0 || len < 0 || (size_t)off + (size_t)len > d.buffers[(size_t)bi].size()) throw std::runtime_error("image bufferView exceeds its buffer");
+      bytes = d.buffers[(size_t)bi].data() + off; nbytes = (size_t)len;
+    } else {
+      const std::string uri = img.string("uri");
+      if (uri.empty()) throw std::runtime_error("image without bufferView or uri");
+      if (uri.rfind("data:", 0) == 0) {
+        const size_t k = uri.find("base64,");
+        if (k == std::string::npos) throw std::runtime_error("only base64 data: URIs are supported");
+        owned = base64(uri.substr(k + 7));
+      } else owned = read_file(dir + uri);
+      bytes = owned.data(); nbytes = owned.size();
+    }
+    Texture t;
+    if (pbr::image::is_png(bytes, nbytes)) t.rgba = pbr::image::decode_png(bytes, nbytes, t.w, t.h);
+    else if (nbytes >= 2 && bytes[0] == 0xFF && bytes[1] == 0xD8) throw std::runtime_error("image " + std::to_string(ii) + " is a JPEG: only PNG images are decoded");
+    else throw std::runtime_error("image " + std::to_string(ii) + " is not a PNG");
+    out.textures.push_back(std::move(t));
+    return image_slot[(size_t)ii] = (int)out.textures.size() - 1;
+  };
   // ---- materials (Asset::loadMaterial + the metal-rough / emissive factors the reference ignores) ----
   for (const JValue& m : d.root.array("materials")) {
     Material o;
@@ -340,6 +387,11 @@ inline FlatScene load(const std::string& path, int scene_index = -1, bool compos
     if (const JValue* ext = m.get("extensions"))
       if (const JValue* es = ext->get("KHR_materials_emissive_strength")) strength = (float)es->number("emissiveStrength", 1.0);
     for (size_t k = 0; k < 3 && k < em.size(); ++k) o.emissive[k] = (float)em[k].num * strength;
+    if (const JValue* pbr = m.get("pbrMetallicRoughness")) {
+      o.tex_color = texture_of(pbr->get("baseColorTexture"));
+      o.tex_mr = texture_of(pbr->get("metallicRoughnessTexture"));
+    }
+    o.tex_normal = texture_of(m.get("normalTexture"));
     out.materials.push_back(o);
   }
   int default_material = -1;
@@ -473,9 +525,15 @@ inline FlatScene load(const std::string& path, int scene_index = -1, bool compos
 
 // Issue the C-ABI calls for a loaded scene (between ptc_scene_begin and ptc_scene_commit).  Returns the first error code.
 inline int upload(ptc_ctx* ctx, const FlatScene& s) {
-  std::vector<int> mat_id, mesh_id;
+  std::vector<int> tex_id, mat_id, mesh_id;
+  for (const Texture& t : s.textures) {
+    const int id = ptc_add_texture_rgba8(ctx, t.rgba.data(), t.w, t.h);
+    if (id < 0) return id;
+    tex_id.push_back(id);
+  }
+  auto tex = [&](int k) { return k < 0 ? -1 : tex_id[(size_t)k]; };
   for (const Material& m : s.materials) {
-    const int id = ptc_add_material(ctx, m.base_color, m.metallic, m.roughness, m.emissive, -1, -1, -1);
+    const int id = ptc_add_material(ctx, m.base_color, m.metallic, m.roughness, m.emissive, tex(m.tex_color), tex(m.tex_normal), tex(m.tex_mr));
     if (id < 0) return id;
     mat_id.push_back(id);
   }

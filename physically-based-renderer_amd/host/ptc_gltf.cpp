@@ -4,6 +4,7 @@
 #include <ptc_gltf.h>
 
 #include <cstdio>
+#include <cstring>
 
 extern "C" long long ptc_gltf_load(ptc_ctx* ctx, const char* path, int scene_index, int compose_parents, float bbox6[6], char* err, int err_len) {
   auto say = [&](const std::string& m) { if (err && err_len > 0) std::snprintf(err, (size_t)err_len, "%s", m.c_str()); };
@@ -16,6 +17,22 @@ extern "C" long long ptc_gltf_load(ptc_ctx* ctx, const char* path, int scene_ind
     return (long long)s.n_triangles;
   } catch (std::exception const& e) {
     say(std::string("ptc_gltf_load: ") + e.what());
+    return PTC_E_ARG;
+  }
+}
+
+extern "C" int ptc_png_decode_rgba8(const unsigned char* data, unsigned long long n, unsigned char* out, unsigned long long out_capacity, int* w, int* h, char* err, int err_len) {
+  auto say = [&](const std::string& m) { if (err && err_len > 0) std::snprintf(err, (size_t)err_len, "%s", m.c_str()); };
+  if (!data || !w || !h) { say("ptc_png_decode_rgba8: null argument"); return PTC_E_ARG; }
+  try {
+    const std::vector<std::uint8_t> px = pbr::image::decode_png(data, (std::size_t)n, *w, *h);
+    if (out) {
+      if (out_capacity < px.size()) { say("ptc_png_decode_rgba8: output buffer too small"); return PTC_E_ARG; }
+      std::memcpy(out, px.data(), px.size());
+    }
+    return PTC_OK;
+  } catch (std::exception const& e) {
+    say(std::string("ptc_png_decode_rgba8: ") + e.what());
     return PTC_E_ARG;
   }
 }

@@ -13,6 +13,7 @@ import ctypes as C
 import json
 import os
 import struct
+import zlib
 
 import numpy as np
 
@@ -35,9 +36,10 @@ def _load():
     return _lib
 
 
-def load_into(pt, path: str, camera=None, scene_index: int = -1, compose_parents: bool = True):
+def load_into(pt, path: str, camera=None, scene_index: int = -1, compose_parents: bool = True, env=None):
     """scene_begin → materials/meshes/instances from the file → camera → scene_commit.
-    Returns (n_triangles, bbox_lo, bbox_hi).  camera: CameraDesc, or None to frame the bounding box from +z."""
+    Returns (n_triangles, bbox_lo, bbox_hi).  camera: CameraDesc, or None to frame the bounding box from +z.
+    env: optional (h, w, 3) float32 lat-long environment map (glTF has no such thing; ptc_set_env_latlong_rgb32f)."""
     L = _load()
     h = pt._h
     pt._ck(pt._L.ptc_scene_begin(h))
@@ -54,11 +56,106 @@ def load_into(pt, path: str, camera=None, scene_index: int = -1, compose_parents
         pt.set_camera((c[0], c[1], c[2] + r / np.tan(0.5 * fov) + r), c, float(fov), 1.0)
     else:
         pt.set_camera(camera.position, camera.target, camera.fov_y, camera.aspect)
+    if env is not None:
+        e = np.ascontiguousarray(env, np.float32)
+        assert e.ndim == 3 and e.shape[2] == 3, "env is (h, w, 3) float32"
+        pt._ck(pt._L.ptc_set_env_latlong_rgb32f(h, e.ctypes.data_as(C.POINTER(C.c_float)), e.shape[1], e.shape[0]))
     pt._ck(pt._L.ptc_scene_commit(h))
     return int(n), lo, hi
 
 
+def png_decode(data: bytes) -> np.ndarray:
+    """PNG file image → (h, w, 4) uint8 through the loader's own decoder (ptc_png_decode_rgba8)."""
+    L = _load()
+    L.ptc_png_decode_rgba8.restype = C.c_int
+    L.ptc_png_decode_rgba8.argtypes = [C.c_char_p, C.c_ulonglong, C.c_void_p, C.c_ulonglong, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]
+    w, h = C.c_int(0), C.c_int(0)
+    err = C.create_string_buffer(256)
+    if L.ptc_png_decode_rgba8(data, len(data), None, 0, C.byref(w), C.byref(h), err, 256):
+        raise _ptc.PtcError(err.value.decode())
+    out = np.empty((h.value, w.value, 4), np.uint8)
+    if L.ptc_png_decode_rgba8(data, len(data), out.ctypes.data, out.nbytes, C.byref(w), C.byref(h), err, 256):
+        raise _ptc.PtcError(err.value.decode())
+    return out
+
+
 # ----------------------------------------------------------------------------------------------------
+_ADAM7 = ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2))
+
+
+def png_encode(samples: np.ndarray, color_type: int = 6, depth: int = 8, interlace: bool = False, filters="cycle",
+               level: int = 9, strategy: int = 0, palette=None, trns: bytes = None, idat_split: int = 0) -> bytes:
+    """Small PNG writer for assets and decoder tests.  samples: (h, w, channels) unsigned integers already in the
+    file's sample range (channels = 1, 3, 1, 2, 4 for colour types 0, 2, 3, 4, 6).  filters: "cycle" (row y uses
+    filter y % 5), or a fixed filter type 0..4.  strategy: zlib strategy (zlib.Z_FIXED forces fixed Huffman blocks)."""
+    s = np.asarray(samples)
+    h, w, ch = s.shape
+    assert ch == {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[color_type]
+    bpp = max(1, ch * depth // 8)
+
+    def pack_rows(img):
+        hh, ww, _ = img.shape
+        flat = img.reshape(hh, ww * ch)
+        if depth == 16:
+            return flat.astype(">u2").view(np.uint8).reshape(hh, -1)
+        if depth == 8:
+            return flat.astype(np.uint8)
+        bits = np.zeros((hh, (ww * ch * depth + 7) // 8 * 8), np.uint8)
+        for b in range(depth):
+            bits[:, b : ww * ch * depth : depth] = (flat >> (depth - 1 - b)) & 1
+        return np.packbits(bits, axis=1)
+
+    def paeth(a, b, c):
+        p = a + b - c
+        pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+        return a if pa <= pb and pa <= pc else (b if pb <= pc else c)
+
+    def filtered(rows):
+        out = bytearray()
+        prev = np.zeros(rows.shape[1], np.int32)
+        for y in range(rows.shape[0]):
+            cur = rows[y].astype(np.int32)
+            ft = y % 5 if filters == "cycle" else int(filters)
+            left = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]]) if cur.size > bpp else np.zeros(cur.size, np.int32)
+            ul = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]]) if cur.size > bpp else np.zeros(cur.size, np.int32)
+            if ft == 0:
+                f = cur
+            elif ft == 1:
+                f = cur - left
+            elif ft == 2:
+                f = cur - prev
+            elif ft == 3:
+                f = cur - ((left + prev) >> 1)
+            else:
+                f = cur - np.array([paeth(int(a), int(b), int(c)) for a, b, c in zip(left, prev, ul)], np.int32)
+            out.append(ft)
+            out.extend((f & 255).astype(np.uint8).tobytes())
+            prev = cur
+        return bytes(out)
+
+    if interlace:
+        raw = b"".join(filtered(pack_rows(s[y0::dy, x0::dx])) for x0, y0, dx, dy in _ADAM7 if s[y0::dy, x0::dx].size)
+    else:
+        raw = filtered(pack_rows(s))
+    co = zlib.compressobj(level, zlib.DEFLATED, 15, 8, strategy)
+    z = co.compress(raw) + co.flush()
+
+    def chunk(t: bytes, body: bytes) -> bytes:
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body) & 0xFFFFFFFF)
+
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color_type, 0, 0, 1 if interlace else 0))
+    if palette is not None:
+        out += chunk(b"PLTE", bytes(np.asarray(palette, np.uint8).reshape(-1)))
+    if trns is not None:
+        out += chunk(b"tRNS", bytes(trns))
+    if idat_split:
+        for k in range(0, len(z), idat_split):
+            out += chunk(b"IDAT", z[k : k + idat_split])
+    else:
+        out += chunk(b"IDAT", z)
+    return out + chunk(b"IEND", b"")
+
+
 def _pad4(b: bytes, fill: bytes = b"\x00") -> bytes:
     return b + fill * ((4 - len(b) % 4) % 4)
 
@@ -112,12 +209,21 @@ def write_glb(desc, path: str, index_type: str = "auto", interleaved: bool = Fal
         ia = add_acc(add_view(ib, target=34963), 5123 if use16 else 5125, idx.size, "SCALAR")
         meshes.append({"primitives": [{"attributes": attrs, "indices": ia, "material": int(m.material), "mode": 4}]})
 
+    images = []
+    for t in getattr(desc, "textures", []) or []:   # RGBA8 images embedded as PNG bufferViews, one glTF texture per image
+        images.append({"bufferView": add_view(png_encode(np.ascontiguousarray(t, np.uint8), 6, 8)), "mimeType": "image/png"})
     mats = []
     for m in desc.materials:
         e = [float(x) for x in m.emissive]
         strength = max(1.0, max(e))
         g = {"pbrMetallicRoughness": {"baseColorFactor": [float(x) for x in m.base_color], "metallicFactor": float(m.metallic), "roughnessFactor": float(m.roughness)},
              "emissiveFactor": [x / strength for x in e]}
+        if getattr(m, "tex_color", -1) >= 0:
+            g["pbrMetallicRoughness"]["baseColorTexture"] = {"index": int(m.tex_color)}
+        if getattr(m, "tex_mr", -1) >= 0:
+            g["pbrMetallicRoughness"]["metallicRoughnessTexture"] = {"index": int(m.tex_mr)}
+        if getattr(m, "tex_normal", -1) >= 0:
+            g["normalTexture"] = {"index": int(m.tex_normal)}
         if strength > 1.0:
             g["extensions"] = {"KHR_materials_emissive_strength": {"emissiveStrength": strength}}
         mats.append(g)
@@ -139,6 +245,10 @@ def write_glb(desc, path: str, index_type: str = "auto", interleaved: bool = Fal
         node_list, roots = nodes
     doc = {"asset": {"version": "2.0", "generator": "pbr_amd.gltf.write_glb"}, "scene": 0, "scenes": [{"nodes": list(roots)}], "nodes": node_list,
            "meshes": meshes, "materials": mats, "accessors": accessors, "bufferViews": views, "buffers": [{"byteLength": len(blob)}]}
+    if images:
+        doc["images"] = images
+        doc["samplers"] = [{"magFilter": 9728, "minFilter": 9728, "wrapS": 10497, "wrapT": 10497}]   # NEAREST, REPEAT (what the reference uses regardless)
+        doc["textures"] = [{"source": k, "sampler": 0} for k in range(len(images))]
     if any("extensions" in g for g in mats):
         doc["extensionsUsed"] = ["KHR_materials_emissive_strength"]
     js = _pad4(json.dumps(doc, separators=(",", ":")).encode(), b" ")

@@ -30,6 +30,7 @@ ABI_SYMBOLS = [
     "ptc_frame_begin", "ptc_frame_add_samples", "ptc_frame_resolve", "ptc_sync", "ptc_read_radiance_rgba32f",
     "ptc_radiance_device_ptr", "ptc_write_radiance_rgba32f", "ptc_tonemap_rgba8", "ptc_get_stats",
     "ptc_debug_trace_closest", "ptc_debug_trace_any", "ptc_debug_get_flat_scene", "ptc_debug_get_bvh", "ptc_debug_get_counters",
+    "ptc_debug_get_description", "ptc_debug_get_material", "ptc_debug_get_texture",
 ]
 
 
@@ -98,6 +99,9 @@ def load_library():
     L.ptc_debug_get_flat_scene.argtypes = [vp, u32p, u32p, vp, u32p, i32p]
     L.ptc_debug_get_bvh.argtypes = [vp, u32p, u32p, fp, fp]
     L.ptc_debug_get_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
+    L.ptc_debug_get_description.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.ptc_debug_get_material.argtypes = [vp, C.c_int, fp, C.POINTER(C.c_int)]
+    L.ptc_debug_get_texture.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), vp]
     _lib = L
     return L
 
@@ -236,6 +240,24 @@ class PathTracer:
         self._ck(self._L.ptc_debug_get_flat_scene(self._h, None, None, verts.ctypes.data, idx.ctypes.data_as(C.POINTER(C.c_uint32)),
                                                   tm.ctypes.data_as(C.POINTER(C.c_int32))))
         return verts, idx, tm
+
+    def description(self):
+        """Materials and textures as the context received them: ([(factors9, (tex_color, tex_normal, tex_mr))], [rgba arrays])."""
+        nm, nt = C.c_int(0), C.c_int(0)
+        self._ck(self._L.ptc_debug_get_description(self._h, C.byref(nm), C.byref(nt)))
+        mats, texs = [], []
+        for i in range(nm.value):
+            f = np.zeros(9, np.float32)
+            t = (C.c_int * 3)()
+            self._ck(self._L.ptc_debug_get_material(self._h, i, f.ctypes.data_as(C.POINTER(C.c_float)), t))
+            mats.append((f, tuple(t)))
+        for i in range(nt.value):
+            w, h = C.c_int(0), C.c_int(0)
+            self._ck(self._L.ptc_debug_get_texture(self._h, i, C.byref(w), C.byref(h), None))
+            px = np.zeros((h.value, w.value, 4), np.uint8)
+            self._ck(self._L.ptc_debug_get_texture(self._h, i, C.byref(w), C.byref(h), px.ctypes.data))
+            texs.append(px)
+        return mats, texs
 
     def bvh(self):
         nn, nt = C.c_uint32(), C.c_uint32()

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol(pbr):
     assert sorted(pbr.ptc.ABI_SYMBOLS) == declared
     assert L.ptc_abi_version() == 1
     gl = open(os.path.join(ROOT, "include", "ptc_gltf.h")).read()
-    for sym in set(re.findall(r"\b(ptc_gltf_[a-z0-9_]+)\s*\(", gl)):
+    for sym in set(re.findall(r"\b(ptc_(?:gltf|png)_[a-z0-9_]+)\s*\(", gl)):
         assert hasattr(pbr.gltf._load(), sym), f"libptc_gltf.so does not export {sym}"
     assert C.sizeof(pbr.ptc.PtcStats) == 9 * 8 + 5 * 8 + 6 * 4
 

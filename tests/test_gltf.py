@@ -144,3 +144,68 @@ def test_broken_containers(pbr, tmp_path):
             _flat_glb(pbr, str(tmp_path / name))
     with pytest.raises(pbr.PtcError, match="cannot open"):
         _flat_glb(pbr, str(tmp_path / "missing.glb"))
+
+
+def test_textured_glb_carries_images_and_texture_indices(pbr, tmp_path):
+    """Config-5 material set through a file: RGBA8 textures embedded as PNG bufferViews, baseColorTexture /
+    normalTexture (what Asset::loadMaterial reads, Asset.cpp:147-150) + metallicRoughnessTexture.  The context must
+    receive the same texels and the same material → texture links as when the SceneDesc is handed over directly."""
+    d = pbr.scenes.by_name("textured_objects")
+    assert d.textures and any(m.tex_color >= 0 for m in d.materials) and any(m.tex_normal >= 0 for m in d.materials)
+    p = str(tmp_path / "textured.glb")
+    pbr.gltf.write_glb(d, p)
+    (v1, i1, m1), (n, _, _), pt = _flat_glb(pbr, p, camera=d.camera)
+    ref = pbr.PathTracer(pbr.DEVICE_NONE).load_scene(d)
+    v2, i2, m2 = ref.flat_scene()
+    assert np.array_equal(v1.view(np.uint32), v2.view(np.uint32)) and np.array_equal(i1, i2) and np.array_equal(m1, m2)
+    (mats_a, tex_a), (mats_b, tex_b) = pt.description(), ref.description()
+    assert len(mats_a) == len(mats_b)
+    for (fa, ta), (fb, tb) in zip(mats_a, mats_b):
+        assert np.array_equal(fa, fb)
+        for ka, kb in zip(ta, tb):                       # the loader numbers textures in first-use order: compare the texels
+            assert (ka < 0) == (kb < 0)
+            if ka >= 0:
+                assert np.array_equal(tex_a[ka], tex_b[kb])
+
+
+def test_image_sources_and_errors(pbr, tmp_path):
+    """Images from a bufferView, an external file and a base64 data URI decode alike; JPEG, a second uv set and bad
+    indices are reported."""
+    sc = pbr.scene
+    rng = np.random.default_rng(3)
+    tex = rng.integers(0, 256, (8, 8, 4), dtype=np.uint8)
+    png = pbr.gltf.png_encode(tex, 6, 8)
+    d = sc.SceneDesc([sc.Material(tex_color=0, tex_normal=0)], [_tri_mesh(pbr)], [sc.InstanceDesc(0)], sc.CameraDesc((0, 0, 5), (0, 0, 0), 1.0, 1.0), textures=[tex])
+    glb = str(tmp_path / "a.glb")
+    pbr.gltf.write_glb(d, glb)
+    # re-express the GLB as .gltf + external .bin, then vary the image source
+    raw = open(glb, "rb").read()
+    jlen = struct.unpack("<I", raw[12:16])[0]
+    doc = json.loads(raw[20 : 20 + jlen])
+    blob = raw[20 + jlen + 8 :]
+    (tmp_path / "a.bin").write_bytes(blob)
+    (tmp_path / "tex.png").write_bytes(png)
+    doc["buffers"][0]["uri"] = "a.bin"
+
+    def load(mut):
+        j = json.loads(json.dumps(doc))
+        mut(j)
+        q = str(tmp_path / "v.gltf")
+        open(q, "w").write(json.dumps(j))
+        pt = pbr.PathTracer(pbr.DEVICE_NONE)
+        pbr.gltf.load_into(pt, q, camera=d.camera)
+        return pt.description()
+
+    for mut in (lambda j: None,
+                lambda j: j["images"].__setitem__(0, {"uri": "tex.png"}),
+                lambda j: j["images"].__setitem__(0, {"uri": "data:image/png;base64," + base64.b64encode(png).decode()})):
+        mats, texs = load(mut)
+        assert len(texs) == 1 and np.array_equal(texs[0], tex) and mats[0][1] == (0, 0, -1)   # one image, shared by both slots
+    (tmp_path / "tex.jpg").write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 32)
+    for mut, msg in ((lambda j: j["images"].__setitem__(0, {"uri": "tex.jpg"}), "JPEG"),
+                     (lambda j: j["materials"][0]["normalTexture"].__setitem__("texCoord", 1), "TEXCOORD_0"),
+                     (lambda j: j["materials"][0]["normalTexture"].__setitem__("index", 5), "texture index out of range"),
+                     (lambda j: j["textures"][0].__setitem__("source", 3), "image source"),
+                     (lambda j: j["images"].__setitem__(0, {"uri": "a.bin"}), "not a PNG")):
+        with pytest.raises(pbr.PtcError, match=msg):
+            load(mut)

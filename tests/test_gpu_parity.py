@@ -284,6 +284,20 @@ def test_cpp_host_cli(gpu, ora, tmp_path):
     assert bad.returncode == 1 and "unknown scene" in bad.stderr
 
 
+def test_textured_gltf_renders_identically(gpu, ora, tmp_path):
+    """§8f-1 + §8f-3 together: textures that travelled as PNG images inside a GLB (deflate → own decoder → RGBA8,
+    like the reference's stb path) give the same picture, bit for bit, as the oracle fed with the arrays."""
+    d = gpu.scenes.by_name("textured_objects")
+    p = str(tmp_path / "t.glb")
+    gpu.gltf.write_glb(d, p)
+    pt = gpu.PathTracer(0)
+    n, _, _ = gpu.gltf.load_into(pt, p, camera=d.camera, env=d.env)   # a GLB carries no environment: handed over beside it
+    assert n == d.n_triangles
+    a = pt.render(96, 96, 4, seed=11, max_bounces=4)
+    ref = ora.Oracle().load_scene(d).render(96, 96, 4, seed=11, max_bounces=4)
+    assert _bits_equal(a, ref) and float(ref[..., :3].sum()) > 0.0
+
+
 def test_gltf_loaded_scene_renders_identically(gpu, ora, tmp_path):
     """§8f-1: a scene that went through the GLB writer and the C++ glTF loader renders bit for bit like the same
     SceneDesc handed to the C-ABI directly (and like the oracle); the CLI takes the same file."""
