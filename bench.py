@@ -11,9 +11,12 @@ resident in HBM before the timed region.
 Contract: W untimed warm-up steps, then exactly K timed steps bracketed by barrier +
 torch.cuda.synchronize() on both sides, MAX over ranks, rank 0 prints ONE JSON line.
 N > 1: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`; one process per
-GPU, 32×32-pixel tiles interleaved over ranks (strong scaling: the frame is fixed), and the single
-collective of the path — the RCCL fp32 sum of the framebuffer onto rank 0 — is inside the timed
-region.
+GPU, 32×32-pixel tiles interleaved over ranks, and the single collective of the path — the RCCL fp32
+sum of the framebuffer onto rank 0 — is inside the timed region.  Scaling is WEAK by default (SURVEY
+§8e, the path partitions by tile with no data-path exchange): a step adds `spp-per-step × N` samples, so
+every rank keeps the N=1 batch size (its 1/N of the pixels × N× the samples) and the job renders
+1024·N spp of the frame; `--scaling strong` keeps the 1024-spp frame fixed instead (per-rank batches
+shrink by N).
 
 Extra objects on the JSON line:
   roofline     dominant kernel k_trace_closest: algorithmic bytes (counted node visits × 48 B +
@@ -52,6 +55,10 @@ def main():
                          "albedo/normal/metal-rough textures and a 2048x1024 environment light")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the bounded CPU-baseline render")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --share-device rehearses N ranks on a one-GPU box")
+    ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = every step adds spp-per-step x N samples (per-GPU batch as at N=1); strong = the 1024-spp frame is fixed")
     args = ap.parse_args()
 
     import numpy as np
@@ -67,15 +74,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run); got {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the path tracer is HIP-only (no CPU fallback)")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     desc = scenes.atrium(args.scene_scale) if args.workload == "atrium" else scenes.textured_atrium(args.scene_scale)
     desc.camera.aspect = args.width / args.height
     pt = pbr_amd.PathTracer(local_rank).load_scene(desc)
-    K, W, S = args.steps, args.warmup, args.spp_per_step
+    K, W, S = args.steps, args.warmup, args.spp_per_step * (world if args.scaling == "weak" else 1)
     spp_total = (K + W) * S
     pt.frame_begin(args.width, args.height, spp_total, args.seed, args.max_bounces, pbr_amd.INTEGRATOR_PATH, tile_rank=rank, tile_count=world)
 
@@ -142,7 +154,7 @@ def main():
             "warmup": W,
             "ms_per_step": dt / K * 1e3,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -151,7 +163,8 @@ def main():
                              f"textured atrium {desc.n_triangles} tris + 1024^2 albedo/normal/metal-rough textures + 2048x1024 env light (BASELINE configs[4])")
                             + f", {args.width}x{args.height}, {S * K} spp = {K} steps x {S} spp, max_bounces {args.max_bounces}, seed {args.seed}",
                 "paths": paths,
-                "sharding": f"32x32 tiles over {world} rank(s), RCCL reduce to rank 0" if world > 1 else "single GPU",
+                "sharding": (f"32x32 tiles over {world} ranks (each rank: 1/{world} of the pixels x {S} spp per step), RCCL reduce to rank 0"
+                             if world > 1 else "single GPU"),
             },
             "roofline": {
                 "bound": "hbm",

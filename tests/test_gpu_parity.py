@@ -320,3 +320,25 @@ def test_gltf_loaded_scene_renders_identically(gpu, ora, tmp_path):
     assert r.returncode == 0, r.stderr
     img = np.frombuffer(open(out, "rb").read().split(b"-1.0\n", 1)[1], "<f4").reshape(96, 96, 3)[::-1]
     assert rel_l2(np.ascontiguousarray(img), ref[..., :3]) <= TOL          # the CLI rounds fov from degrees in float: not bit-identical inputs
+
+
+def test_bench_two_rank_rehearsal(gpu):
+    """bench.py's N > 1 path (tile sharding, framebuffer reduce, max-over-ranks timing, whole-job sums) rehearsed with
+    two ranks sharing this box's one GPU over gloo; the driver's real runs use RCCL with one GPU per rank."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--spp-per-step", "2", "--width", "256", "--height", "192",
+           "--scene-scale", "0.05", "--backend", "gloo", "--share-device", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2
+    assert d["config"]["paths"] == 256 * 192 * 2 * 2 * 2 and d["value"] > 0          # weak: 2 spp x 2 ranks per step, 2 steps
+    assert d["per_path"]["segments"] > 1.0
