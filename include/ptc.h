@@ -77,7 +77,7 @@ typedef struct ptc_stats {
   double seconds_trace_closest; /* HIP-event time of the dominant kernel (sum over launches) */
   double seconds_trace_any;
   double seconds_shade;
-  double seconds_commit;      /* flatten + LBVH + upload                                 */
+  double seconds_commit;      /* flatten + BVH build + upload                               */
   uint32_t launches_trace_closest;
   uint32_t launches_trace_any;
   uint32_t n_triangles;
@@ -91,7 +91,7 @@ typedef struct ptc_stats {
  * (src/pbr_engine/core/pbr/core/GpuHandle.cpp:94-101, engine/pbr/memory/MemoryAllocator.cpp:68-88).
  * device_id: HIP ordinal.  Returns NULL on failure.
  * PTC_DEVICE_NONE gives a description-only context: the scene calls (begin/add/commit: flatten +
- * LBVH on the host) and the ptc_debug_get_* hooks work, every call that needs the GPU fails with
+ * BVH build on the host) and the ptc_debug_get_* hooks work, every call that needs the GPU fails with
  * PTC_E_DEVICE.  It exists so that the host logic can be checked without a GPU; it renders nothing. */
 #define PTC_DEVICE_NONE (-1)
 ptc_ctx* ptc_create(int device_id);
@@ -141,7 +141,7 @@ int ptc_set_camera(ptc_ctx*, const float pos[3], const float target[3], float fo
  * luminance x sin(theta).  rgb == NULL removes it.  Call before ptc_scene_commit. */
 int ptc_set_env_latlong_rgb32f(ptc_ctx*, const float* rgb, int w, int h);
 
-/* Flatten instances to world space (geometry_pass/vertex.glsl:25-36), build + flatten the LBVH,
+/* Flatten instances to world space (geometry_pass/vertex.glsl:25-36), build + flatten the BVH,
  * build the emitter CDF, upload everything to HBM. */
 int ptc_scene_commit(ptc_ctx*);
 
@@ -200,7 +200,7 @@ int ptc_debug_get_texture(ptc_ctx*, int index, int* w, int* h, uint8_t* rgba);
  * loop-iteration diagnostics a -DPT_DIAG build fills).  Returns the number of counters the library keeps. */
 int ptc_debug_get_counters(ptc_ctx*, uint64_t* out, int n);
 
-/* The flattened 4-wide LBVH as committed: nodes (n_nodes*12 32-bit words = 48 bytes each: org.xyz, packed
+/* The flattened 4-wide BVH as committed: nodes (n_nodes*12 32-bit words = 48 bytes each: org.xyz, packed
  * exponents + child descriptors, 8-bit quantised child planes, child / triangle base indices; layout in
  * csrc/ptc_scene.cpp) and triangle records in node order (n_tris*12 floats: v0,prim | e1,class | e2,0).
  * Pass NULL to query sizes only. */

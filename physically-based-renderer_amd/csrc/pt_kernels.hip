@@ -280,7 +280,7 @@ struct Reservoir {
 #endif
 
 // =================================================================================================
-// P3 closest-hit traversal + triangle intersection: persistent waves, dynamic lane refill, 4-wide LBVH.
+// P3 closest-hit traversal + triangle intersection: persistent waves, dynamic lane refill, 4-wide BVH.
 // Children are visited nearest first (order key above); a popped entry whose entry distance exceeds the
 // current best hit is skipped.  Closest hit = lexicographic minimum of (t, original primitive id).
 // The hit record (t, prim | class<<28, u, v) is written IN PLACE at the ray's slot (miss: prim = -1).

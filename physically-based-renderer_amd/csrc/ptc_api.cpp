@@ -259,7 +259,7 @@ extern "C" {
 int ptc_abi_version(void) { return PTC_ABI_VERSION; }
 
 ptc_ctx* ptc_create(int device_id) {
-  if (device_id == PTC_DEVICE_NONE) {   // description-only context: host flatten + LBVH, no rendering
+  if (device_id == PTC_DEVICE_NONE) {   // description-only context: host flatten + BVH build, no rendering
     ptc_ctx* c = new ptc_ctx();
     c->device = PTC_DEVICE_NONE;
     if (const char* s = std::getenv("PTC_NODELETS")) c->nodelet_budget = (uint32_t)std::strtoul(s, nullptr, 10);

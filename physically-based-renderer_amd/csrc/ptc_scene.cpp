@@ -1,4 +1,4 @@
-// ptc_scene.cpp — host side of ptc_scene_commit: flatten instances to world space, build the LBVH,
+// ptc_scene.cpp — host side of ptc_scene_commit: flatten instances to world space, build the SAH BVH,
 // lay it out for the trace kernels, build the emitter table.
 //
 // Reference conventions implemented here (file:line under the reference checkout):

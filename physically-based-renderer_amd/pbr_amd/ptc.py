@@ -19,7 +19,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libptc.so")
 
-DEVICE_NONE = -1  # PTC_DEVICE_NONE: description-only context (host flatten + LBVH; renders nothing)
+DEVICE_NONE = -1  # PTC_DEVICE_NONE: description-only context (host flatten + BVH build; renders nothing)
 INTEGRATOR_PATH = 0
 INTEGRATOR_RASTER_COMPAT = 1
 

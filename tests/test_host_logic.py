@@ -1,5 +1,5 @@
 """Host logic of the product without a GPU: a PTC_DEVICE_NONE context flattens the scene and builds
-the LBVH on the host (no compute call is made), and both must equal the oracle's bit for bit."""
+the BVH on the host (no compute call is made), and both must equal the oracle's bit for bit."""
 import math
 
 import numpy as np
