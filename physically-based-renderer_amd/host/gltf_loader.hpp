@@ -63,10 +63,14 @@ public:
 private:
   const std::string& s;
   size_t p = 0;
+  int depth = 0;     // nesting of the value being parsed: bounded, the parser is recursive
+  struct Nest { int& d; explicit Nest(int& x) : d(x) { ++d; } ~Nest() { --d; } };
   [[noreturn]] void fail(const std::string& m) const { throw std::runtime_error("JSON: " + m + " at offset " + std::to_string(p)); }
   void ws() { while (p < s.size() && (s[p] == ' ' || s[p] == '\t' || s[p] == '\n' || s[p] == '\r')) ++p; }
   bool lit(const char* w) { size_t n = std::strlen(w); if (s.compare(p, n, w) == 0) { p += n; return true; } return false; }
   JValue value() {
+    const Nest nest(depth);
+    if (depth > 128) fail("nesting deeper than 128");
     ws();
     if (p >= s.size()) fail("unexpected end");
     JValue v;
@@ -235,14 +239,17 @@ struct Doc {
     View r;
     r.ct = a.integer("componentType", 0);
     r.ncomp = type_count(a.string("type"));
-    r.count = (size_t)a.integer("count", 0);
+    const long count = a.integer("count", 0), stride = v.integer("byteStride", 0), off_v = v.integer("byteOffset", 0), off_a = a.integer("byteOffset", 0);
+    if (count < 0 || stride < 0 || off_v < 0 || off_a < 0) throw std::runtime_error("accessor with a negative count, stride or offset");
+    r.count = (size_t)count;
     r.normalized = a.get("normalized") && a.get("normalized")->b;
     const size_t elem = comp_size(r.ct) * (size_t)r.ncomp;
-    r.stride = (size_t)v.integer("byteStride", 0);
+    r.stride = (size_t)stride;
     if (r.stride == 0) r.stride = elem;
-    const size_t off = (size_t)v.integer("byteOffset", 0) + (size_t)a.integer("byteOffset", 0);
     const auto& data = buffers[(size_t)buf];
-    if (r.count && off + (r.count - 1) * r.stride + elem > data.size()) throw std::runtime_error("accessor exceeds its buffer");
+    const size_t off = (size_t)off_v + (size_t)off_a;   // both < 2^63: no wrap
+    // overflow-safe form of  off + (count-1)*stride + elem <= size
+    if (r.count && (off > data.size() || elem > data.size() - off || (r.count - 1) > (data.size() - off - elem) / r.stride)) throw std::runtime_error("accessor exceeds its buffer");
     r.base = data.data() + off;
     return r;
   }

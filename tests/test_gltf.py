@@ -209,3 +209,32 @@ def test_image_sources_and_errors(pbr, tmp_path):
                      (lambda j: j["images"].__setitem__(0, {"uri": "a.bin"}), "not a PNG")):
         with pytest.raises(pbr.PtcError, match=msg):
             load(mut)
+
+
+def test_hostile_accessors_and_json_are_rejected(pbr, tmp_path):
+    """Found by fuzzing the loader under ASan/UBSan: negative offsets/counts/strides wrapped the bounds check."""
+    d = pbr.scenes.by_name("cornell")
+    glb = str(tmp_path / "c.glb")
+    pbr.gltf.write_glb(d, glb)
+    raw = open(glb, "rb").read()
+    jlen = struct.unpack("<I", raw[12:16])[0]
+    doc = json.loads(raw[20 : 20 + jlen])
+    body = raw[20 + jlen :]
+
+    def load(j):
+        js = json.dumps(j).encode() if not isinstance(j, bytes) else j
+        js += b" " * ((4 - len(js) % 4) % 4)
+        out = raw[:8] + struct.pack("<I", 12 + 8 + len(js) + len(body)) + struct.pack("<II", len(js), 0x4E4F534A) + js + body
+        q = str(tmp_path / "h.glb")
+        open(q, "wb").write(out)
+        pbr.gltf.load_into(pbr.PathTracer(pbr.DEVICE_NONE), q, camera=d.camera)
+
+    load(doc)
+    for key, where, val in (("byteOffset", "accessors", -1), ("byteOffset", "bufferViews", -8), ("count", "accessors", -3), ("byteStride", "bufferViews", -4),
+                            ("byteOffset", "accessors", 2 ** 62), ("count", "accessors", 2 ** 40), ("byteStride", "bufferViews", 2 ** 61)):
+        j = json.loads(json.dumps(doc))
+        j[where][0][key] = val
+        with pytest.raises(pbr.PtcError, match="negative|exceeds"):
+            load(j)
+    with pytest.raises(pbr.PtcError, match="nesting"):
+        load(b'{"asset":{"version":"2.0"},"x":' + b"[" * 5000 + b"]" * 5000 + b"}")

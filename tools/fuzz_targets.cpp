@@ -1,0 +1,20 @@
+// Fuzz entry points for tools/sanitize.sh (host-only, built with -fsanitize=address,undefined).
+#ifdef FUZZ_PNG
+#include "png_decode.hpp"
+extern "C" int png_try(const unsigned char* d, unsigned long long n) {
+  try { int w, h; auto v = pbr::image::decode_png(d, (size_t)n, w, h); return (int)(v.size() & 0x7fffffff); } catch (std::exception const&) { return -1; }
+}
+#endif
+#ifdef FUZZ_GLTF
+#include "gltf_loader.hpp"
+extern "C" {
+// link-time stand-ins so that the header's upload() resolves; the fuzz target only runs load()
+int ptc_add_material(ptc_ctx*, const float*, float, float, const float*, int, int, int) { return 0; }
+int ptc_add_texture_rgba8(ptc_ctx*, const uint8_t*, int, int) { return 0; }
+int ptc_add_mesh(ptc_ctx*, const ptc_vertex*, uint32_t, const uint32_t*, uint32_t, int) { return 0; }
+int ptc_add_instance_matrix(ptc_ctx*, int, const float*) { return 0; }
+int gltf_try(const char* path) {
+  try { auto s = pbr::gltf::load(path); return (int)(s.n_triangles & 0x7fffffff); } catch (std::exception const&) { return -1; }
+}
+}
+#endif

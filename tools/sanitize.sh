@@ -1,0 +1,39 @@
+#!/bin/bash
+# Host-side AddressSanitizer + UBSan runs (CPU only; GPU sanitizers are not available on this pool).
+#   1. libptc.so / libptc_gltf.so with the HOST code instrumented (clang, -fno-gpu-sanitize), CPU test-suite on it
+#   2. the oracle instrumented (gcc), its CPU tests
+#   3. mutation fuzzers of the PNG decoder and the glTF loader (tools/fuzz_png.py, tools/fuzz_gltf.py)
+# Everything is built into build_san/ (git-ignored).  usage: tools/sanitize.sh [fuzz-iterations]
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd); OUT=$ROOT/build_san; mkdir -p $OUT
+PKG=$ROOT/physically-based-renderer_amd; ITERS=${1:-4000}
+CLANG=/opt/rocm/lib/llvm/bin/clang++; RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
+SAN="-fsanitize=address,undefined -fno-omit-frame-pointer -g -O1"
+( cd $PKG/csrc && /opt/rocm/bin/hipcc $SAN -fno-gpu-sanitize --offload-arch=gfx950 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
+    -fno-fast-math -I$ROOT/include -shared -o $OUT/libptc.so pt_kernels.hip ptc_api.cpp ptc_scene.cpp )
+$CLANG $SAN -std=c++17 -fPIC -ffp-contract=off -I$ROOT/include -I$PKG/host -shared -o $OUT/libptc_gltf.so $PKG/host/ptc_gltf.cpp -L$OUT -lptc -Wl,-rpath,$OUT
+cat > $OUT/run_host.py <<P
+import sys
+sys.path.insert(0, '$ROOT'); sys.path.insert(0, '$PKG')
+from pbr_amd import ptc, gltf
+ptc.LIB_PATH = '$OUT/libptc.so'; gltf._LIB = '$OUT/libptc_gltf.so'
+import pytest
+sys.exit(pytest.main(['-x', '-q', '-m', 'not gpu', '-p', 'no:cacheprovider'] + ['$ROOT/tests/' + t for t in ('test_host_logic.py', 'test_cabi.py', 'test_gltf.py', 'test_png.py', 'test_textures_env.py')]))
+P
+LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0 python $OUT/run_host.py
+gcc $SAN -std=c11 -fPIC -ffp-contract=off -mfma -pthread -shared -I$ROOT/oracle -o $OUT/libptc_oracle.so $ROOT/oracle/ptc_oracle.c -lm -lpthread
+cat > $OUT/run_oracle.py <<P
+import sys
+sys.path.insert(0, '$ROOT'); sys.path.insert(0, '$PKG')
+from oracle import ora
+ora._LIB_PATH = '$OUT/libptc_oracle.so'
+import pytest
+sys.exit(pytest.main(['-x', '-q', '-m', 'not gpu', '-p', 'no:cacheprovider'] + ['$ROOT/tests/' + t for t in ('test_oracle_kats.py', 'test_textures_env.py', 'test_host_logic.py')]))
+P
+GA=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)
+LD_PRELOAD=$GA ASAN_OPTIONS=detect_leaks=0 python $OUT/run_oracle.py
+g++ $SAN -std=c++17 -fPIC -I$ROOT/include -I$PKG/host -shared -o $OUT/libpng_fuzz.so $ROOT/tools/fuzz_targets.cpp -DFUZZ_PNG
+g++ $SAN -std=c++17 -fPIC -I$ROOT/include -I$PKG/host -shared -o $OUT/libgltf_fuzz.so $ROOT/tools/fuzz_targets.cpp -DFUZZ_GLTF
+LD_PRELOAD=$GA ASAN_OPTIONS=detect_leaks=0 python $ROOT/tools/fuzz_png.py $OUT $((ITERS * 10))
+LD_PRELOAD=$GA ASAN_OPTIONS=detect_leaks=0 python $ROOT/tools/fuzz_gltf.py $OUT $ITERS
+echo "sanitize: all clean"
