@@ -629,6 +629,8 @@ int ora_scene_commit(ora_ctx* c) {
     vb += m->nv; tb += m->ni / 3;
   }
   uint32_t n = c->n_tris;
+  for (uint32_t i = 0; i < c->n_wv; ++i) for (int k = 0; k < 3; ++k)
+    if (!isfinite(c->wv[i].position[k])) return fail(c, "scene_commit: non-finite vertex position after the instance transform");
   /* triangle boxes, scene bounds */
   float* tlo = (float*)malloc(12u * n); float* thi = (float*)malloc(12u * n);
   for (int k = 0; k < 3; ++k) { c->scene_lo[k] = INFINITY; c->scene_hi[k] = -INFINITY; }

@@ -284,6 +284,10 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
   }
   const uint32_t n = (uint32_t)nt;
   B.n_tris = n;
+  // NaN / Inf anywhere in the flattened positions (bad vertices or a bad instance matrix) is an error: the builder
+  // computes bin indices from them
+  for (const auto& v : B.wverts)
+    if (!(std::isfinite(v.position[0]) && std::isfinite(v.position[1]) && std::isfinite(v.position[2]))) return "scene_commit: non-finite vertex position after the instance transform";
   // ---- triangle boxes, scene bounds ------------------------------------------------------------------
   std::vector<Box> tbox(n);
   Box sb = empty_box();

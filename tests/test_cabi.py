@@ -72,3 +72,22 @@ def test_argument_errors_are_codes_and_text(pbr):
     assert L.ptc_scene_begin(None) == -1
     L.ptc_destroy(h)
     L.ptc_destroy(None)
+
+
+def test_non_finite_geometry_is_rejected(pbr, ora):
+    """NaN / Inf vertices or instance matrices must fail scene_commit (product and oracle alike), not reach the BVH builder."""
+    sc = pbr.scene
+    for bad, where in ((np.nan, "vertex"), (np.inf, "vertex"), (np.nan, "matrix")):
+        d = pbr.scenes.by_name("cornell")
+        if where == "vertex":
+            v = d.meshes[0].vertices.copy()
+            v["position"][1, 2] = bad
+            d.meshes[0] = sc.MeshDesc(v, d.meshes[0].indices, d.meshes[0].material)
+        else:
+            m = np.eye(4, dtype=np.float32).reshape(16)
+            m[13] = bad
+            d.instances[0] = sc.InstanceDesc(d.instances[0].mesh, matrix=m)
+        with pytest.raises(pbr.PtcError, match="non-finite"):
+            pbr.PathTracer(pbr.DEVICE_NONE).load_scene(d)
+        with pytest.raises(Exception, match="non-finite"):
+            ora.Oracle().load_scene(d)
