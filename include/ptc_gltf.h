@@ -4,8 +4,9 @@
  * (src/pbr_engine/gltf/pbr/gltf/Loader.hpp:20-21, Asset.hpp:76-78): reads a .gltf / .glb file and issues the
  * ptc_add_texture_rgba8 / ptc_add_material / ptc_add_mesh / ptc_add_instance_matrix calls of include/ptc.h on `ctx`.
  * Images (Asset::loadImage2D, Asset.cpp:121-133; bufferView, file URI or base64 data URI) are decoded to RGBA8 like
- * image::loadImage2D does (LoadImage.cpp:56-73: 4 channels of 8 bits whatever the file holds); PNG only — the reference
- * decodes with its vendored stb_image, which is not part of this library.  Samplers are ignored: the reference creates
+ * image::loadImage2D does (LoadImage.cpp:56-73: 4 channels of 8 bits whatever the file holds) by the library's own PNG
+ * and JPEG decoders, which reproduce the output of the reference's vendored stb_image bit for bit (tests/test_jpeg.py,
+ * tests/test_png.py against oracle/_ref).  Samplers are ignored: the reference creates
  * default samplers (NEAREST, REPEAT) whatever the asset says (Asset.cpp:116-117).
  * Call between ptc_scene_begin and ptc_scene_commit; the camera stays the caller's (the reference ignores glTF
  * cameras too and injects its own, Asset.cpp:262-265).  Host-only: works on a PTC_DEVICE_NONE context.
@@ -29,6 +30,12 @@ long long ptc_gltf_load(ptc_ctx* ctx, const char* path, int scene_index, int com
  * query the size only.  Returns 0 or a negative PTC_E_* code with the text in err. */
 int ptc_png_decode_rgba8(const unsigned char* data, unsigned long long n, unsigned char* out, unsigned long long out_capacity,
                          int* w, int* h, char* err, int err_len);
+
+/* JPEG file image (baseline / extended / progressive Huffman, 8 bit, 1, 3 or 4 components) → w*h*4 bytes RGBA8 with
+ * alpha 255; inverse DCT, chroma upsampling and colour conversion as stb_image does them (stb/stb_image.h:2430-2520,
+ * 3465-3528, 3658-3685), so the texels equal the reference's.  Same calling convention as ptc_png_decode_rgba8. */
+int ptc_jpeg_decode_rgba8(const unsigned char* data, unsigned long long n, unsigned char* out, unsigned long long out_capacity,
+                          int* w, int* h, char* err, int err_len);
 
 #ifdef __cplusplus
 }

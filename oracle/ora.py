@@ -238,3 +238,29 @@ def tile_owner(w, h, x, y, n):
 
 def hw_threads():
     return lib().ora_hw_threads()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# oracle/_ref: the reference's own image decoder (stb_image, compiled from /root/reference by `make -C oracle ref`).
+_REF_STB = os.path.join(_HERE, "_ref", "libstb_image_ref.so")
+
+
+def have_ref_stb() -> bool:
+    return os.path.exists(_REF_STB)
+
+
+def ref_stb_decode(data: bytes) -> np.ndarray:
+    """What image::loadImage2D hands to Vulkan for this file: stbi_load_from_memory(..., 4) of the reference's stb build
+    (src/pbr_engine/image/pbr/image/LoadImage.cpp:66-72).  Returns (h, w, 4) uint8; raises ValueError with stb's reason."""
+    L = C.CDLL(_REF_STB)
+    L.stbi_load_from_memory.restype = C.c_void_p
+    L.stbi_load_from_memory.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
+    L.stbi_failure_reason.restype = C.c_char_p
+    L.stbi_image_free.argtypes = [C.c_void_p]
+    w, h, ch = C.c_int(0), C.c_int(0), C.c_int(0)
+    p = L.stbi_load_from_memory(data, len(data), C.byref(w), C.byref(h), C.byref(ch), 4)
+    if not p:
+        raise ValueError((L.stbi_failure_reason() or b"stb_image failed").decode())
+    out = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (h.value, w.value, 4)).copy()
+    L.stbi_image_free(p)
+    return out

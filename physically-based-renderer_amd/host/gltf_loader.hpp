@@ -16,6 +16,7 @@
 #pragma once
 #include <ptc.h>
 
+#include "jpeg_decode.hpp"
 #include "png_decode.hpp"
 
 #include <array>
@@ -375,8 +376,8 @@ inline FlatScene load(const std::string& path, int scene_index = -1, bool compos
     }
     Texture t;
     if (pbr::image::is_png(bytes, nbytes)) t.rgba = pbr::image::decode_png(bytes, nbytes, t.w, t.h);
-    else if (nbytes >= 2 && bytes[0] == 0xFF && bytes[1] == 0xD8) throw std::runtime_error("image " + std::to_string(ii) + " is a JPEG: only PNG images are decoded");
-    else throw std::runtime_error("image " + std::to_string(ii) + " is not a PNG");
+    else if (pbr::image::is_jpeg(bytes, nbytes)) t.rgba = pbr::image::decode_jpeg(bytes, nbytes, t.w, t.h);
+    else throw std::runtime_error("image " + std::to_string(ii) + " is neither PNG nor JPEG");
     out.textures.push_back(std::move(t));
     return image_slot[(size_t)ii] = (int)out.textures.size() - 1;
   };

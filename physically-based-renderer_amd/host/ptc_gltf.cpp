@@ -21,6 +21,30 @@ extern "C" long long ptc_gltf_load(ptc_ctx* ctx, const char* path, int scene_ind
   }
 }
 
+namespace {
+template <class Decode>
+int decode_into(const char* who, Decode&& dec, unsigned char* out, unsigned long long out_capacity, int* w, int* h, char* err, int err_len) {
+  auto say = [&](const std::string& m) { if (err && err_len > 0) std::snprintf(err, (size_t)err_len, "%s", m.c_str()); };
+  if (!w || !h) { say(std::string(who) + ": null argument"); return PTC_E_ARG; }
+  try {
+    const std::vector<std::uint8_t> px = dec(*w, *h);
+    if (out) {
+      if (out_capacity < px.size()) { say(std::string(who) + ": output buffer too small"); return PTC_E_ARG; }
+      std::memcpy(out, px.data(), px.size());
+    }
+    return PTC_OK;
+  } catch (std::exception const& e) {
+    say(std::string(who) + ": " + e.what());
+    return PTC_E_ARG;
+  }
+}
+}  // namespace
+
+extern "C" int ptc_jpeg_decode_rgba8(const unsigned char* data, unsigned long long n, unsigned char* out, unsigned long long out_capacity, int* w, int* h, char* err, int err_len) {
+  if (!data) { if (err && err_len > 0) std::snprintf(err, (size_t)err_len, "ptc_jpeg_decode_rgba8: null argument"); return PTC_E_ARG; }
+  return decode_into("ptc_jpeg_decode_rgba8", [&](int& ww, int& hh) { return pbr::image::decode_jpeg(data, (std::size_t)n, ww, hh); }, out, out_capacity, w, h, err, err_len);
+}
+
 extern "C" int ptc_png_decode_rgba8(const unsigned char* data, unsigned long long n, unsigned char* out, unsigned long long out_capacity, int* w, int* h, char* err, int err_len) {
   auto say = [&](const std::string& m) { if (err && err_len > 0) std::snprintf(err, (size_t)err_len, "%s", m.c_str()); };
   if (!data || !w || !h) { say("ptc_png_decode_rgba8: null argument"); return PTC_E_ARG; }

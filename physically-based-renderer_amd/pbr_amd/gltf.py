@@ -64,19 +64,29 @@ def load_into(pt, path: str, camera=None, scene_index: int = -1, compose_parents
     return int(n), lo, hi
 
 
-def png_decode(data: bytes) -> np.ndarray:
-    """PNG file image → (h, w, 4) uint8 through the loader's own decoder (ptc_png_decode_rgba8)."""
+def _decode(fn_name: str, data: bytes) -> np.ndarray:
     L = _load()
-    L.ptc_png_decode_rgba8.restype = C.c_int
-    L.ptc_png_decode_rgba8.argtypes = [C.c_char_p, C.c_ulonglong, C.c_void_p, C.c_ulonglong, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]
+    fn = getattr(L, fn_name)
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_char_p, C.c_ulonglong, C.c_void_p, C.c_ulonglong, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]
     w, h = C.c_int(0), C.c_int(0)
     err = C.create_string_buffer(256)
-    if L.ptc_png_decode_rgba8(data, len(data), None, 0, C.byref(w), C.byref(h), err, 256):
+    if fn(data, len(data), None, 0, C.byref(w), C.byref(h), err, 256):
         raise _ptc.PtcError(err.value.decode())
     out = np.empty((h.value, w.value, 4), np.uint8)
-    if L.ptc_png_decode_rgba8(data, len(data), out.ctypes.data, out.nbytes, C.byref(w), C.byref(h), err, 256):
+    if fn(data, len(data), out.ctypes.data, out.nbytes, C.byref(w), C.byref(h), err, 256):
         raise _ptc.PtcError(err.value.decode())
     return out
+
+
+def png_decode(data: bytes) -> np.ndarray:
+    """PNG file image → (h, w, 4) uint8 through the loader's own decoder (ptc_png_decode_rgba8)."""
+    return _decode("ptc_png_decode_rgba8", data)
+
+
+def jpeg_decode(data: bytes) -> np.ndarray:
+    """JPEG file image → (h, w, 4) uint8 through the loader's own decoder (ptc_jpeg_decode_rgba8)."""
+    return _decode("ptc_jpeg_decode_rgba8", data)
 
 
 # ----------------------------------------------------------------------------------------------------

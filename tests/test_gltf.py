@@ -201,12 +201,17 @@ def test_image_sources_and_errors(pbr, tmp_path):
                 lambda j: j["images"].__setitem__(0, {"uri": "data:image/png;base64," + base64.b64encode(png).decode()})):
         mats, texs = load(mut)
         assert len(texs) == 1 and np.array_equal(texs[0], tex) and mats[0][1] == (0, 0, -1)   # one image, shared by both slots
-    (tmp_path / "tex.jpg").write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 32)
-    for mut, msg in ((lambda j: j["images"].__setitem__(0, {"uri": "tex.jpg"}), "JPEG"),
+    # a JPEG image goes through the loader's own JPEG decoder; the fixture's texels are the reference decoder's (tests/golden/make_jpeg_golden.py)
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg_progressive_422")
+    (tmp_path / "tex.jpg").write_bytes(open(gold + ".jpg", "rb").read())
+    mats, texs = load(lambda j: j["images"].__setitem__(0, {"uri": "tex.jpg"}))
+    assert len(texs) == 1 and np.array_equal(texs[0], np.load(gold + ".npy"))
+    (tmp_path / "bad.jpg").write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 32)
+    for mut, msg in ((lambda j: j["images"].__setitem__(0, {"uri": "bad.jpg"}), "JPEG:"),
                      (lambda j: j["materials"][0]["normalTexture"].__setitem__("texCoord", 1), "TEXCOORD_0"),
                      (lambda j: j["materials"][0]["normalTexture"].__setitem__("index", 5), "texture index out of range"),
                      (lambda j: j["textures"][0].__setitem__("source", 3), "image source"),
-                     (lambda j: j["images"].__setitem__(0, {"uri": "a.bin"}), "not a PNG")):
+                     (lambda j: j["images"].__setitem__(0, {"uri": "a.bin"}), "neither PNG nor JPEG")):
         with pytest.raises(pbr.PtcError, match=msg):
             load(mut)
 

@@ -5,6 +5,12 @@ extern "C" int png_try(const unsigned char* d, unsigned long long n) {
   try { int w, h; auto v = pbr::image::decode_png(d, (size_t)n, w, h); return (int)(v.size() & 0x7fffffff); } catch (std::exception const&) { return -1; }
 }
 #endif
+#ifdef FUZZ_JPEG
+#include "jpeg_decode.hpp"
+extern "C" int jpeg_try(const unsigned char* d, unsigned long long n) {
+  try { int w, h; auto v = pbr::image::decode_jpeg(d, (size_t)n, w, h); return (int)(v.size() & 0x7fffffff); } catch (std::exception const&) { return -1; }
+}
+#endif
 #ifdef FUZZ_GLTF
 #include "gltf_loader.hpp"
 extern "C" {

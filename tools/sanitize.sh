@@ -18,7 +18,7 @@ sys.path.insert(0, '$ROOT'); sys.path.insert(0, '$PKG')
 from pbr_amd import ptc, gltf
 ptc.LIB_PATH = '$OUT/libptc.so'; gltf._LIB = '$OUT/libptc_gltf.so'
 import pytest
-sys.exit(pytest.main(['-x', '-q', '-m', 'not gpu', '-p', 'no:cacheprovider'] + ['$ROOT/tests/' + t for t in ('test_host_logic.py', 'test_cabi.py', 'test_gltf.py', 'test_png.py', 'test_textures_env.py')]))
+sys.exit(pytest.main(['-x', '-q', '-m', 'not gpu', '-p', 'no:cacheprovider'] + ['$ROOT/tests/' + t for t in ('test_host_logic.py', 'test_cabi.py', 'test_gltf.py', 'test_png.py', 'test_jpeg.py', 'test_textures_env.py')]))
 P
 LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0 python $OUT/run_host.py
 gcc $SAN -std=c11 -fPIC -ffp-contract=off -mfma -pthread -shared -I$ROOT/oracle -o $OUT/libptc_oracle.so $ROOT/oracle/ptc_oracle.c -lm -lpthread
@@ -33,7 +33,9 @@ P
 GA=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)
 LD_PRELOAD=$GA ASAN_OPTIONS=detect_leaks=0 python $OUT/run_oracle.py
 g++ $SAN -std=c++17 -fPIC -I$ROOT/include -I$PKG/host -shared -o $OUT/libpng_fuzz.so $ROOT/tools/fuzz_targets.cpp -DFUZZ_PNG
+g++ $SAN -std=c++17 -fPIC -I$ROOT/include -I$PKG/host -shared -o $OUT/libjpeg_fuzz.so $ROOT/tools/fuzz_targets.cpp -DFUZZ_JPEG
 g++ $SAN -std=c++17 -fPIC -I$ROOT/include -I$PKG/host -shared -o $OUT/libgltf_fuzz.so $ROOT/tools/fuzz_targets.cpp -DFUZZ_GLTF
 LD_PRELOAD=$GA ASAN_OPTIONS=detect_leaks=0 python $ROOT/tools/fuzz_png.py $OUT $((ITERS * 10))
+LD_PRELOAD=$GA ASAN_OPTIONS=detect_leaks=0 python $ROOT/tools/fuzz_jpeg.py $OUT $((ITERS * 10))
 LD_PRELOAD=$GA ASAN_OPTIONS=detect_leaks=0 python $ROOT/tools/fuzz_gltf.py $OUT $ITERS
 echo "sanitize: all clean"
