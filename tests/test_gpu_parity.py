@@ -342,3 +342,14 @@ def test_bench_two_rank_rehearsal(gpu):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2
     assert d["config"]["paths"] == 256 * 192 * 2 * 2 * 2 and d["value"] > 0          # weak: 2 spp x 2 ranks per step, 2 steps
     assert d["per_path"]["segments"] > 1.0
+
+
+def test_plain_c_client_renders(gpu, tmp_path):
+    """examples/c_client.c (C99, nothing but include/ptc.h) renders on GPU 0 through the C-ABI."""
+    import subprocess
+
+    import test_cabi
+
+    r = subprocess.run([test_cabi._build_c_client(tmp_path), "0"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rendered 65536 paths" in r.stdout
