@@ -3,6 +3,7 @@
 // reference only ever presents to a swapchain (src/gltf_viewer/App.cpp:384-393).
 #pragma once
 #include <cstdint>
+#include <cstring>
 #include <fstream>
 #include <stdexcept>
 #include <string>
@@ -17,6 +18,27 @@ inline void write_pfm(const std::string& path, const float* rgba, int w, int h) 
   f << "PF\n" << w << " " << h << "\n-1.0\n";
   for (int y = h - 1; y >= 0; --y)
     for (int x = 0; x < w; ++x) f.write(reinterpret_cast<const char*>(&rgba[((std::size_t)y * w + x) * 4]), 12);
+}
+
+// PFM (PF = RGB, Pf = grey; little or big endian by the sign of the scale line) → w*h*3 floats, row 0 = top.
+inline std::vector<float> read_pfm(const std::string& path, int& w, int& h) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) throw std::runtime_error("cannot read " + path);
+  std::string magic; double scale = 0.0;
+  f >> magic >> w >> h >> scale;
+  if ((magic != "PF" && magic != "Pf") || w <= 0 || h <= 0 || scale == 0.0 || (std::uint64_t)w * (std::uint64_t)h > (1u << 28)) throw std::runtime_error(path + ": not a PFM image");
+  f.get();                                                   // the single whitespace byte after the scale line
+  const int ch = magic == "PF" ? 3 : 1;
+  std::vector<float> raw((std::size_t)w * h * ch);
+  f.read(reinterpret_cast<char*>(raw.data()), (std::streamsize)(raw.size() * 4));
+  if (!f) throw std::runtime_error(path + ": truncated PFM image");
+  if (scale > 0.0)                                           // big endian
+    for (float& v : raw) { std::uint32_t u; std::memcpy(&u, &v, 4); u = (u >> 24) | ((u >> 8) & 0xff00u) | ((u << 8) & 0xff0000u) | (u << 24); std::memcpy(&v, &u, 4); }
+  std::vector<float> out((std::size_t)w * h * 3);
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x)
+      for (int c = 0; c < 3; ++c) out[((std::size_t)y * w + x) * 3 + c] = raw[((std::size_t)(h - 1 - y) * w + x) * ch + (ch == 3 ? c : 0)];
+  return out;
 }
 
 namespace detail {

@@ -1,12 +1,16 @@
 // ptc_render — dependency-free C++17 offline renderer over the C-ABI (include/ptc.h).
 //   ptc_render (--scene cornell|sphere | --gltf file.glb [--cam-pos x y z --cam-target x y z --fov deg]) --width W --height H
-//              --spp N --seed S --bounces B [--raster] --out image.pfm [--png image.png] [--ppm image.ppm]
+//              --spp N --seed S --bounces B [--raster] [--env latlong.pfm | --sky] --out image.pfm [--png image.png] [--ppm image.ppm]
+// --env: ordinary lat-long RGB environment map (PFM, top row = up).  The reference's world is y-down (up = -y, CameraData.hpp:28) and
+// ptc_set_env_latlong_rgb32f takes row 0 = +y, so the rows are flipped on the way in.  --sky: a built-in gradient sky with a sun, for
+// assets that carry no emitters.
 // Without --cam-* a glTF scene is framed from its bounding box (the reference ignores glTF cameras and injects its own).
 // The scenes are the procedural stand-ins of BASELINE configs 1 and 2 (the reference's assets are stripped).
 #include "gltf_loader.hpp"
 #include "image_io.hpp"
 #include "pbr_pt.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -97,7 +101,8 @@ void buildSphere(pbr::PathTraceRenderSystem& rs, float aspect) {
 }  // namespace
 
 int main(int argc, char** argv) {
-  std::string scene = "cornell", out = "out.pfm", ppm, png, gltf;
+  std::string scene = "cornell", out = "out.pfm", ppm, png, gltf, envPath;
+  bool sky = false;
   float camPos[3] = {0, 0, 0}, camTarget[3] = {0, 0, -1}, fovDeg = 60.0f;
   bool haveCam = false;
   int w = 256, h = 256, spp = 64, bounces = 8, device = 0, integrator = PTC_INTEGRATOR_PATH;
@@ -109,6 +114,7 @@ int main(int argc, char** argv) {
     else if (a == "--spp") spp = std::atoi(next()); else if (a == "--seed") seed = std::strtoull(next(), nullptr, 10);
     else if (a == "--bounces") bounces = std::atoi(next()); else if (a == "--device") device = std::atoi(next());
     else if (a == "--gltf") gltf = next();
+    else if (a == "--env") envPath = next(); else if (a == "--sky") sky = true;
     else if (a == "--cam-pos") { for (float& v : camPos) v = (float)std::atof(next()); haveCam = true; }
     else if (a == "--cam-target") { for (float& v : camTarget) v = (float)std::atof(next()); }
     else if (a == "--fov") fovDeg = (float)std::atof(next());
@@ -129,6 +135,27 @@ int main(int argc, char** argv) {
         camPos[0] = cx; camPos[1] = cy; camPos[2] = cz + r / std::tan(0.5f * fovDeg * 3.14159265f / 180.0f) + r;
       }
       rs.setCamera({camPos[0], camPos[1], camPos[2]}, {camTarget[0], camTarget[1], camTarget[2]}, fovDeg * 3.14159265f / 180.0f, (float)w / h);
+      if (!envPath.empty()) {
+        int ew = 0, eh = 0;
+        std::vector<float> env = pbr::image::read_pfm(envPath, ew, eh);
+        for (int y = 0; y < eh / 2; ++y)                 // top row = up = -y = the map's last row
+          for (int k = 0; k < ew * 3; ++k) std::swap(env[(std::size_t)y * ew * 3 + k], env[(std::size_t)(eh - 1 - y) * ew * 3 + k]);
+        if (ptc_set_env_latlong_rgb32f(rs.handle(), env.data(), ew, eh) < 0) throw std::runtime_error(ptc_last_error(rs.handle()));
+      } else if (sky) {                                  // 256 x 128 gradient + sun; row 0 is the map's +y pole = down
+        const int ew = 256, eh = 128;
+        std::vector<float> env((std::size_t)ew * eh * 3);
+        for (int y = 0; y < eh; ++y)
+          for (int x = 0; x < ew; ++x) {
+            const float t = 1.0f - (float)y / (eh - 1);     // 0 at the zenith (-y), 1 at the nadir
+            float r = 0.9f - 0.55f * (1.0f - t), g = 0.95f - 0.35f * (1.0f - t), b = 1.0f;
+            if (t > 0.5f) { r = g = b = 0.25f; }                       // ground half
+            const float dx = (float)(x - ew / 4) / ew * 2.0f, dy = (float)(y - 3 * eh / 4) / eh;
+            if (dx * dx + dy * dy < 0.0004f) { r = 60.0f; g = 55.0f; b = 45.0f; }
+            float* o = &env[((std::size_t)y * ew + x) * 3];
+            o[0] = r; o[1] = g; o[2] = b;
+          }
+        if (ptc_set_env_latlong_rgb32f(rs.handle(), env.data(), ew, eh) < 0) throw std::runtime_error(ptc_last_error(rs.handle()));
+      }
       rs.commitScene();
       scene = gltf;
     } else if (scene == "cornell") buildCornell(rs); else if (scene == "sphere") buildSphere(rs, (float)w / h); else throw std::runtime_error("unknown scene " + scene);

@@ -296,6 +296,22 @@ def test_textured_gltf_renders_identically(gpu, ora, tmp_path):
     a = pt.render(96, 96, 4, seed=11, max_bounces=4)
     ref = ora.Oracle().load_scene(d).render(96, 96, 4, seed=11, max_bounces=4)
     assert _bits_equal(a, ref) and float(ref[..., :3].sum()) > 0.0
+    # the CLI with the same environment from a PFM file (top row = up = -y = the map's last row: the CLI flips it back)
+    import subprocess
+
+    env_pfm, out = str(tmp_path / "env.pfm"), str(tmp_path / "t.pfm")
+    eh, ew, _ = d.env.shape
+    with open(env_pfm, "wb") as f:
+        f.write(f"PF\n{ew} {eh}\n-1.0\n".encode() + np.ascontiguousarray(d.env, "<f4").tobytes())   # PFM rows run bottom-up
+    exe = os.path.join(os.path.dirname(gpu.ptc.LIB_PATH), "ptc_render")
+    cam = d.camera
+    r = subprocess.run([exe, "--gltf", p, "--env", env_pfm, "--width", "96", "--height", "96", "--spp", "4", "--seed", "11", "--bounces", "4", "--out", out,
+                        "--cam-pos", *map(str, cam.position), "--cam-target", *map(str, cam.target), "--fov", str(np.degrees(cam.fov_y))], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    img = np.frombuffer(open(out, "rb").read().split(b"-1.0\n", 1)[1], "<f4").reshape(96, 96, 3)[::-1]
+    assert rel_l2(np.ascontiguousarray(img), ref[..., :3]) <= 5e-3          # the CLI rounds fov through degrees in float: a few paths differ
+    r = subprocess.run([exe, "--gltf", p, "--sky", "--width", "64", "--height", "64", "--spp", "4", "--png", str(tmp_path / "s.png"), "--out", out], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and gpu.gltf.png_decode(open(tmp_path / "s.png", "rb").read())[..., :3].mean() > 5
 
 
 def test_gltf_loaded_scene_renders_identically(gpu, ora, tmp_path):
