@@ -1172,7 +1172,13 @@ static v3 trace_path(const ora_ctx* c, const camera_t* cam, int w, int h, uint32
           float k = (wil.z * wgt) / pl;
           v3 contrib = V3(T.x * f.x * lt->Le.x * k, T.y * f.y * lt->Le.y * k, T.z * f.z * lt->Le.z * k);
           pc->shadow_rays++;
-          if (!trace_any(c, porg, wi, 0.0f, dist * 0.999f, &pc->any)) L = vadd(L, contrib);
+          /* visibility: the segment from the offset origin porg = P + ng*eps to the sampled point, minus its last 0.1 %
+           * (aiming from porg along wi would miss the point by eps*sin and, with a large scene eps, run into the emitter
+           * itself before dist*0.999) */
+          v3 sv = vsub(y, porg);
+          float sd = sqrtf(dot3(sv, sv));
+          v3 sdir = vscale(sv, 1.0f / sd);
+          if (!trace_any(c, porg, sdir, 0.0f, sd * 0.999f, &pc->any)) L = vadd(L, contrib);
         }
       }
     }

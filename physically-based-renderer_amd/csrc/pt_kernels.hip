@@ -737,8 +737,12 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene
               const float wgt = pl2 / pt_fma(pb, pb, pl2);
               const float k = (wil.z * wgt) / pl;
               has_shadow = true;
-              sA = make_float4(porg.x, porg.y, porg.z, wi.x);
-              sB = make_float4(wi.y, wi.z, dist * 0.999f, __uint_as_float(path));
+              // visibility: the segment from the offset origin porg to the sampled point, minus its last 0.1 %
+              const v3 sv = y - porg;
+              const float sd = pt_sqrt(dot3(sv, sv));
+              const v3 sdir = sv * (1.0f / sd);
+              sA = make_float4(porg.x, porg.y, porg.z, sdir.x);
+              sB = make_float4(sdir.y, sdir.z, sd * 0.999f, __uint_as_float(path));
               sC = make_float4(T.x * f.x * l4.x * k, T.y * f.y * l4.y * k, T.z * f.z * l4.z * k, 0.0f);
             }
           }

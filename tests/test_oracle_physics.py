@@ -1,0 +1,98 @@
+"""Analytic known answers for the path-tracer specification itself.  The reference has no ray tracer, so the oracle is
+"parity unpinned" against it; these tests pin it against physics instead: closed forms and quadrature
+that any correct unidirectional path tracer with next-event estimation, MIS and Russian roulette must reproduce in the
+mean.  The HIP path equals the oracle bit for bit (tests/test_gpu_parity.py), so they hold for the product too."""
+import math
+
+import numpy as np
+import pytest
+
+
+def _box(pbr, mat_ids, lo=(-1, -1, -1), hi=(1, 1, 1)):
+    """Closed axis-aligned box, all faces looking inward (the six quads of scenes.cornell_box plus the front)."""
+    q = pbr.scenes._quad
+    (x0, y0, z0), (x1, y1, z1) = lo, hi
+    quads = [q((x0, y0, z1), (x1, y0, z1), (x1, y0, z0), (x0, y0, z0)),    # y = y0, normal +y
+             q((x0, y1, z0), (x1, y1, z0), (x1, y1, z1), (x0, y1, z1)),    # y = y1, normal -y
+             q((x0, y0, z0), (x1, y0, z0), (x1, y1, z0), (x0, y1, z0)),    # z = z0, normal +z
+             q((x1, y0, z1), (x0, y0, z1), (x0, y1, z1), (x1, y1, z1)),    # z = z1, normal -z
+             q((x0, y0, z1), (x0, y0, z0), (x0, y1, z0), (x0, y1, z1)),    # x = x0, normal +x
+             q((x1, y0, z0), (x1, y0, z1), (x1, y1, z1), (x1, y1, z0))]    # x = x1, normal -x
+    return [pbr.scene.MeshDesc(v, i, m) for (v, i), m in zip(quads, mat_ids)]
+
+
+@pytest.mark.parametrize("rho,max_bounces", [(0.5, 8), (0.8, 8), (0.8, 3), (0.3, 0), (0.95, 12)])
+def test_emitting_furnace_geometric_series(ora, pbr, rho, max_bounces):
+    """A closed box whose every wall emits Le and reflects rho (Lambert): radiance seen from inside is
+    Le * sum_{k=0..B} rho^k for bounce limit B.  Exercises emission + NEE with MIS on every bounce, the throughput
+    update and Russian roulette (from bounce 3 on) — a biased roulette or a wrong MIS weight breaks the series."""
+    sc = pbr.scene
+    le = 2.0
+    mat = sc.Material((rho, rho, rho, 1.0), 0.0, 1.0, (le, le, le))
+    meshes = _box(pbr, [0] * 6)
+    d = sc.SceneDesc([mat], meshes, [sc.InstanceDesc(k) for k in range(6)], sc.CameraDesc((0.1, -0.2, 0.3), (0.4, 0.1, -1.0), 1.2, 1.0))
+    img = ora.Oracle().load_scene(d).render(48, 48, 64, seed=5, max_bounces=max_bounces)[..., :3]
+    want = le * sum(rho ** k for k in range(max_bounces + 1))
+    assert abs(float(img.mean()) / want - 1.0) < 0.01, (float(img.mean()), want)
+    assert np.allclose(img.mean((0, 1)), want, rtol=0.015)
+
+
+def test_furnace_with_ggx_walls_conserves_energy(ora, pbr):
+    """Same furnace with rough-dielectric and metal walls: the BSDF (single-scattering GGX + Lambert) may lose energy but
+    never creates it, so the radiance stays below the Lambert series for albedo 1 and above the pure emission."""
+    sc = pbr.scene
+    le = 1.0
+    for metallic, rough in ((0.0, 0.5), (1.0, 0.3), (1.0, 0.8), (0.0, 0.1)):
+        mat = sc.Material((0.9, 0.9, 0.9, 1.0), metallic, rough, (le, le, le))
+        d = sc.SceneDesc([mat], _box(pbr, [0] * 6), [sc.InstanceDesc(k) for k in range(6)], sc.CameraDesc((0.1, -0.2, 0.3), (0.4, 0.1, -1.0), 1.2, 1.0))
+        m = float(ora.Oracle().load_scene(d).render(32, 32, 64, seed=2, max_bounces=6)[..., :3].mean())
+        assert le * 1.5 < m < le * 7.0 * 1.01, (metallic, rough, m)          # 7 = sum_{k=0..6} 1^k
+
+
+def test_direct_light_from_a_rectangular_emitter_matches_quadrature(ora, pbr):
+    """One-bounce radiance on a Lambert floor under a square emitter: L = rho/pi * integral over the emitter of
+    Le cos(theta_floor) cos(theta_light) / r^2 dA (one-sided emitter facing the floor), evaluated here by brute-force
+    quadrature in float64.  Checks area-light sampling pdfs, the geometry term and MIS against BSDF hits."""
+    sc = pbr.scene
+    q = pbr.scenes._quad
+    rho, le, hgt, e = 0.7, 10.0, 1.5, 0.5
+    floor = q((-50, 0, 50), (50, 0, 50), (50, 0, -50), (-50, 0, -50))               # y = 0, normal +y
+    light = q((-e, hgt, -e), (e, hgt, -e), (e, hgt, e), (-e, hgt, e))               # y = hgt, normal -y (faces the floor)
+    mats = [sc.Material((rho, rho, rho, 1.0), 0.0, 1.0), sc.Material((0, 0, 0, 1.0), 0.0, 1.0, (le, le, le))]
+    cam = sc.CameraDesc((0.0, 6.0, 0.0), (0.0, 0.0, 0.0001), 0.35, 1.0)             # looking straight down at the origin
+    d = sc.SceneDesc(mats, [sc.MeshDesc(*floor, 0), sc.MeshDesc(*light, 1)], [sc.InstanceDesc(0), sc.InstanceDesc(1)], cam)
+    o = ora.Oracle().load_scene(d)
+    img = o.render(64, 64, 256, seed=3, max_bounces=1)[..., :3]
+
+    def radiance_at(x, z, n=400):
+        u = (np.arange(n) + 0.5) / n * 2 * e - e
+        X, Z = np.meshgrid(u, u)
+        dx, dz = X - x, Z - z
+        r2 = dx * dx + dz * dz + hgt * hgt
+        return rho / math.pi * le * float((hgt * hgt / (r2 * r2)).sum()) * (2 * e / n) ** 2
+
+    # the camera sees |x|,|z| <= 6 tan(0.175) ~ 1.06 on the floor; the emitter hides the centre (it is one-sided: black from above)
+    half = 6.0 * math.tan(0.175)
+    for (px, py) in ((4, 4), (60, 8), (10, 56), (58, 58), (2, 32)):
+        blk = img[py - 2 : py + 3, px - 2 : px + 3].mean((0, 1))
+        # pixel centre → floor point; the image is x-mirrored (lookAtRH with up = -y) but the scene is symmetric in x and z
+        fx, fz = ((px + 0.5) / 64 * 2 - 1) * half, ((py + 0.5) / 64 * 2 - 1) * half
+        want = radiance_at(abs(fx), abs(fz))
+        assert np.allclose(blk, want, rtol=0.03), ((px, py), blk, want)
+    centre = img[28:36, 28:36]
+    assert float(centre.max()) == 0.0                                                # back of the one-sided emitter
+
+
+def test_more_bounces_than_russian_roulette_start_stay_unbiased(ora, pbr):
+    """Russian roulette (from bounce 3) must not change the mean: the furnace value with rho = 0.9 at B = 20 is within 1 %
+    of the series although most paths are terminated early."""
+    sc = pbr.scene
+    rho, le, B = 0.9, 1.0, 20
+    mat = sc.Material((rho, rho, rho, 1.0), 0.0, 1.0, (le, le, le))
+    d = sc.SceneDesc([mat], _box(pbr, [0] * 6), [sc.InstanceDesc(k) for k in range(6)], sc.CameraDesc((0.0, 0.0, 0.0), (0.3, 0.2, -1.0), 1.0, 1.0))
+    o = ora.Oracle().load_scene(d)
+    img = o.render(48, 48, 128, seed=11, max_bounces=B)[..., :3]
+    want = le * (1 - rho ** (B + 1)) / (1 - rho)
+    assert abs(float(img.mean()) / want - 1.0) < 0.01
+    st = o.stats()
+    assert st["segments"] / st["paths"] < B * 0.8          # roulette really did end paths early
