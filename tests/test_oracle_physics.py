@@ -96,3 +96,73 @@ def test_more_bounces_than_russian_roulette_start_stay_unbiased(ora, pbr):
     assert abs(float(img.mean()) / want - 1.0) < 0.01
     st = o.stats()
     assert st["segments"] / st["paths"] < B * 0.8          # roulette really did end paths early
+
+
+def _ggx_albedo(base, metallic, roughness, mu, n_th=1500, n_ph=720):
+    """Directional albedo  ∫ f(wo, wi) cos(theta_i) dwi  of the specified BSDF (Lambert (1-m)·base/pi + F·D·G1(v)·G1(l) /
+    (4 nov nol), D GGX, separable Smith, Schlick) by midpoint quadrature in float64."""
+    a2 = max(roughness * roughness, 1e-3) ** 2
+    cd = np.asarray(base, np.float64) * (1.0 - metallic)
+    f0 = 0.04 * (1.0 - metallic) + np.asarray(base, np.float64) * metallic
+    wo = np.array([math.sqrt(1 - mu * mu), 0.0, mu])
+    ct = (np.arange(n_th) + 0.5) / n_th                       # cos(theta_i), uniform in cos → dw = dcos dphi
+    ph = (np.arange(n_ph) + 0.5) / n_ph * 2 * math.pi
+    CT, PH = np.meshgrid(ct, ph, indexing="ij")
+    ST = np.sqrt(1 - CT * CT)
+    wi = np.stack([ST * np.cos(PH), ST * np.sin(PH), CT], -1)
+    h = wi + wo
+    h /= np.linalg.norm(h, axis=-1, keepdims=True)
+    noh, voh = h[..., 2], (h * wo).sum(-1)
+    D = a2 / (math.pi * (noh * noh * (a2 - 1) + 1) ** 2)
+    g1 = lambda x: 2 * x / (x + np.sqrt((1 - a2) * x * x + a2))
+    sp = D * g1(mu) * g1(CT) / (4 * mu * CT)
+    m5 = np.clip(1 - voh, 0, None) ** 5
+    dw = (1.0 / n_th) * (2 * math.pi / n_ph)
+    out = []
+    for c in range(3):
+        F = f0[c] + (1 - f0[c]) * m5
+        out.append(float(((cd[c] / math.pi + F * sp) * CT).sum() * dw))
+    return np.array(out)
+
+
+@pytest.mark.parametrize("metallic,roughness,base", [(1.0, 0.5, (0.9, 0.6, 0.2)), (0.0, 0.5, (0.8, 0.8, 0.8)), (1.0, 0.25, (1.0, 1.0, 1.0)), (0.0, 0.3, (0.2, 0.5, 0.9)),
+                                                     (0.5, 0.7, (0.7, 0.7, 0.3))])
+@pytest.mark.parametrize("height", [3.0, 0.6])
+def test_ggx_plane_under_a_white_sky_equals_the_brdf_albedo(ora, pbr, metallic, roughness, base, height):
+    """A convex GGX surface under radiance 1 from every direction shows its directional albedo.  The estimator mixes VNDF
+    sampling, cosine sampling and environment NEE by MIS; all of it has to agree with the quadrature of the BSDF itself."""
+    sc = pbr.scene
+    env = np.ones((16, 32, 3), np.float32)
+    v, i = pbr.scenes._quad((-200, 0, 200), (200, 0, 200), (200, 0, -200), (-200, 0, -200))      # normal +y
+    cam = sc.CameraDesc((0.0, height, 2.0), (0.0, 0.0, 0.0), 0.05, 1.0)                           # narrow view: one angle of incidence
+    d = sc.SceneDesc([sc.Material((*base, 1.0), metallic, roughness)], [sc.MeshDesc(v, i, 0)], [sc.InstanceDesc(0)], cam, env=env)
+    img = ora.Oracle().load_scene(d).render(24, 24, 512, seed=7, max_bounces=1)[..., :3]
+    mu = height / math.hypot(height, 2.0)
+    want = _ggx_albedo(base, metallic, roughness, mu)
+    got = img.mean((0, 1))
+    assert np.allclose(got, want, rtol=0.02, atol=2e-3), (got, want)
+
+
+def test_ray_generation_agrees_with_the_reference_projection(ora, pbr):
+    """P1 against R5: a small emitter at a known world position must light the pixel that the reference's own matrices
+    (glm::lookAtRH with up = (0,-1,0), perspectiveRH_NO, un-flipped Vulkan viewport: CameraData.hpp:22-32,
+    PbrRenderSystem.cpp:425-430) send it to:  pixel = ((ndc.x + 1)/2 · W, (ndc.y + 1)/2 · H)."""
+    sc = pbr.scene
+    q = pbr.scenes._quad
+    W, H = 96, 64
+    cam = sc.CameraDesc((0.5, -0.3, 4.0), (0.2, 0.1, 0.0), 0.9, W / H)
+    cd = sc.make_camera_data(cam.position, cam.target, cam.fov_y, cam.aspect)
+    view, proj = cd.view.astype(np.float64).T, cd.proj.astype(np.float64).T          # stored column-major (glm): transpose → row-major math
+    for world in ((1.0, 0.5, 0.0), (-1.2, -0.8, 0.5), (0.3, 0.9, -1.0), (-0.6, 0.2, 1.5)):
+        e = 0.03
+        x, y, z = world
+        light = q((x - e, y - e, z), (x + e, y - e, z), (x + e, y + e, z), (x - e, y + e, z))      # faces +z, towards the camera
+        d = sc.SceneDesc([sc.Material((0, 0, 0, 1), 0.0, 1.0, (50.0, 50.0, 50.0))], [sc.MeshDesc(*light, 0)], [sc.InstanceDesc(0)], cam)
+        img = ora.Oracle().load_scene(d).render(W, H, 16, seed=1, max_bounces=0)[..., 0]
+        clip = proj @ view @ np.array([x, y, z, 1.0])
+        ndc = clip[:3] / clip[3]
+        px, py = (ndc[0] + 1) / 2 * W, (ndc[1] + 1) / 2 * H
+        ys, xs = np.nonzero(img > 0)
+        assert len(xs) > 0
+        cx, cy = (xs + 0.5).mean(), (ys + 0.5).mean()
+        assert abs(cx - px) < 0.75 and abs(cy - py) < 0.75, (world, (cx, cy), (px, py))
