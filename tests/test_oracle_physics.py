@@ -166,3 +166,23 @@ def test_ray_generation_agrees_with_the_reference_projection(ora, pbr):
         assert len(xs) > 0
         cx, cy = (xs + 0.5).mean(), (ys + 0.5).mean()
         assert abs(cx - px) < 0.75 and abs(cy - py) < 0.75, (world, (cx, cy), (px, py))
+
+
+def test_light_transport_is_linear_in_the_emitters(ora, pbr):
+    """Rendering with the environment only, plus rendering with the emissive triangles only, equals rendering with both
+    (in the mean): pins the environment-vs-area selection probability (RNG dim 7, p = 1/2) and both MIS pairs together."""
+    import copy
+
+    both = pbr.scenes.by_name("textured_atrium", scale=0.05, tex_size=64, env_size=(64, 32))
+    assert both.env is not None and any(max(m.emissive) > 0 for m in both.materials)
+    env_only = copy.deepcopy(both)
+    for m in env_only.materials:
+        m.emissive = (0.0, 0.0, 0.0)
+    area_only = copy.deepcopy(both)
+    area_only.env = None
+    r = {}
+    for name, d in (("both", both), ("env", env_only), ("area", area_only)):
+        r[name] = ora.Oracle().load_scene(d).render(40, 24, 256, seed=21, max_bounces=4)[..., :3].astype(np.float64)
+    total, parts = r["both"].mean((0, 1)), (r["env"] + r["area"]).mean((0, 1))
+    assert r["env"].mean() > 0 and r["area"].mean() > 0
+    assert np.allclose(total, parts, rtol=0.03), (total, parts)
