@@ -369,3 +369,28 @@ def test_plain_c_client_renders(gpu, tmp_path):
     r = subprocess.run([test_cabi._build_c_client(tmp_path), "0"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "rendered 65536 paths" in r.stdout
+
+
+def test_contexts_release_their_device_memory(gpu):
+    """create → commit → render → re-commit → destroy, several times: the free device memory comes back (queues, scene
+    buffers, overflow slabs, per-lane allocations, events)."""
+    import gc
+
+    import torch
+
+    def cycle(k):
+        pt = gpu.PathTracer(0).load_scene(gpu.scenes.atrium(0.05))
+        pt.render(320, 200, 8, seed=k)
+        pt.load_scene(gpu.scenes.sphere_scene(32, 17))          # re-commit on a live context frees the old scene
+        pt.render(64, 64, 4, seed=k)
+        del pt
+        gc.collect()
+
+    cycle(99)                                                   # the first use loads code objects and runtime pools that stay
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(0)
+    for k in range(4):
+        cycle(k)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(0)
+    assert free0 - free1 < 64 << 20, (free0, free1, (free0 - free1) >> 20)
