@@ -394,3 +394,18 @@ def test_contexts_release_their_device_memory(gpu):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info(0)
     assert free0 - free1 < 64 << 20, (free0, free1, (free0 - free1) >> 20)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_render_sharded_two_ranks_on_one_gpu(gpu, world):
+    """pbr_amd.dist.render_sharded end to end on the GPU: ranks share the card, gloo carries the reduce of the
+    library-owned device buffers, the assembled frame equals the undivided one bit for bit."""
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29530 + world), os.path.join(here, "_dist_gpu_worker.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "DIST_GPU_OK" in r.stdout
