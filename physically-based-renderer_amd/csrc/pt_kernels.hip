@@ -101,7 +101,6 @@ __global__ __launch_bounds__(256) void k_raygen(DevCamera cam, DevFrame fr, DevQ
   r.A[p] = make_float4(cam.pos[0], cam.pos[1], cam.pos[2], d.x);
   r.B[p] = make_float4(d.y, d.z, bz, bw);
   r.C[p] = make_float4(1.0f, 0.0f, __uint_as_float(p), __uint_as_float(key));
-  r.D[p] = 0u;
   q.lpath[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
@@ -566,7 +565,7 @@ PT_DEV v3 env_sample(const DevScene& sc, float r1, float r2) {
 // Russian roulette.
 // Back end (P9): continuation and shadow rays are compacted into the output queues with the same
 // ballot/prefix scheme and ONE atomic per block and queue.
-__global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, DevFrame fr, DevQueues q, int qi) {
+__global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, DevFrame fr, DevQueues q, int qi, uint32_t b) {
   __shared__ uint32_t s_cnt[4][SHADE_WAVES];     // per-wave counts: class0, class1, shadow, next
   __shared__ uint32_t s_base[2];                 // block's base slots in the shadow / next queues
   __shared__ uint16_t s_idx[SHADE_BLOCK];        // sorted local slot of each work item (0xffff = none)
@@ -631,12 +630,11 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene
     const uint32_t slot = wbase + (valid ? item : 0u);
 
     bool alive = false, has_shadow = false;
-    float4 oA, oB, oC; uint32_t oD = 0;              // continuation ray
+    float4 oA, oB, oC;                               // continuation ray
     float4 sA, sB, sC;                               // shadow ray
     oA = oB = oC = sA = sB = sC = make_float4(0, 0, 0, 0);
     if (valid) {
       const float4 A = rin.A[slot], Bq = rin.B[slot], Cq = rin.C[slot], H = q.hit[slot];
-      const uint32_t b = rin.D[slot];
       const v3 d = V3(A.w, Bq.x, Bq.y);
       v3 T = V3(Bq.z, Bq.w, Cq.x);
       const float prev_pdf = Cq.y;
@@ -779,7 +777,6 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene
           oA = make_float4(porg.x, porg.y, porg.z, wi.x);
           oB = make_float4(wi.y, wi.z, T.x, T.y);
           oC = make_float4(T.z, pdf, __uint_as_float(path), __uint_as_float(key));
-          oD = rb;
         }
       }
       }   // hit
@@ -801,7 +798,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene
     }
     __syncthreads();
     if (has_shadow) { const uint32_t s = s_base[0] + offs + mbcnt64(ms); q.shadow.A[s] = sA; q.shadow.B[s] = sB; q.shadow.C[s] = sC; }
-    if (alive) { const uint32_t s = s_base[1] + offa + mbcnt64(ma); rout.A[s] = oA; rout.B[s] = oB; rout.C[s] = oC; rout.D[s] = oD; }
+    if (alive) { const uint32_t s = s_base[1] + offa + mbcnt64(ma); rout.A[s] = oA; rout.B[s] = oB; rout.C[s] = oC; }
     __syncthreads();   // s_cnt / s_idx are rewritten by the next window
   }
 }
@@ -932,8 +929,8 @@ void pt_launch_trace_any(hipStream_t s, const LaunchCfg& cfg, const DevScene& sc
 #undef TA
 }
 
-void pt_launch_shade(hipStream_t s, const LaunchCfg& cfg, const DevScene& sc, const DevFrame& fr, const DevQueues& q, int qi) {
-  hipLaunchKernelGGL(k_shade, dim3((unsigned)(cfg.n_cu * SHADE_GRID)), dim3(SHADE_BLOCK), 0, s, sc, fr, q, qi);
+void pt_launch_shade(hipStream_t s, const LaunchCfg& cfg, const DevScene& sc, const DevFrame& fr, const DevQueues& q, int qi, uint32_t bounce) {
+  hipLaunchKernelGGL(k_shade, dim3((unsigned)(cfg.n_cu * SHADE_GRID)), dim3(SHADE_BLOCK), 0, s, sc, fr, q, qi, bounce);
 }
 void pt_launch_accumulate(hipStream_t s, const DevFrame& fr, const DevQueues& q, float4* accum, uint32_t n_samples) {
   hipLaunchKernelGGL(k_accumulate, dim3((fr.n_owned + 255u) / 256u), dim3(256), 0, s, fr, (const float4*)q.lpath, accum, n_samples);

@@ -33,7 +33,7 @@ struct ptc_ctx {
   LaunchCfg cfg{};
   uint32_t nodelet_budget = 85;   // wide nodes staged in LDS: the top four levels (1+4+16+64) of the tree, 48 B each = 4 KB
   size_t max_batch_paths = (size_t)1 << 27;   // paths in flight over all lanes: large batches amortise launch tails (sized for 288 GB of HBM:
-                                              // 184 B per path -> 24.7 GB of queues at 1080p x 32 spp x 2 lanes)
+                                              // 176 B per path -> 23.6 GB of queues at 1080p x 32 spp x 2 lanes)
   bool timing = true;
   // description
   std::vector<HostMaterial> mats;
@@ -123,7 +123,7 @@ int ensure_queues_in(ptc_ctx* c, DevQueues& dst, std::vector<void*>& allocs, uin
   int rc = 0;
   for (int k = 0; k < 2; ++k) {
     rc |= dev_alloc(c, allocs, &q.ray[k].A, cap); rc |= dev_alloc(c, allocs, &q.ray[k].B, cap);
-    rc |= dev_alloc(c, allocs, &q.ray[k].C, cap); rc |= dev_alloc(c, allocs, &q.ray[k].D, cap);
+    rc |= dev_alloc(c, allocs, &q.ray[k].C, cap);
   }
   rc |= dev_alloc(c, allocs, &q.shadow.A, cap); rc |= dev_alloc(c, allocs, &q.shadow.B, cap);
   rc |= dev_alloc(c, allocs, &q.shadow.C, cap);
@@ -212,7 +212,7 @@ int run_batch(ptc_ctx* c, int l, uint32_t first_sample, uint32_t n_samples) {
     pt_launch_raygen(st, c->cam, c->fr, q, first_sample, n_samples, false);
     for (int b = 0; b <= c->fr.max_bounces; ++b) {
       { ScopedSpan t(c, st, 0); pt_launch_trace_closest(st, c->cfg, sc, q, b & 1, false); c->stats.launches_trace_closest++; }
-      { ScopedSpan t(c, st, 2); pt_launch_shade(st, c->cfg, sc, c->fr, q, b & 1); }
+      { ScopedSpan t(c, st, 2); pt_launch_shade(st, c->cfg, sc, c->fr, q, b & 1, (uint32_t)b); }
       if (b < c->fr.max_bounces && (sc.n_lights > 0 || sc.env_ok)) {
         ScopedSpan t(c, st, 1); pt_launch_trace_any(st, c->cfg, sc, q, nullptr); c->stats.launches_trace_any++;
       }

@@ -42,11 +42,11 @@ struct DevFrame {
 };
 
 // ---- wavefront queues (SoA of 16-byte lanes) ------------------------------------------------------
-// ray record   : A=(o.xyz,d.x) B=(d.y,d.z,T.x,T.y) C=(T.z,prev_pdf,path_id,key) D=bounce   (52 B)
+// ray record   : A=(o.xyz,d.x) B=(d.y,d.z,T.x,T.y) C=(T.z,prev_pdf,path_id,key)   (48 B; the bounce index is the same for a whole launch and travels as a kernel argument)
 //   raster/debug rays reuse B.zw as (tmin,tmax)
 // hit record   : H=(t,prim,u,v)                                                            (16 B)
 // shadow record: A=(o.xyz,d.x) B=(d.y,d.z,tmax,path_id) C=(contrib.rgb,-)                  (48 B)
-struct RayQ { float4* A; float4* B; float4* C; uint32_t* D; };
+struct RayQ { float4* A; float4* B; float4* C; };   // 48 B per ray; the bounce index is a launch constant, not a field
 struct ShadowQ { float4* A; float4* B; float4* C; };
 
 struct DevQueues {
@@ -73,7 +73,7 @@ void pt_launch_set_counts(hipStream_t, const DevQueues&, uint32_t n_rays, uint32
 void pt_launch_advance(hipStream_t, const DevQueues&);
 void pt_launch_raygen(hipStream_t, const DevCamera&, const DevFrame&, const DevQueues&, uint32_t first_sample, uint32_t n_samples, bool raster);
 void pt_launch_trace_closest(hipStream_t, const LaunchCfg&, const DevScene&, const DevQueues&, int qi, bool cull);
-void pt_launch_shade(hipStream_t, const LaunchCfg&, const DevScene&, const DevFrame&, const DevQueues&, int qi);
+void pt_launch_shade(hipStream_t, const LaunchCfg&, const DevScene&, const DevFrame&, const DevQueues&, int qi, uint32_t bounce);   // every ray of a wavefront launch is at the same bounce
 void pt_launch_trace_any(hipStream_t, const LaunchCfg&, const DevScene&, const DevQueues&, uint8_t* debug_out /*or null*/);
 void pt_launch_accumulate(hipStream_t, const DevFrame&, const DevQueues&, float4* accum, uint32_t n_samples);
 void pt_launch_shade_raster(hipStream_t, const DevScene&, const DevCamera&, const DevFrame&, const DevQueues&, float4* accum);
