@@ -38,6 +38,16 @@ def _bits_equal(a, b):
     return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
 
 
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def _pair(gpu, ora, desc):
     return gpu.PathTracer(0).load_scene(desc), ora.Oracle().load_scene(desc)
 
@@ -347,7 +357,7 @@ def test_bench_two_rank_rehearsal(gpu):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--spp-per-step", "2", "--width", "256", "--height", "192",
            "--scene-scale", "0.05", "--backend", "gloo", "--share-device", "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
@@ -405,7 +415,7 @@ def test_render_sharded_two_ranks_on_one_gpu(gpu, world):
 
     here = os.path.dirname(os.path.abspath(__file__))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29530 + world), os.path.join(here, "_dist_gpu_worker.py")]
+           "--master-port", str(_free_port()), os.path.join(here, "_dist_gpu_worker.py")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "DIST_GPU_OK" in r.stdout
