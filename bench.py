@@ -179,6 +179,7 @@ def main():
                 "launches": n_launch,
             },
             "whole_path_algorithmic_GBs": tot["algorithmic_bytes"] / dt / 1e9,
+            "scene_commit_seconds": s1.get("seconds_commit"),    # flatten + SAH BVH + upload, once per scene, outside the timed region
             "seconds": {"wall": dt, "trace_closest": d["seconds_trace_closest"], "trace_any": d["seconds_trace_any"], "shade": d["seconds_shade"]},
             "per_path": {"segments": tot["segments"] / paths, "shadow_rays": tot["shadow_rays"] / paths,
                          "node_visits": (tot["node_visits_closest"] + tot["node_visits_any"]) / paths,

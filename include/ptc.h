@@ -141,6 +141,13 @@ int ptc_set_camera(ptc_ctx*, const float pos[3], const float target[3], float fo
  * luminance x sin(theta).  rgb == NULL removes it.  Call before ptc_scene_commit. */
 int ptc_set_env_latlong_rgb32f(ptc_ctx*, const float* rgb, int w, int h);
 
+/* Texture filter of the scene being described (applies to every texture; reset to NEAREST by ptc_scene_begin).
+ * PTC_FILTER_NEAREST is what the reference renders with — its samplers are default-constructed (gltf/Asset.cpp:116-117:
+ * NEAREST, REPEAT, no mips).  PTC_FILTER_LINEAR is an option the reference does not have: bilinear over the 4 nearest
+ * texels (centres at i + 1/2), REPEAT wrap, lerp(a, b, t) = fma(t, b - a, a) along x then y. */
+enum { PTC_FILTER_NEAREST = 0, PTC_FILTER_LINEAR = 1 };
+int ptc_set_texture_filter(ptc_ctx*, int filter);
+
 /* Flatten instances to world space (geometry_pass/vertex.glsl:25-36), build + flatten the BVH,
  * build the emitter CDF, upload everything to HBM. */
 int ptc_scene_commit(ptc_ctx*);

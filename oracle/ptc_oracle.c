@@ -217,6 +217,7 @@ struct ora_ctx {
   uint32_t* widx; uint32_t n_tris;     /* 3 per triangle        */
   int32_t* tri_mat;
   /* BVH (triangles in sorted order) */
+  int tex_linear;                      /* 0 = NEAREST (the reference's sampler), 1 = bilinear */
   uint32_t* order;                     /* sorted position → original prim id */
   v3 *tv0, *te1, *te2;                 /* per sorted position */
   node_t* nodes; uint32_t n_nodes; uint32_t max_depth;   /* binary radix tree (intermediate) */
@@ -255,7 +256,7 @@ static void free_description(ora_ctx* c) {
 }
 void ora_destroy(ora_ctx* c) { if (!c) return; free_committed(c); free_description(c); free(c); }
 
-int ora_scene_begin(ora_ctx* c) { free_committed(c); free_description(c); c->have_cam = 0; return 0; }
+int ora_scene_begin(ora_ctx* c) { free_committed(c); free_description(c); c->have_cam = 0; c->tex_linear = 0; return 0; }
 
 int ora_add_material(ora_ctx* c, const float base[4], float metallic, float roughness,
                      const float emissive[3], int tc, int tn, int tmr) {
@@ -310,6 +311,12 @@ int ora_set_camera(ora_ctx* c, const float pos[3], const float target[3], float 
 
 /* Lat-long environment map: w*h RGB texels, row 0 = +y (up), u = atan2(d.z, d.x)/(2pi) + 0.5.  Piecewise-constant
  * radiance; sampled proportionally to luminance x sin(theta_row) (row marginal + per-row conditional cdf). */
+int ora_set_texture_filter(ora_ctx* c, int mode) {
+  if (mode != 0 && mode != 1) return fail(c, "set_texture_filter: mode must be 0 (nearest) or 1 (linear)");
+  c->tex_linear = mode;
+  return 0;
+}
+
 int ora_set_env_latlong_rgb32f(ora_ctx* c, const float* px, int w, int h) {
   free(c->env_px); free(c->env_pmf); free(c->env_marg); free(c->env_cond);
   c->env_px = c->env_pmf = c->env_marg = c->env_cond = NULL; c->env_w = c->env_h = 0; c->env_ok = 0;
@@ -995,13 +1002,34 @@ typedef struct { v3 p, ng, ns; int front; const material_t* mat; float base[4]; 
 
 /* R7 sampler: the reference creates samplers with default create-info (gltf/Asset.cpp:116-117): NEAREST, REPEAT, no mips.
  * RGBA8 UNORM texel → float /255 (image/pbr/image/LoadImage.cpp:27). */
-static inline void tex_fetch(const tex_t* t, float u, float v, float out[4]) {
+static inline void tex_fetch(const tex_t* t, float u, float v, int linear, float out[4]) {
   float fu = u - floorf(u), fv = v - floorf(v);
-  int x = (int)(fu * (float)t->w), y = (int)(fv * (float)t->h);
-  if (x > t->w - 1) x = t->w - 1;
-  if (y > t->h - 1) y = t->h - 1;
-  const uint8_t* p = &t->px[((size_t)y * t->w + x) * 4];
-  for (int k = 0; k < 4; ++k) out[k] = (float)p[k] / 255.0f;
+  if (!linear) {
+    int x = (int)(fu * (float)t->w), y = (int)(fv * (float)t->h);
+    if (x > t->w - 1) x = t->w - 1;
+    if (y > t->h - 1) y = t->h - 1;
+    const uint8_t* p = &t->px[((size_t)y * t->w + x) * 4];
+    for (int k = 0; k < 4; ++k) out[k] = (float)p[k] / 255.0f;
+    return;
+  }
+  /* PTC_FILTER_LINEAR (not what the reference does; an option): texel centres at i + 0.5, REPEAT wrap,
+   * lerp(a, b, t) = fma(t, b - a, a), first along x then along y */
+  float x = fmaf(fu, (float)t->w, -0.5f), y = fmaf(fv, (float)t->h, -0.5f);
+  float x0f = floorf(x), y0f = floorf(y);
+  float tx = x - x0f, ty = y - y0f;
+  int x0 = (int)x0f, y0 = (int)y0f;
+  int x1 = x0 + 1, y1 = y0 + 1;
+  if (x0 < 0) x0 += t->w;
+  if (y0 < 0) y0 += t->h;
+  if (x1 > t->w - 1) x1 -= t->w;
+  if (y1 > t->h - 1) y1 -= t->h;
+  const uint8_t* p00 = &t->px[((size_t)y0 * t->w + x0) * 4]; const uint8_t* p10 = &t->px[((size_t)y0 * t->w + x1) * 4];
+  const uint8_t* p01 = &t->px[((size_t)y1 * t->w + x0) * 4]; const uint8_t* p11 = &t->px[((size_t)y1 * t->w + x1) * 4];
+  for (int k = 0; k < 4; ++k) {
+    float c00 = (float)p00[k] / 255.0f, c10 = (float)p10[k] / 255.0f, c01 = (float)p01[k] / 255.0f, c11 = (float)p11[k] / 255.0f;
+    float a = fmaf(tx, c10 - c00, c00), b = fmaf(tx, c11 - c01, c01);
+    out[k] = fmaf(ty, b - a, a);
+  }
 }
 
 #define LERP3(fa, fb, fc, k) fmaf((fc)[k], v, fmaf((fb)[k], u, (fa)[k] * w))
@@ -1025,10 +1053,10 @@ static inline surf_t reconstruct(const ora_ctx* c, v3 d, const hit_t* h, int two
   if (m->tex_color >= 0 || m->tex_normal >= 0 || m->tex_mr >= 0) {
     float tu = LERP3(a->texcoord, b->texcoord, e->texcoord, 0), tv = LERP3(a->texcoord, b->texcoord, e->texcoord, 1);
     float t4[4];
-    if (m->tex_color >= 0) { tex_fetch(&c->texs[m->tex_color], tu, tv, t4); for (int k = 0; k < 4; ++k) s.base[k] = m->base[k] * t4[k]; }   /* fragment.glsl:30 */
-    if (m->tex_mr >= 0) { tex_fetch(&c->texs[m->tex_mr], tu, tv, t4); s.roughness = m->roughness * t4[1]; s.metallic = m->metallic * t4[2]; }   /* glTF: G = roughness, B = metallic */
+    if (m->tex_color >= 0) { tex_fetch(&c->texs[m->tex_color], tu, tv, c->tex_linear, t4); for (int k = 0; k < 4; ++k) s.base[k] = m->base[k] * t4[k]; }   /* fragment.glsl:30 */
+    if (m->tex_mr >= 0) { tex_fetch(&c->texs[m->tex_mr], tu, tv, c->tex_linear, t4); s.roughness = m->roughness * t4[1]; s.metallic = m->metallic * t4[2]; }   /* glTF: G = roughness, B = metallic */
     if (m->tex_normal >= 0) {                                                                                       /* fragment.glsl:24-27 */
-      tex_fetch(&c->texs[m->tex_normal], tu, tv, t4);
+      tex_fetch(&c->texs[m->tex_normal], tu, tv, c->tex_linear, t4);
       float nx = 2.0f * t4[0] - 1.0f, ny = 2.0f * t4[1] - 1.0f, nz = 2.0f * t4[2] - 1.0f;
       v3 ti = V3(LERP3(a->tangent, b->tangent, e->tangent, 0), LERP3(a->tangent, b->tangent, e->tangent, 1), LERP3(a->tangent, b->tangent, e->tangent, 2));
       const float* ba = &c->wbt[(size_t)i0 * 3]; const float* bb = &c->wbt[(size_t)i1 * 3]; const float* be = &c->wbt[(size_t)i2 * 3];

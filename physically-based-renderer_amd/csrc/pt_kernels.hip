@@ -487,14 +487,34 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_any(DevS
 // =================================================================================================
 // R7 sampler: NEAREST, REPEAT, no mips (the reference creates its samplers with default create-info, gltf/Asset.cpp:116-117);
 // RGBA8 UNORM texel → float / 255.
+PT_DEV float4 texel_rgba(const DevScene& sc, size_t at) {
+  const uint32_t p = sc.texels[at];
+  return make_float4((float)(p & 255u) / 255.0f, (float)((p >> 8) & 255u) / 255.0f, (float)((p >> 16) & 255u) / 255.0f, (float)(p >> 24) / 255.0f);
+}
 PT_DEV float4 tex_fetch(const DevScene& sc, int tex, float u, float v) {
   const int4 ti = sc.tex_info[tex];
   const float fu = u - __builtin_floorf(u), fv = v - __builtin_floorf(v);
-  int x = (int)(fu * (float)ti.y), y = (int)(fv * (float)ti.z);
-  if (x > ti.y - 1) x = ti.y - 1;
-  if (y > ti.z - 1) y = ti.z - 1;
-  const uint32_t p = sc.texels[(size_t)ti.x + (size_t)y * (size_t)ti.y + (size_t)x];
-  return make_float4((float)(p & 255u) / 255.0f, (float)((p >> 8) & 255u) / 255.0f, (float)((p >> 16) & 255u) / 255.0f, (float)(p >> 24) / 255.0f);
+  if (!sc.tex_linear) {
+    int x = (int)(fu * (float)ti.y), y = (int)(fv * (float)ti.z);
+    if (x > ti.y - 1) x = ti.y - 1;
+    if (y > ti.z - 1) y = ti.z - 1;
+    return texel_rgba(sc, (size_t)ti.x + (size_t)y * (size_t)ti.y + (size_t)x);
+  }
+  // PTC_FILTER_LINEAR: texel centres at i + 0.5, REPEAT wrap, lerp(a, b, t) = fma(t, b - a, a), x then y
+  const float x = pt_fma(fu, (float)ti.y, -0.5f), y = pt_fma(fv, (float)ti.z, -0.5f);
+  const float x0f = __builtin_floorf(x), y0f = __builtin_floorf(y);
+  const float tx = x - x0f, ty = y - y0f;
+  int x0 = (int)x0f, y0 = (int)y0f;
+  int x1 = x0 + 1, y1 = y0 + 1;
+  if (x0 < 0) x0 += ti.y;
+  if (y0 < 0) y0 += ti.z;
+  if (x1 > ti.y - 1) x1 -= ti.y;
+  if (y1 > ti.z - 1) y1 -= ti.z;
+  const size_t r0 = (size_t)ti.x + (size_t)y0 * (size_t)ti.y, r1 = (size_t)ti.x + (size_t)y1 * (size_t)ti.y;
+  const float4 c00 = texel_rgba(sc, r0 + (size_t)x0), c10 = texel_rgba(sc, r0 + (size_t)x1), c01 = texel_rgba(sc, r1 + (size_t)x0), c11 = texel_rgba(sc, r1 + (size_t)x1);
+  const float ax = pt_fma(tx, c10.x - c00.x, c00.x), ay = pt_fma(tx, c10.y - c00.y, c00.y), az = pt_fma(tx, c10.z - c00.z, c00.z), aw = pt_fma(tx, c10.w - c00.w, c00.w);
+  const float bx = pt_fma(tx, c11.x - c01.x, c01.x), by = pt_fma(tx, c11.y - c01.y, c01.y), bz = pt_fma(tx, c11.z - c01.z, c01.z), bw = pt_fma(tx, c11.w - c01.w, c01.w);
+  return make_float4(pt_fma(ty, bx - ax, ax), pt_fma(ty, by - ay, ay), pt_fma(ty, bz - az, az), pt_fma(ty, bw - aw, aw));
 }
 
 // Textured surface attributes of primitive `prim` at barycentrics (hu, hv): base colour × texel, metallic-roughness texel

@@ -43,6 +43,7 @@ struct ptc_ctx {
   HostEnv env;
   float cam_pos[3]{}, cam_target[3]{}, cam_fov = 0, cam_aspect = 1;
   bool have_cam = false;
+  int tex_linear = 0;                    // PTC_FILTER_*: texture filter of the scene being described
   // committed scene
   bool committed = false;
   HostBuilt built;
@@ -317,7 +318,7 @@ int ptc_scene_begin(ptc_ctx* c) {
     HIP_TRY(c, hipSetDevice(c->device));
     { int rs = sync_all_lanes(c); if (rs) return rs; }
   }
-  c->mats.clear(); c->meshes.clear(); c->insts.clear(); c->texs.clear(); c->env = HostEnv{};
+  c->mats.clear(); c->meshes.clear(); c->insts.clear(); c->texs.clear(); c->env = HostEnv{}; c->tex_linear = 0;
   c->have_cam = false; c->committed = false; c->in_frame = false;
   free_all(c->scene_allocs);
   return PTC_OK;
@@ -391,6 +392,13 @@ int ptc_set_camera(ptc_ctx* c, const float pos[3], const float target[3], float 
   return PTC_OK;
 }
 
+int ptc_set_texture_filter(ptc_ctx* c, int filter) {
+  if (!c) return PTC_E_ARG;
+  if (filter != PTC_FILTER_NEAREST && filter != PTC_FILTER_LINEAR) return fail(c, PTC_E_ARG, "set_texture_filter: unknown filter");
+  c->tex_linear = filter;
+  return PTC_OK;
+}
+
 int ptc_set_env_latlong_rgb32f(ptc_ctx* c, const float* rgb, int w, int h) {
   if (!c) return PTC_E_ARG;
   if (!rgb) { c->env = HostEnv{}; return PTC_OK; }
@@ -436,6 +444,7 @@ int ptc_scene_commit(ptc_ctx* c) {
   }
   if (rc) { free_all(c->scene_allocs); return PTC_E_DEVICE; }
   d.env_w = B.env_w; d.env_h = B.env_h; d.env_ok = B.env_ok;
+  d.tex_linear = c->tex_linear;
   d.n_lights = B.n_lights; d.n_mats = (uint32_t)c->mats.size(); d.n_nodelets = B.n_nodelets; d.ray_eps = B.ray_eps;
   c->dsc = d;
   { int rc2 = configure_launch(c); if (rc2) { free_all(c->scene_allocs); return rc2; } }

@@ -17,6 +17,7 @@ struct DevScene {
   const float4* shade_tex;    // 6 × float4 per primitive, only when a material has a texture: uv ×3, world tangent ×3, world bitangent ×3
   const uint32_t* texels;     // all RGBA8 textures back to back
   const int4* tex_info;       // per texture: (offset into texels, width, height, 0)
+  int tex_linear;             // 0 = NEAREST (the reference's sampler), 1 = bilinear
   const float4* env;          // lat-long environment: (radiance.rgb, texel pmf) per texel, row 0 = +y
   const float* env_marg;      // row cdf (env_h)
   const float* env_cond;      // per-row column cdf (env_w × env_h)

@@ -94,3 +94,31 @@ def test_environment_argument_errors(ora, pbr):
     pt = pbr.PathTracer(pbr.DEVICE_NONE)
     with pytest.raises(pbr.PtcError, match="texture id out of range"):
         pt.load_scene(_plane_scene(pbr, pbr.scene.Material((1, 1, 1, 1), 0.0, 1.0, (0, 0, 0), 3, -1, -1)))
+
+
+def test_bilinear_filter_option(ora, pbr):
+    """PTC_FILTER_LINEAR (an option beyond the reference, whose samplers are NEAREST): a 2-texel-wide black→white texture under a
+    white furnace shows a linear ramp between the texel centres, wraps around (REPEAT), and the NEAREST result stays a step."""
+    tex = np.zeros((1, 2, 4), np.uint8)
+    tex[0, 1] = 255
+    tex[..., 3] = 255
+    env = np.ones((8, 16, 3), np.float32)
+    mat = pbr.scene.Material((1.0, 1.0, 1.0, 1.0), 0.0, 1.0, (0, 0, 0), 0, -1, -1)
+    d = _plane_scene(pbr, mat, [tex], env, uv_scale=1.0)
+    d.camera = pbr.scene.CameraDesc((0, 60, 0), (0, 0, -0.001), 1.2, 1.0)      # sees most of the 100-unit plane = one uv period
+    o = ora.Oracle()
+    near = o.load_scene(d).render(64, 64, 32, seed=2, max_bounces=2)[..., 0]
+    d.texture_filter = "linear"
+    lin = o.load_scene(d).render(64, 64, 32, seed=2, max_bounces=2)[..., 0]
+    row_n, row_l = near.mean(0), lin.mean(0)
+    assert set(np.round(row_n, 1)) <= {0.0, 1.0}                                # a step
+    # between the two texel centres (u = 1/4 and 3/4) the ramp is linear in u; u maps linearly to the pixel column here
+    inner = row_l[20:44]
+    k = np.arange(inner.size)
+    slope, icpt = np.polyfit(k, inner, 1)
+    assert abs(slope) > 0.02 and np.abs(inner - (slope * k + icpt)).max() < 0.02, (slope, inner)      # a straight ramp (Monte-Carlo noise aside)
+    assert 0.4 < row_l[32] < 0.6 and abs(row_l.mean() - 0.5) < 0.03                 # symmetric wrap-around: the mean stays 1/2
+    # exact texels: sampling at a texel centre returns the texel
+    assert min(row_l) < 0.05 and max(row_l) > 0.95
+    d.texture_filter = "nearest"                                                  # scene_begin resets the filter
+    assert np.array_equal(o.load_scene(d).render(64, 64, 32, seed=2, max_bounces=2)[..., 0], near)
