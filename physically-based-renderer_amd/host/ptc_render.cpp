@@ -1,6 +1,6 @@
 // ptc_render — dependency-free C++17 offline renderer over the C-ABI (include/ptc.h).
 //   ptc_render (--scene cornell|sphere | --gltf file.glb [--cam-pos x y z --cam-target x y z --fov deg]) --width W --height H
-//              --spp N --seed S --bounces B [--raster] [--env latlong.pfm | --sky] --out image.pfm [--png image.png] [--ppm image.ppm]
+//              --spp N --seed S --bounces B [--raster] [--env latlong.pfm | --sky] [--filter nearest|linear] --out image.pfm [--png image.png] [--ppm image.ppm]
 // --env: ordinary lat-long RGB environment map (PFM, top row = up).  The reference's world is y-down (up = -y, CameraData.hpp:28) and
 // ptc_set_env_latlong_rgb32f takes row 0 = +y, so the rows are flipped on the way in.  --sky: a built-in gradient sky with a sun, for
 // assets that carry no emitters.
@@ -103,6 +103,7 @@ void buildSphere(pbr::PathTraceRenderSystem& rs, float aspect) {
 int main(int argc, char** argv) {
   std::string scene = "cornell", out = "out.pfm", ppm, png, gltf, envPath;
   bool sky = false;
+  int filter = PTC_FILTER_NEAREST;          // what the reference's default-constructed samplers do
   float camPos[3] = {0, 0, 0}, camTarget[3] = {0, 0, -1}, fovDeg = 60.0f;
   bool haveCam = false;
   int w = 256, h = 256, spp = 64, bounces = 8, device = 0, integrator = PTC_INTEGRATOR_PATH;
@@ -115,6 +116,7 @@ int main(int argc, char** argv) {
     else if (a == "--bounces") bounces = std::atoi(next()); else if (a == "--device") device = std::atoi(next());
     else if (a == "--gltf") gltf = next();
     else if (a == "--env") envPath = next(); else if (a == "--sky") sky = true;
+    else if (a == "--filter") { const std::string f = next(); if (f == "linear") filter = PTC_FILTER_LINEAR; else if (f == "nearest") filter = PTC_FILTER_NEAREST; else { std::cerr << "--filter nearest|linear\n"; return 2; } }
     else if (a == "--cam-pos") { for (float& v : camPos) v = (float)std::atof(next()); haveCam = true; }
     else if (a == "--cam-target") { for (float& v : camTarget) v = (float)std::atof(next()); }
     else if (a == "--fov") fovDeg = (float)std::atof(next());
@@ -127,6 +129,7 @@ int main(int argc, char** argv) {
       const pbr::gltf::FlatScene fs = pbr::gltf::load(gltf);
       rs.beginScene();
       if (pbr::gltf::upload(rs.handle(), fs) < 0) throw std::runtime_error(ptc_last_error(rs.handle()));
+      if (ptc_set_texture_filter(rs.handle(), filter) < 0) throw std::runtime_error(ptc_last_error(rs.handle()));
       if (!haveCam) {   // frame the bounding box from +z
         const float cx = 0.5f * (fs.bbox_lo[0] + fs.bbox_hi[0]), cy = 0.5f * (fs.bbox_lo[1] + fs.bbox_hi[1]), cz = 0.5f * (fs.bbox_lo[2] + fs.bbox_hi[2]);
         const float r = 0.5f * std::sqrt((fs.bbox_hi[0] - fs.bbox_lo[0]) * (fs.bbox_hi[0] - fs.bbox_lo[0]) + (fs.bbox_hi[1] - fs.bbox_lo[1]) * (fs.bbox_hi[1] - fs.bbox_lo[1]) +
