@@ -1,5 +1,6 @@
 #!/bin/bash
-# usage: tools/envsweep.sh "VAR=val VAR2=val" ...   runs a short bench under each environment
-for ev in "$@"; do
-  env $ev python bench.py --steps 6 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('$ev', '=> %.1f Mpaths/s' % d['value'], {k: round(v,4) for k,v in d['seconds'].items()})"
+# usage: tools/envsweep.sh "<bench args>|VAR=val ..." ...
+for item in "$@"; do
+  ar="${item%%|*}"; ev="${item#*|}"
+  env $ev python bench.py $ar --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('$ar | $ev', '=> %.1f Mpaths/s' % d['value'], {k: round(v,4) for k,v in d['seconds'].items()})"
 done
