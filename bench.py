@@ -4,7 +4,7 @@
 Workload (config.workload): the Sponza-class procedural atrium (249,936 triangles, SURVEY §8d row 3 —
 the reference's assets are stripped, so the scene is generated) at 1920×1080.  One STEP = one
 wavefront batch of `--spp-per-step` samples of every pixel this rank owns; the default
-32 steps × 32 spp = the 1024 spp of BASELINE.json's metric (successive batches alternate between two
+16 steps × 64 spp = the 1024 spp of BASELINE.json's metric (successive batches alternate between two
 HIP streams so that one batch's launch tails overlap the other's full-occupancy phases).  Inputs (scene, BVH, queues) are
 resident in HBM before the timed region.
 
@@ -42,9 +42,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp-per-step", type=int, default=32)
+    ap.add_argument("--spp-per-step", type=int, default=64)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--max-bounces", type=int, default=8)
