@@ -499,3 +499,17 @@ def test_random_scenes_are_bit_exact(gpu, ora):
         for key in COUNTERS + ("n_bvh_nodes", "bvh_max_depth", "n_emitters", "n_triangles"):
             assert sg[key] == so[key], (k, key)
         assert _bits_equal(pt.render(w, h, 1, integrator=gpu.INTEGRATOR_RASTER_COMPAT), o.render(w, h, 1, integrator=1)), k
+
+
+def test_full_resolution_frame_is_bit_exact(gpu, ora):
+    """BASELINE config 3 at its real resolution: 1920x1080 on the 249,936-triangle atrium, 2 spp (the oracle needs a few
+    seconds for 4 M paths on the box's host cores) — image, counters and tone-mapped bytes identical."""
+    d = gpu.scenes.atrium()
+    d.camera.aspect = 1920 / 1080
+    pt, o = _pair(gpu, ora, d)
+    g = pt.render(1920, 1080, 2, seed=3, max_bounces=8)
+    c = o.render(1920, 1080, 2, seed=3, max_bounces=8, n_threads=ora.hw_threads())
+    assert _bits_equal(g, c), int((g != c).any(-1).sum())
+    for k in COUNTERS:
+        assert pt.stats()[k] == o.stats()[k], k
+    assert np.array_equal(pt.tonemap(), ora.tonemap_rgba8(c))
