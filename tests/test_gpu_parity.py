@@ -513,3 +513,27 @@ def test_full_resolution_frame_is_bit_exact(gpu, ora):
     for k in COUNTERS:
         assert pt.stats()[k] == o.stats()[k], k
     assert np.array_equal(pt.tonemap(), ora.tonemap_rgba8(c))
+
+
+def test_camera_change_without_recommit(gpu, ora):
+    """Viewer-style use: the camera moves between frames of a committed scene — no BVH rebuild, and each
+    frame equals a fresh context (and the oracle) with that camera; progressive accumulation restarts with frame_begin."""
+    sc = gpu.scene
+    d = gpu.scenes.sphere_scene(32, 17)
+    pt = gpu.PathTracer(0).load_scene(d)
+    commit_s = pt.stats()["seconds_commit"]
+    for k, (pos, tgt, fov) in enumerate((((0.0, 1.0, 6.0), (0.0, 0.0, 0.0), 0.8), ((3.0, 2.0, 3.0), (0.0, -0.2, 0.0), 1.1), ((-4.0, 0.5, 1.0), (0.5, 0.0, 0.0), 0.6))):
+        pt.set_camera(pos, tgt, fov, 1.5)
+        g = pt.render(96, 64, 3, seed=k, max_bounces=4)
+        d2 = sc.SceneDesc(d.materials, d.meshes, d.instances, sc.CameraDesc(pos, tgt, fov, 1.5))
+        c = ora.Oracle().load_scene(d2).render(96, 64, 3, seed=k, max_bounces=4)
+        assert _bits_equal(g, c), k
+        assert pt.stats()["seconds_commit"] == commit_s                      # the scene was not committed again
+    # progressive: 1 + 2 samples added to one frame = the 3-sample frame
+    pt.frame_begin(96, 64, 3, 2, 4, 0)
+    pt.frame_add_samples(1)
+    pt.frame_resolve()
+    first = pt.read_radiance().copy()
+    pt.frame_add_samples(2)
+    pt.frame_resolve()
+    assert _bits_equal(pt.read_radiance(), g) and not np.array_equal(first, g)
