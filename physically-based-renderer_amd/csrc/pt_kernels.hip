@@ -287,6 +287,7 @@ struct Reservoir {
 template <bool CULL, bool NODELETS>
 __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_closest(DevScene sc, DevQueues q, int qi, int stack_lds) {
   extern __shared__ float4 lds_raw[];
+  __shared__ uint8_t s_pair[2][TRACE_WAVES][64];   // leaf phase: k-th two-triangle lane <-> k-th idle lane
   float4* lds_nodes = lds_raw;                                                       // [n_nodelets × 48 B]
   uint2* lds_stack = reinterpret_cast<uint2*>(lds_raw + (NODELETS ? (size_t)sc.n_nodelets * 3 : 0));   // [waves][L][64]
   const uint32_t lane = lane_id();
@@ -354,23 +355,69 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_closest(
         }
       }
       STAMP(t_node);
-      if (cur < 0 && cur > CUR_FINISHED) {                                        // a leaf
-        const uint32_t code = (uint32_t)~cur;
-        const uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
-        DIAG_ITER(d_leaf);
-        for (uint32_t k = first; k < first + count; ++k) {
-          const float4 a = sc.tris[(size_t)k * 3 + 0], b = sc.tris[(size_t)k * 3 + 1], c = sc.tris[(size_t)k * 3 + 2];
-          DIAG_ITER(d_tri);
-          ++nt;
-          float t, u, v;
-          if (!tri_test<CULL>(r, V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), t, u, v)) continue;
-          const int pid = __float_as_int(a.w);
-          if (t > tmin && (t < best_t || (t == best_t && pid < best_prim))) {
-            best_t = t; best_u = u; best_v = v; best_prim = pid; best_cls = __float_as_int(b.w); found = true;
+      {
+        // ---- leaf phase.  A leaf holds 1 or 2 triangles (PT_LEAF_MAX).  The second triangle of a leaf is tested in the
+        // SAME pass by an idle lane (a lane that is not at a leaf) with the owner's ray fetched through ds_bpermute, instead
+        // of a second pass over the few lanes that have one: same tests, same order of the hit updates, half the passes.
+        const bool leaf = cur < 0 && cur > CUR_FINISHED;
+        const uint64_t m_leaf = __ballot(leaf);
+        if (m_leaf) {
+          const uint32_t code = leaf ? (uint32_t)~cur : 0u;
+          const uint32_t first = code & 0x0fffffffu, count = leaf ? (code >> 28) + 1u : 0u;
+          const bool two = count == 2u;
+          const uint64_t m_two = __ballot(two), m_free = ~m_leaf;
+          const uint32_t n_two = (uint32_t)__popcll(m_two);
+          if (__ballot(count > 2u) == 0 && n_two <= (uint32_t)__popcll(m_free)) {
+            const uint32_t rank_two = mbcnt64(m_two), rank_free = mbcnt64(m_free);
+            const bool helper = !leaf && rank_free < n_two;
+            typedef __attribute__((address_space(3))) volatile uint8_t lds_u8;
+            lds_u8* tab_owner = (lds_u8*)s_pair[0][wave];
+            lds_u8* tab_helper = (lds_u8*)s_pair[1][wave];
+            if (two) tab_owner[rank_two] = (uint8_t)lane;
+            if (helper) tab_helper[rank_free] = (uint8_t)lane;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int src = helper ? (int)tab_owner[rank_free] : (int)lane;      // whose ray this lane tests with
+            ray_t rr;
+            rr.o = V3(__shfl(r.o.x, src), __shfl(r.o.y, src), __shfl(r.o.z, src));
+            rr.d = V3(__shfl(r.d.x, src), __shfl(r.d.y, src), __shfl(r.d.z, src));
+            const uint32_t first_src = (uint32_t)__shfl((int)first, src);         // unconditional: a shuffle inside ?: would run with the owners masked off
+            const uint32_t k = helper ? first_src + 1u : first;
+            bool hit = false; float t = 0.0f, u = 0.0f, v = 0.0f; int pid = 0, cls = 0;
+            if (leaf || helper) {
+              const float4 a = sc.tris[(size_t)k * 3 + 0], b = sc.tris[(size_t)k * 3 + 1], c = sc.tris[(size_t)k * 3 + 2];
+              ++nt;
+              hit = tri_test<CULL>(rr, V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), t, u, v);
+              pid = __float_as_int(a.w); cls = __float_as_int(b.w);
+            }
+            if (leaf && hit && t > tmin && (t < best_t || (t == best_t && pid < best_prim))) {
+              best_t = t; best_u = u; best_v = v; best_prim = pid; best_cls = cls; found = true;
+            }
+            const int hsrc = two ? (int)tab_helper[rank_two] : (int)lane;        // the lane that tested this leaf's second triangle
+            const int h2 = __shfl(hit ? 1 : 0, hsrc);
+            const float t2 = __shfl(t, hsrc), u2 = __shfl(u, hsrc), v2 = __shfl(v, hsrc);
+            const int pid2 = __shfl(pid, hsrc), cls2 = __shfl(cls, hsrc);
+            if (two && h2 && t2 > tmin && (t2 < best_t || (t2 == best_t && pid2 < best_prim))) {
+              best_t = t2; best_u = u2; best_v = v2; best_prim = pid2; best_cls = cls2; found = true;
+            }
+          } else if (leaf) {                                                      // no spare lanes (or wider leaves): one triangle per pass
+            for (uint32_t k = first; k < first + count; ++k) {
+              const float4 a = sc.tris[(size_t)k * 3 + 0], b = sc.tris[(size_t)k * 3 + 1], c = sc.tris[(size_t)k * 3 + 2];
+              ++nt;
+              float t, u, v;
+              if (!tri_test<CULL>(r, V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), t, u, v)) continue;
+              const int pid = __float_as_int(a.w);
+              if (t > tmin && (t < best_t || (t == best_t && pid < best_prim))) {
+                best_t = t; best_u = u; best_v = v; best_prim = pid; best_cls = __float_as_int(b.w); found = true;
+              }
+            }
+          }
+          if (leaf) {
+            cur = CUR_FINISHED;
+            while (!st.empty()) { const uint2 e = st.pop(); if (__uint_as_float(e.y) > best_t) continue; cur = (int)e.x; break; }
           }
         }
-        cur = CUR_FINISHED;
-        while (!st.empty()) { const uint2 e = st.pop(); if (__uint_as_float(e.y) > best_t) continue; cur = (int)e.x; break; }
       }
       STAMP(t_leaf);
       nh += (unsigned long long)__popcll(__ballot(cur == CUR_FINISHED && found));
@@ -404,6 +451,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_closest(
 template <bool NODELETS, bool DEBUG_OUT>
 __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_any(DevScene sc, DevQueues q, int stack_lds, uint8_t* debug_out) {
   extern __shared__ float4 lds_raw[];
+  __shared__ uint8_t s_pair[2][TRACE_WAVES][64];   // leaf phase: k-th two-triangle lane <-> k-th idle lane
   float4* lds_nodes = lds_raw;
   uint2* lds_stack = reinterpret_cast<uint2*>(lds_raw + (NODELETS ? (size_t)sc.n_nodelets * 3 : 0));
   const uint32_t lane = lane_id();
@@ -452,19 +500,60 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_any(DevS
           if (cur == CODE_EMPTY) cur = st.empty() ? CUR_FINISHED : (int)st.pop().x;
         }
       }
-      if (cur < 0 && cur > CUR_FINISHED) {
-        const uint32_t code = (uint32_t)~cur;
-        const uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
-        for (uint32_t k = first; k < first + count; ++k) {
-          const float4 a = sc.tris[(size_t)k * 3 + 0], b = sc.tris[(size_t)k * 3 + 1], c = sc.tris[(size_t)k * 3 + 2];
-          ++nt;
-          float t, u, v;
-          if (tri_test<false>(r, V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), t, u, v) && t > 0.0f && t < tmax) {
-            occluded = true;
-            break;
+      {
+        // ---- leaf phase: as in k_trace_closest, the second triangle of a 2-triangle leaf is tested in the same pass by an idle
+        // lane.  The counter stays the sequential one: the second test is counted only when the first one missed.
+        const bool leaf = cur < 0 && cur > CUR_FINISHED;
+        const uint64_t m_leaf = __ballot(leaf);
+        if (m_leaf) {
+          const uint32_t code = leaf ? (uint32_t)~cur : 0u;
+          const uint32_t first = code & 0x0fffffffu, count = leaf ? (code >> 28) + 1u : 0u;
+          const bool two = count == 2u;
+          const uint64_t m_two = __ballot(two), m_free = ~m_leaf;
+          const uint32_t n_two = (uint32_t)__popcll(m_two);
+          if (__ballot(count > 2u) == 0 && n_two <= (uint32_t)__popcll(m_free)) {
+            const uint32_t rank_two = mbcnt64(m_two), rank_free = mbcnt64(m_free);
+            const bool helper = !leaf && rank_free < n_two;
+            typedef __attribute__((address_space(3))) volatile uint8_t lds_u8;
+            lds_u8* tab_owner = (lds_u8*)s_pair[0][wave];
+            lds_u8* tab_helper = (lds_u8*)s_pair[1][wave];
+            if (two) tab_owner[rank_two] = (uint8_t)lane;
+            if (helper) tab_helper[rank_free] = (uint8_t)lane;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int src = helper ? (int)tab_owner[rank_free] : (int)lane;
+            ray_t rr;
+            rr.o = V3(__shfl(r.o.x, src), __shfl(r.o.y, src), __shfl(r.o.z, src));
+            rr.d = V3(__shfl(r.d.x, src), __shfl(r.d.y, src), __shfl(r.d.z, src));
+            const float tmax_src = __shfl(tmax, src);
+            const uint32_t first_src = (uint32_t)__shfl((int)first, src);         // unconditional (see k_trace_closest)
+            const uint32_t k = helper ? first_src + 1u : first;
+            bool hit = false;
+            if (leaf || helper) {
+              const float4 a = sc.tris[(size_t)k * 3 + 0], b = sc.tris[(size_t)k * 3 + 1], c = sc.tris[(size_t)k * 3 + 2];
+              float t, u, v;
+              hit = tri_test<false>(rr, V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), t, u, v) && t > 0.0f && t < tmax_src;
+            }
+            const int hsrc = two ? (int)tab_helper[rank_two] : (int)lane;
+            const int h2 = __shfl(hit ? 1 : 0, hsrc);
+            if (leaf) {
+              nt += 1u + ((two && !hit) ? 1u : 0u);
+              if (hit || (two && h2)) occluded = true;
+            }
+          } else if (leaf) {
+            for (uint32_t k = first; k < first + count; ++k) {
+              const float4 a = sc.tris[(size_t)k * 3 + 0], b = sc.tris[(size_t)k * 3 + 1], c = sc.tris[(size_t)k * 3 + 2];
+              ++nt;
+              float t, u, v;
+              if (tri_test<false>(r, V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), t, u, v) && t > 0.0f && t < tmax) {
+                occluded = true;
+                break;
+              }
+            }
           }
+          if (leaf) cur = (occluded || st.empty()) ? CUR_FINISHED : (int)st.pop().x;
         }
-        cur = (occluded || st.empty()) ? CUR_FINISHED : (int)st.pop().x;
       }
       if (cur == CUR_FINISHED) {
         if (DEBUG_OUT) debug_out[ri] = occluded ? 1 : 0;
