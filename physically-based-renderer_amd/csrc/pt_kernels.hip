@@ -28,7 +28,7 @@
 #define TRACE_CHUNK 512u          // rays per work-fetch atomic
 #endif
 #ifndef TRACE_REFILL_IDLE
-#define TRACE_REFILL_IDLE 16      // refill as soon as this many lanes are idle
+#define TRACE_REFILL_IDLE 4       // refill as soon as this many lanes are idle (1..24 swept: flat optimum 4..8, +1 % over 16)
 #endif
 #ifndef TRACE_NODE_MIN
 #define TRACE_NODE_MIN 36         // leave the node loop when fewer lanes than this are still at interior nodes
