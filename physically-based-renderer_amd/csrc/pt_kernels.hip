@@ -31,7 +31,7 @@
 #define TRACE_REFILL_IDLE 4       // refill as soon as this many lanes are idle (1..24 swept: flat optimum 4..8, +1 % over 16)
 #endif
 #ifndef TRACE_NODE_MIN
-#define TRACE_NODE_MIN 36         // leave the node loop when fewer lanes than this are still at interior nodes
+#define TRACE_NODE_MIN 40         // leave the node loop when fewer lanes than this are still at interior nodes
 #endif                            // while others wait at a leaf (keeps both phases well populated)
 #ifndef SHADE_BLOCK
 #define SHADE_BLOCK 512
