@@ -2,25 +2,32 @@
 """bench.py — Mpaths/s of the wavefront path tracer on BASELINE.json's headline configuration.
 
 Workload (config.workload): the Sponza-class procedural atrium (249,936 triangles, SURVEY §8d row 3 —
-the reference's assets are stripped, so the scene is generated) at 1920×1080.  One STEP = one
-wavefront batch of `--spp-per-step` samples of every pixel this rank owns; the default
-16 steps × 64 spp = the 1024 spp of BASELINE.json's metric (successive batches alternate between two
-HIP streams so that one batch's launch tails overlap the other's full-occupancy phases).  Inputs (scene, BVH, queues) are
-resident in HBM before the timed region.
+the reference's assets are stripped, so the scene is generated) at 1920×1080.  One STEP = `--spp-per-step`
+samples of every pixel of the frame; the default 16 steps × 64 spp = the 1024 spp of BASELINE.json's metric.
+Inputs (scene, BVH, queues) are resident in HBM before the timed region.
 
 Contract: W untimed warm-up steps, then exactly K timed steps bracketed by barrier +
 torch.cuda.synchronize() on both sides, MAX over ranks, rank 0 prints ONE JSON line.
 N > 1: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`; one process per
 GPU, 32×32-pixel tiles interleaved over ranks, and the single collective of the path — the RCCL fp32
-sum of the framebuffer onto rank 0 — is inside the timed region.  Scaling is WEAK by default (SURVEY
-§8e, the path partitions by tile with no data-path exchange): a step adds `spp-per-step × N` samples, so
-every rank keeps the N=1 batch size (its 1/N of the pixels × N× the samples) and the job renders
-1024·N spp of the frame; `--scaling strong` keeps the 1024-spp frame fixed instead (per-rank batches
-shrink by N).
+sum of the framebuffer onto rank 0 (ncclReduce through the C-ABI, ptc_comm_reduce_radiance) — is inside
+the timed region.  Scaling is STRONG by default: the frame is the metric's fixed 1920×1080×1024-spp frame at
+every N, a rank traces its 1/N of the pixels.  The library merges the samples of successive steps into full
+wavefront batches (ptc_frame_add_samples defers a partial batch), so a rank's launches stay as wide as at N=1
+(N× deeper in samples) instead of shrinking by N; everything queued is finished inside the timed region
+(resolve + sync + reduce).  `--scaling weak` is the opt-in alternative: a step adds spp-per-step × N samples
+(the job renders 1024·N spp).
 
 Extra objects on the JSON line:
-  roofline     dominant kernel k_trace_closest: algorithmic bytes (counted node visits × 48 B +
-               triangle tests × 48 B + ray/hit records) ÷ its HIP-event time, against 8 TB/s HBM.
+  roofline     the dominant kernel, k_trace_closest, against the bound that limits it: VALU issue.
+               achieved = counted node visits × the VALU wave-instructions per node visit calibrated from
+               the committed rocprofv3 PMC profile (profiles/r02_kernel_model.json: SQ_INSTS_VALU ÷ counted
+               visits of the same workload) ÷ the kernel's HIP-event time; peak = the measured issue rate of
+               an all-fma stream at 7 waves per SIMD (tools/valu_issue_bench.hip → profiles/r02_valu_issue.json).
+               `traffic` = HBM-side bytes per launch from the same PMC profile; `algorithmic_*` = the
+               SURVEY §8(d) byte model (counted units × record sizes), labelled as such: those bytes are mostly
+               served by LDS / L2 / Infinity Cache and are NOT an HBM roofline.
+  kernels      the same two rooflines (valu_issue, hbm) for k_trace_closest, k_trace_any and k_shade.
   cpu_baseline the oracle (scalar C restatement, kind "port") timed on this box's host cores on a
                bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -37,6 +44,18 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "physically-based-renderer_amd"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+N_SIMD = 1024          # 256 CUs × 4 SIMD32
+# VALU issue: a wave64 instruction occupies a SIMD32 for 2 cycles → 1024 SIMDs × 2.4 GHz / 2 = 1228.8 G wave-instr/s on paper;
+# measured with an all-v_fma_f32 stream at 7 waves per SIMD (profiles/r02_valu_issue.json): 1.127 ns per instruction and SIMD.
+VALU_PEAK_PAPER_GIPS = N_SIMD * 2.4 / 2.0
+
+
+def _load_json(path):
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return None
 
 
 def main():
@@ -57,8 +76,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --share-device rehearses N ranks on a one-GPU box")
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="N > 1: weak = every step adds spp-per-step x N samples (per-GPU batch as at N=1); strong = the 1024-spp frame is fixed")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="N > 1: strong (default) = the metric's fixed 1024-spp frame, a rank traces 1/N of the pixels; weak = every step adds spp-per-step x N samples")
+    ap.add_argument("--reduce", choices=["cabi", "torch"], default="cabi",
+                    help="N > 1: cabi = ncclReduce through the C-ABI (ptc_comm_*), the id shipped over torch.distributed; torch = torch.distributed.reduce on the zero-copy tensor")
     args = ap.parse_args()
 
     import numpy as np
@@ -90,6 +111,23 @@ def main():
     K, W, S = args.steps, args.warmup, args.spp_per_step * (world if args.scaling == "weak" else 1)
     spp_total = (K + W) * S
     pt.frame_begin(args.width, args.height, spp_total, args.seed, args.max_bounces, pbr_amd.INTEGRATOR_PATH, tile_rank=rank, tile_count=world)
+    reduce_impl = None
+    if world > 1:
+        reduce_impl = "torch.distributed.reduce"
+        if args.reduce == "cabi":
+            # rank 0 makes the RCCL unique id (C-ABI), torch.distributed ships it, every rank joins the communicator
+            ok, uid = 1, None
+            if rank == 0:
+                try:
+                    uid = pbr_amd.comm_unique_id()
+                except pbr_amd.PtcError as e:
+                    print(f"bench: ptc_comm_unique_id failed ({e}); falling back to torch.distributed.reduce", file=sys.stderr)
+                    ok = 0
+            box = [uid if ok else None]
+            dist.broadcast_object_list(box, src=0)
+            if box[0] is not None:
+                pt.comm_init(box[0], rank, world)
+                reduce_impl = "ncclReduce via C-ABI (ptc_comm_reduce_radiance)"
 
     def barrier():
         if world > 1:
@@ -105,10 +143,14 @@ def main():
     for _ in range(K):
         pt.frame_add_samples(S)
     pt.frame_resolve()
-    pt.sync()
-    if world > 1:
-        fb = pdist.radiance_tensor(pt, args.width, args.height)
-        pdist.reduce_framebuffer(fb, 0)
+    if world > 1 and reduce_impl.startswith("ncclReduce"):
+        pt.comm_reduce_radiance(0)           # queued on the context's stream behind the resolve
+        pt.sync()
+    else:
+        pt.sync()
+        if world > 1:
+            fb = pdist.radiance_tensor(pt, args.width, args.height)
+            pdist.reduce_framebuffer(fb, 0)
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
@@ -131,20 +173,45 @@ def main():
     if rank == 0:
         paths = args.width * args.height * S * K
         assert abs(tot["paths"] - paths) < 0.5, (tot["paths"], paths)
-        # dominant kernel on this rank: k_trace_closest.  Algorithmic bytes per launch = counted units
-        # × record sizes (DESIGN.md §Algorithmic bytes) ÷ launches; duration = HIP events on the
-        # kernel's own stream, summed by the library, ÷ launches.
+        # Rooflines of the three kernels that carry the frame, on this rank.  Units are counted by the kernels; the
+        # per-unit instruction and HBM-byte figures come from the committed PMC profile of the same workload.
+        model = _load_json(os.path.join(ROOT, "profiles", "r02_kernel_model.json")) or {}
+        valu = _load_json(os.path.join(ROOT, "profiles", "r02_valu_issue.json")) or {}
+        ns_per_instr = valu.get("ns_per_instr_per_simd_at_7_waves")
+        valu_peak_measured = N_SIMD / ns_per_instr if ns_per_instr else None          # G wave-instr/s
+        units = {"k_trace_closest": ("node_visits_closest", d["seconds_trace_closest"], max(1, d["launches_trace_closest"])),
+                 "k_trace_any": ("node_visits_any", d["seconds_trace_any"], max(1, d["launches_trace_any"])),
+                 "k_shade": ("segments", d["seconds_shade"], max(1, d["launches_trace_closest"]))}
+        kernels = {}
+        for kname, (ukey, sec, nl) in units.items():
+            m = model.get(kname, {})
+            n_units = float(d[ukey])
+            e = {"unit_counted": ukey, "units_per_launch": n_units / nl, "avg_launch_ms": sec / nl * 1e3, "launches": nl}
+            if m.get("valu_winstr_per_unit") and sec > 0:
+                gips = n_units * m["valu_winstr_per_unit"] / sec / 1e9
+                e["valu_issue"] = {"achieved": gips, "unit": "G wave-instr/s", "peak": valu_peak_measured or VALU_PEAK_PAPER_GIPS,
+                                   "peak_kind": "measured all-fma stream, 7 waves/SIMD" if valu_peak_measured else "paper: 1024 SIMD x 2.4 GHz / 2 cycles",
+                                   "frac": gips / (valu_peak_measured or VALU_PEAK_PAPER_GIPS), "frac_of_paper_peak": gips / VALU_PEAK_PAPER_GIPS}
+            if m.get("hbm_bytes_per_unit") and sec > 0:
+                gbs = n_units * m["hbm_bytes_per_unit"] / sec / 1e9
+                e["hbm"] = {"achieved": gbs, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
+                            "bytes_per_launch": n_units * m["hbm_bytes_per_unit"] / nl}
+            kernels[kname] = e
         n_launch = max(1, d["launches_trace_closest"])
-        tc_bytes = d["segments"] * (56 + 16) + d["node_visits_closest"] * 48 + d["tri_tests_closest"] * 48
+        tc_bytes = d["segments"] * (56 + 16) + d["node_visits_closest"] * 80 + d["tri_tests_closest"] * 48
         tc_sec = d["seconds_trace_closest"]
-        achieved = tc_bytes / tc_sec / 1e9 if tc_sec > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("k_trace_closest_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        tc = kernels["k_trace_closest"]
+        if "valu_issue" in tc:
+            roof = {"bound": "valu_issue", "kernel": "k_trace_closest", "achieved": tc["valu_issue"]["achieved"], "peak": tc["valu_issue"]["peak"],
+                    "unit": "G wave-instr/s", "frac": tc["valu_issue"]["frac"], "frac_of_paper_peak": tc["valu_issue"]["frac_of_paper_peak"],
+                    "peak_kind": tc["valu_issue"]["peak_kind"], "traffic": tc.get("hbm", {}).get("bytes_per_launch"),
+                    "hbm_achieved_GBs": tc.get("hbm", {}).get("achieved"), "hbm_frac": tc.get("hbm", {}).get("frac")}
+        else:   # no committed profile to calibrate from: report the physical side as unknown rather than a byte model as a bound
+            roof = {"bound": "valu_issue", "kernel": "k_trace_closest", "achieved": None, "peak": VALU_PEAK_PAPER_GIPS, "unit": "G wave-instr/s", "frac": None, "traffic": None}
+        roof.update({"avg_launch_ms": tc_sec / n_launch * 1e3, "launches": n_launch,
+                     "algorithmic_bytes_per_launch": tc_bytes / n_launch,
+                     "algorithmic_GBs": tc_bytes / tc_sec / 1e9 if tc_sec > 0 else 0.0,
+                     "algorithmic_note": "SURVEY 8(d) byte model (counted units x record sizes); served mostly by LDS/L2/Infinity Cache, not an HBM bound"})
         out = {
             "metric": "Mpaths/s + HBM GB/s (% of peak), 1920x1080x1024 spp glTF scene",
             "value": paths / dt / 1e6,
@@ -163,21 +230,11 @@ def main():
                              f"textured atrium {desc.n_triangles} tris + 1024^2 albedo/normal/metal-rough textures + 2048x1024 env light (BASELINE configs[4])")
                             + f", {args.width}x{args.height}, {S * K} spp = {K} steps x {S} spp, max_bounces {args.max_bounces}, seed {args.seed}",
                 "paths": paths,
-                "sharding": (f"32x32 tiles over {world} ranks (each rank: 1/{world} of the pixels x {S} spp per step), RCCL reduce to rank 0"
+                "sharding": (f"32x32 tiles over {world} ranks (each rank: 1/{world} of the pixels x {S} spp per step), {reduce_impl} to rank 0"
                              if world > 1 else "single GPU"),
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "k_trace_closest",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "bytes_per_launch": tc_bytes / n_launch,
-                "avg_launch_ms": tc_sec / n_launch * 1e3,
-                "launches": n_launch,
-            },
+            "roofline": roof,
+            "kernels": kernels,
             "whole_path_algorithmic_GBs": tot["algorithmic_bytes"] / dt / 1e9,
             "scene_commit_seconds": s1.get("seconds_commit"),    # flatten + SAH BVH + upload, once per scene, outside the timed region
             "seconds": {"wall": dt, "trace_closest": d["seconds_trace_closest"], "trace_any": d["seconds_trace_any"], "shade": d["seconds_shade"]},

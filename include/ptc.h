@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PTC_ABI_VERSION 1
+#define PTC_ABI_VERSION 2
 
 typedef struct ptc_ctx ptc_ctx;
 
@@ -42,15 +42,20 @@ enum {
   PTC_OK = 0,
   PTC_E_ARG = -1,      /* bad argument (null pointer, index out of range, bad size) */
   PTC_E_STATE = -2,    /* call out of order (e.g. render before scene_commit)       */
-  PTC_E_DEVICE = -3,   /* HIP error (text carries hipGetErrorString)                */
-  PTC_E_NOMEM = -4
+  PTC_E_DEVICE = -3,   /* HIP / RCCL error (text carries hipGetErrorString)         */
+  PTC_E_NOMEM = -4     /* hipErrorOutOfMemory: queues or scene do not fit the device */
 };
 
 /* integrators */
 enum {
   PTC_INTEGRATOR_PATH = 0,          /* wavefront path tracer (SURVEY §8a-2 P1–P10)                  */
-  PTC_INTEGRATOR_RASTER_COMPAT = 1  /* primary hit + the reference's Blinn-Phong pass (R6,R7,R8):
-                                       assets/shaders/pbr/lighting.glsl:19-29                       */
+  PTC_INTEGRATOR_RASTER_COMPAT = 1, /* primary hit + the reference's Blinn-Phong pass (R6,R7,R8):
+                                       assets/shaders/pbr/lighting.glsl:19-29, lit from fp32 P, N, albedo */
+  PTC_INTEGRATOR_RASTER_GBUFFER16 = 2 /* the same pass lit from what the reference's G-buffer holds
+                                       (engine/pbr/GBuffer.hpp:13-16): positions and normals rounded to
+                                       RGBA16F (round to nearest even), albedo to RGBA16 UNORM, the normal not
+                                       re-normalised; read the result with ptc_read_radiance_rgba16f for the
+                                       RGBA16F lighting target (PbrRenderSystem.hpp:21)              */
 };
 
 /* Vertex record == pbr::MeshVertex (src/pbr_engine/engine/pbr/MeshVertex.hpp:14-19):
@@ -159,12 +164,17 @@ int ptc_render(ptc_ctx*, int w, int h, int spp, uint64_t seed, int max_bounces, 
 
 /* Progressive form.  tile_rank/tile_count select the 32×32-pixel tiles this context owns
  * (tile t along a Morton walk belongs to rank t mod tile_count); 0/1 = whole frame.
- * spp_total is the divisor used by frame_resolve. */
+ * spp_total is the sample BUDGET of the frame: frame_add_samples fails with PTC_E_ARG beyond it. */
 int ptc_frame_begin(ptc_ctx*, int w, int h, int spp_total, uint64_t seed, int max_bounces,
                     int integrator, int tile_rank, int tile_count);
-/* Trace the next n_samples samples of every owned pixel (one wavefront batch). */
+/* Accept the next n_samples samples of every owned pixel.  Asynchronous: full wavefront batches (as many samples as
+ * fit the path budget, PTC_BATCH_PATHS, split over the lanes) are queued on the device at once; a remainder is held
+ * back and merged with the samples of later calls, so that many small calls still produce full-width launches.
+ * ptc_frame_resolve / ptc_sync / ptc_get_stats queue whatever is still held back.  Queues are sized by the batches
+ * actually issued: adding one sample per call needs queues for one sample per pixel. */
 int ptc_frame_add_samples(ptc_ctx*, int n_samples);
-/* sum / spp_total → full-frame RGBA32F (zeros in pixels this context does not own). */
+/* sum / (samples accumulated so far) → full-frame RGBA32F (zeros in pixels this context does not own): after k of
+ * N samples the buffer holds the k-sample image, correctly exposed (progressive display). */
 int ptc_frame_resolve(ptc_ctx*);
 /* Block until all queued device work of this context has finished. */
 int ptc_sync(ptc_ctx*);
@@ -176,11 +186,46 @@ int ptc_read_radiance_rgba32f(ptc_ctx*, float* out);
 void* ptc_radiance_device_ptr(ptc_ctx*);
 /* Overwrite the radiance buffer from host (e.g. after a reduce) before tonemapping. */
 int ptc_write_radiance_rgba32f(ptc_ctx*, const float* in);
+/* The same image in the reference's own HdrImage format, vk::Format::eR16G16B16A16Sfloat
+ * (engine/pbr/PbrRenderSystem.hpp:21, HdrImage.cpp:20): w*h*4 IEEE binary16 values (as uint16_t), fp32 → fp16 by
+ * round-to-nearest-even, overflow → inf, half denormals kept.  This is what a viewer shim copies into the HdrImage
+ * (INTEGRATION.md §2).  The device-pointer form converts on the context's stream, waits for the conversion and
+ * returns a buffer that stays valid until the next call of either function (NULL on error). */
+int ptc_read_radiance_rgba16f(ptc_ctx*, uint16_t* out);
+void* ptc_radiance_rgba16f_device_ptr(ptc_ctx*);
 
 /* TonemapperSystem::run + tonemappers/aces+gamma.glsl:10-40 on the radiance buffer → RGBA8. */
 int ptc_tonemap_rgba8(ptc_ctx*, uint8_t* out);
 
 int ptc_get_stats(ptc_ctx*, ptc_stats* out);
+
+/* ---- multi-GPU: tiles shard over devices, one RCCL reduce brings the framebuffer to the root -----------
+ * The reference has no multi-device path (one vk::Device, core/GpuHandle.cpp:94-101); this is BASELINE.json's
+ * "independent pixel/sample tiles shard across the 8 GPUs of one node with an RCCL reduce onto rank 0".
+ *
+ * One process per GPU: rank 0 calls ptc_comm_unique_id and ships the 128 bytes to the other ranks by whatever channel
+ * the host has (MPI, torch.distributed, a file); every rank then calls ptc_comm_init on its context (collective:
+ * ncclCommInitRank), renders its tiles (ptc_frame_begin with tile_rank/tile_count) and, after ptc_frame_resolve,
+ * ptc_comm_reduce_radiance(root): ncclReduce(fp32, sum) in place on the full-frame radiance buffer, queued on the
+ * context's stream behind the resolve (asynchronous; ptc_sync or a read-back waits for it).  Tiles are disjoint and the
+ * other pixels are zero, so the sum is x + 0: the root's image is bit-identical to the single-GPU image. */
+#define PTC_COMM_ID_BYTES 128
+int ptc_comm_unique_id(uint8_t out[PTC_COMM_ID_BYTES]);
+int ptc_comm_init(ptc_ctx*, const uint8_t id[PTC_COMM_ID_BYTES], int rank, int n_ranks);
+int ptc_comm_reduce_radiance(ptc_ctx*, int root);
+int ptc_comm_destroy(ptc_ctx*);
+
+/* One process driving several GPUs: n contexts (one per device id) + ncclCommInitAll.  Describe and commit the same
+ * scene on every ptc_group_ctx(g, i); ptc_group_render then traces device i's tiles on device i (all devices are queued
+ * before anything is waited for), reduces onto device 0 and syncs: ptc_group_ctx(g, 0) holds the whole frame
+ * (ptc_read_radiance_* / ptc_tonemap_rgba8 on it).  ptc_group_create returns NULL on failure (ptc_group_last_error(NULL)). */
+typedef struct ptc_group ptc_group;
+ptc_group* ptc_group_create(const int* device_ids, int n_devices);
+int ptc_group_size(const ptc_group*);
+ptc_ctx* ptc_group_ctx(ptc_group*, int i);
+int ptc_group_render(ptc_group*, int w, int h, int spp, uint64_t seed, int max_bounces, int integrator);
+const char* ptc_group_last_error(const ptc_group*);
+void ptc_group_destroy(ptc_group*);
 
 /* ---- test hooks (parity of single stages; not needed by a renderer) -------------------------
  * Closest-hit of n explicit rays through the same trace kernel: origins/dirs are n*3 floats;
@@ -207,11 +252,16 @@ int ptc_debug_get_texture(ptc_ctx*, int index, int* w, int* h, uint8_t* rgba);
  * loop-iteration diagnostics a -DPT_DIAG build fills).  Returns the number of counters the library keeps. */
 int ptc_debug_get_counters(ptc_ctx*, uint64_t* out, int n);
 
-/* The flattened 4-wide BVH as committed: nodes (n_nodes*12 32-bit words = 48 bytes each: org.xyz, packed
- * exponents + child descriptors, 8-bit quantised child planes, child / triangle base indices; layout in
- * csrc/ptc_scene.cpp) and triangle records in node order (n_tris*12 floats: v0,prim | e1,class | e2,0).
+/* The flattened 8-wide BVH as committed: nodes (n_nodes*20 32-bit words = 80 bytes each: org.xyz, packed exponents +
+ * interior-slot mask, 8-bit quantised child planes of the 8 slots, child / triangle base indices, leaf-slot masks; layout
+ * in csrc/ptc_scene.cpp) and triangle records in node order (n_tris*12 floats: v0,prim | e1,class | e2,0).
  * Pass NULL to query sizes only. */
 int ptc_debug_get_bvh(ptc_ctx*, uint32_t* n_nodes, uint32_t* n_tris, float* nodes, float* tris);
+
+/* Context internals for tests of the host logic: [0] HIP events created so far, [1] timing spans waiting to be
+ * collected, [2] queue capacity (paths) of a lane, [3] samples of one full batch, [4] samples accepted but not yet
+ * issued, [5] trace blocks per CU, [6] stack entries per lane kept in LDS. */
+int ptc_debug_get_internals(ptc_ctx*, uint64_t out[8]);
 
 #ifdef __cplusplus
 }

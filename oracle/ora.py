@@ -76,6 +76,10 @@ def lib():
         L.ora_sincos2pi.restype = None
         L.ora_powf.argtypes = [C.c_float, C.c_float]
         L.ora_powf.restype = C.c_float
+        L.ora_f32_to_f16.argtypes = [C.c_float]
+        L.ora_f32_to_f16.restype = C.c_uint16
+        L.ora_f16_to_f32.argtypes = [C.c_uint16]
+        L.ora_f16_to_f32.restype = C.c_float
         L.ora_rng_u32.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         L.ora_rng_u32.restype = C.c_uint32
         L.ora_tile_owner.argtypes = [C.c_int] * 5
@@ -189,7 +193,7 @@ class Oracle:
 def _bvh(self):
     nn, nt = C.c_uint32(), C.c_uint32()
     self._ck(self._L.ora_get_bvh(self._h, C.byref(nn), C.byref(nt), None, None))
-    nodes = np.zeros((nn.value, 34), np.float32)
+    nodes = np.zeros((nn.value, 62), np.float32)
     tris = np.zeros((nt.value, 12), np.float32)
     self._ck(self._L.ora_get_bvh(self._h, None, None, nodes.ctypes.data_as(C.POINTER(C.c_float)), tris.ctypes.data_as(C.POINTER(C.c_float))))
     return nodes, tris
@@ -224,6 +228,14 @@ def sincos2pi(u):
     s, c = C.c_float(), C.c_float()
     lib().ora_sincos2pi(float(u), C.byref(s), C.byref(c))
     return s.value, c.value
+
+
+def f32_to_f16(x) -> int:
+    return int(lib().ora_f32_to_f16(float(x)))
+
+
+def f16_to_f32(h) -> float:
+    return float(lib().ora_f16_to_f32(int(h)))
 
 
 def powf(x, y):

@@ -6,7 +6,8 @@
  *     (built with -ffp-contract=off); a fused multiply-add happens exactly where fmaf() is written.
  *   - no libm transcendental on the render path: sin/cos/pow are the polynomials below.
  *   - closest hit = lexicographic minimum of (t, original primitive id); traversal order is fixed
- *     (near child first, ties to child 0), so node/triangle counters are reproducible too.
+ *     (a node's leaf triangles first, then its interior children in the order of the ray's direction
+ *     octant), so node/triangle counters are reproducible too.
  *   - RNG is a counter-based hash of (seed, pixel, sample, bounce, dim).
  *
  * Reference conventions restated here (file:line under /root/reference):
@@ -36,7 +37,8 @@
 /* ------------------------------------------------------------------------------------------ */
 /* constants of the specification                                                              */
 #define ORA_LEAF_MAX 2          /* triangles per BVH leaf                                      */
-#define ORA_STACK 256           /* traversal stack entries (3 per wide level, worst case)      */
+#define ORA_W 8                 /* child slots per BVH node                                    */
+#define ORA_STACK 128           /* traversal stack entries (at most one group per level)       */
 #define ORA_EMPTY ((int32_t)0x80000000)  /* unused child slot of a wide node                    */
 #define ORA_RR_START 3          /* Russian roulette from this bounce index on                  */
 #define ORA_RR_PMIN 0.05f
@@ -53,7 +55,7 @@
 #define S_RAY 56u
 #define S_HIT 16u
 #define S_SHADOW 44u
-#define S_NODE 48u
+#define S_NODE 80u
 #define S_TRI 48u
 #define S_SURF 176u
 #define S_FB 16u
@@ -183,21 +185,22 @@ typedef struct { vert48* v; uint32_t nv; uint32_t* idx; uint32_t ni; int materia
 typedef struct { int mesh; float m[16]; } inst_t;   /* column-major model matrix */
 typedef struct { uint8_t* px; int w, h; } tex_t;
 
-typedef struct {                 /* 64-byte interior node: both child boxes + child codes */
+typedef struct {                 /* 64-byte interior node of the BINARY tree (single-triangle leaves): both child boxes + child codes */
   float lo0[3], hi0[3], lo1[3], hi1[3];
   int32_t c0, c1;                /* >=0 interior index; <0 leaf: ~(first | (count-1)<<28) */
-  int32_t pad0, pad1;
+  uint32_t lo, hi;               /* the sorted positions below this node */
 } node_t;
 
-/* 4-wide node with quantised child boxes: the traversal structure (the binary node_t above is only the
+/* 8-wide node with quantised child boxes: the traversal structure (the binary node_t above is only the
  * build's intermediate).  A child plane on axis k is  org[k] + q * 2^(e[k]-127)  with q an 8-bit integer
  * (lower planes rounded down, upper planes rounded up, so the quantised box contains the exact one).
- * code: >=0 wide node index; <0 leaf (as in node_t); ORA_EMPTY unused slot. */
+ * A child sits in the slot whose octant it lies in (assign_slots below), so a ray can order the slots by
+ * its direction signs alone.  code: >=0 node index; <0 leaf (as in node_t); ORA_EMPTY unused slot. */
 typedef struct {
   float org[3];
   uint32_t e[3];
-  uint32_t qlo[3][4], qhi[3][4];     /* [axis][child], values 0..255 */
-  int32_t code[4];
+  uint32_t qlo[3][ORA_W], qhi[3][ORA_W];     /* [axis][slot], values 0..255 */
+  int32_t code[ORA_W];
 } wnode_t;
 
 typedef struct { v3 v0, e1, e2, ng; float area; v3 Le; float pmf; uint32_t prim; } light_t;
@@ -221,7 +224,7 @@ struct ora_ctx {
   uint32_t* order;                     /* sorted position → original prim id */
   v3 *tv0, *te1, *te2;                 /* per sorted position */
   node_t* nodes; uint32_t n_nodes; uint32_t max_depth;   /* binary radix tree (intermediate) */
-  wnode_t* wnodes; uint32_t n_wnodes; uint32_t wdepth;   /* 4-wide collapse: what rays traverse */
+  wnode_t* wnodes; uint32_t n_wnodes; uint32_t wdepth;   /* 8-wide collapse: what rays traverse */
   int32_t* prim_light;                 /* original prim id → light index or -1 */
   light_t* lights; float* cdf; uint32_t n_lights;
   float scene_lo[3], scene_hi[3]; float ray_eps;
@@ -430,8 +433,9 @@ void ora_make_camera(const float pos[3], const float target[3], float fov, float
 }
 
 /* ------------------------------------------------------------------------------------------ */
-/* P2: BVH.  Top-down binned-SAH binary tree over the triangle boxes (sah_split below), ranges of  */
-/* <= ORA_LEAF_MAX triangles are leaves; then the 4-wide collapse and the 8-bit quantisation.      */
+/* P2: BVH.  Top-down binned-SAH binary tree over the triangle boxes (sah_split below) down to     */
+/* single triangles; then the 8-wide collapse (cost-optimal, by dynamic programming, leaves of    */
+/* <= ORA_LEAF_MAX triangles), the octant slot assignment and the 8-bit quantisation.             */
 static inline int32_t leaf_code(uint32_t first, uint32_t count) { return (int32_t)~(first | ((count - 1u) << 28)); }
 
 typedef struct { ora_ctx* c; const float* tlo; const float* thi; uint32_t next; uint32_t depth_max; } build_t;
@@ -504,7 +508,8 @@ static uint32_t sah_split(build_t* b, uint32_t lo, uint32_t hi) {
     return lo + nl - 1;
   }
 }
-/* Emit the interior node covering [lo,hi] (count > LEAF_MAX); returns its index. */
+/* Emit the interior node covering [lo,hi] (count >= 2: the binary tree goes down to single triangles; which
+ * subtrees become leaves of the wide tree is decided by the collapse below); returns its index. */
 static int32_t build_node(build_t* b, uint32_t lo, uint32_t hi, uint32_t depth) {
   uint32_t me = b->next++;
   if (depth > b->depth_max) b->depth_max = depth;
@@ -513,15 +518,25 @@ static int32_t build_node(build_t* b, uint32_t lo, uint32_t hi, uint32_t depth) 
   range_box(b, lo, split, tmp.lo0, tmp.hi0);
   range_box(b, split + 1, hi, tmp.lo1, tmp.hi1);
   uint32_t n0 = split - lo + 1, n1 = hi - split;
-  tmp.c0 = n0 <= ORA_LEAF_MAX ? leaf_code(lo, n0) : build_node(b, lo, split, depth + 1);
-  tmp.c1 = n1 <= ORA_LEAF_MAX ? leaf_code(split + 1, n1) : build_node(b, split + 1, hi, depth + 1);
+  tmp.lo = lo; tmp.hi = hi;
+  tmp.c0 = n0 == 1 ? leaf_code(lo, 1) : build_node(b, lo, split, depth + 1);
+  tmp.c1 = n1 == 1 ? leaf_code(split + 1, 1) : build_node(b, split + 1, hi, depth + 1);
   b->c->nodes[me] = tmp;
   return (int32_t)me;
 }
 
-/* 4-wide collapse of the binary tree (greedy by surface area): start from a binary node's two children and
- * keep replacing the interior child with the largest half-area (ties: lowest slot) by its own two children,
- * in place, until there are 4 children or only leaves remain. */
+/* 8-wide collapse of the binary tree by dynamic programming over its surface-area cost (after Ylitie, Karras,
+ * Laine, "Efficient Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs", 2017, sec. 3.1).  For a binary
+ * node n with box half-area A_n and P_n triangles, C(n,i) = the least cost of representing its subtree by at most i
+ * roots (each root a leaf or an 8-wide node), i = 1..7:
+ *     C(n,1) = min(C_leaf(n), C_int(n))                 C(n,i) = min(C_dist(n,i), C(n,i-1))
+ *     C_leaf(n) = A_n * P_n * ORA_C_PRIM  if P_n <= ORA_LEAF_MAX, else +inf
+ *     C_int(n)  = C_dist(n,8) + A_n * ORA_C_NODE        C_dist(n,j) = min over 0<k<j of C(left,k) + C(right,j-k)
+ * (a single triangle costs A * ORA_C_PRIM for every i).  Ties: a leaf over an interior node, fewer roots over more,
+ * the smallest k.  The root is always an 8-wide node; its children are the roots of C_dist(root,8), left to right. */
+#define ORA_C_NODE 1.0f
+#define ORA_C_PRIM 1.0f
+typedef struct { float c[8]; uint8_t leaf1; uint8_t same[8]; uint8_t k[9]; } dp_t;   /* c[i], same[i]: i = 1..7; k[j]: j = 2..8 */
 typedef struct { float lo[3], hi[3]; int32_t code; } wchild;
 static inline float half_area(const float lo[3], const float hi[3]) {
   float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
@@ -565,34 +580,107 @@ static void quantize_axis(const float* clo, const float* chi, int n, float org, 
   *e_out = e;
 }
 
-static int32_t widen(ora_ctx* c, int32_t bin_idx, uint32_t depth, uint32_t* next, uint32_t* maxd) {
+/* Slot assignment: child i of the (<= 8) children goes to the free slot s that maximises
+ *   score(i, s) = (+-)dx + (+-)dy + (+-)dz,  d = centre(child) - centre(node),  sign of axis k = bit k of s
+ * (slot s is "the octant s of the node"), greedily over all (child, slot) pairs: largest score first, ties to the
+ * lowest child, then the lowest slot.  Centres are 0.5f*(lo+hi); the sum is evaluated left to right. */
+static void assign_slots(const wchild* list, int n, const float nlo[3], const float nhi[3], int slot_of[ORA_W]) {
+  float d[ORA_W][3];
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k) d[i][k] = 0.5f * (list[i].lo[k] + list[i].hi[k]) - 0.5f * (nlo[k] + nhi[k]);
+  int child_done[ORA_W] = {0}, slot_used[ORA_W] = {0};
+  for (int round = 0; round < n; ++round) {
+    int bi = -1, bs = -1; float bsc = 0.0f;
+    for (int i = 0; i < n; ++i) {
+      if (child_done[i]) continue;
+      for (int sl = 0; sl < ORA_W; ++sl) {
+        if (slot_used[sl]) continue;
+        float sc = ((sl & 1) ? d[i][0] : -d[i][0]) + ((sl & 2) ? d[i][1] : -d[i][1]) + ((sl & 4) ? d[i][2] : -d[i][2]);
+        if (bi < 0 || sc > bsc) { bi = i; bs = sl; bsc = sc; }
+      }
+    }
+    child_done[bi] = 1; slot_used[bs] = 1; slot_of[bi] = bs;
+  }
+}
+
+static inline int min7(int k) { return k > 7 ? 7 : k; }
+static float dp_cost(const dp_t* dp, const node_t* parent, int k, int i) {   /* C(child k of parent, i) */
+  int32_t link = k ? parent->c1 : parent->c0;
+  if (link < 0) return half_area(k ? parent->lo1 : parent->lo0, k ? parent->hi1 : parent->hi0) * 1.0f * ORA_C_PRIM;
+  return dp[link].c[i];
+}
+static void dp_compute(const ora_ctx* c, dp_t* dp, int32_t n, float area) {
+  const node_t* nd = &c->nodes[n];
+  if (nd->c0 >= 0) dp_compute(c, dp, nd->c0, half_area(nd->lo0, nd->hi0));
+  if (nd->c1 >= 0) dp_compute(c, dp, nd->c1, half_area(nd->lo1, nd->hi1));
+  dp_t* d = &dp[n];
+  float dist[9];
+  for (int j = 2; j <= 8; ++j) {
+    float best = INFINITY; int bk = 1;
+    for (int k = 1; k < j; ++k) {
+      float v = dp_cost(dp, nd, 0, min7(k)) + dp_cost(dp, nd, 1, min7(j - k));
+      if (v < best) { best = v; bk = k; }
+    }
+    dist[j] = best; d->k[j] = (uint8_t)bk;
+  }
+  uint32_t P = nd->hi - nd->lo + 1u;
+  float cleaf = P <= ORA_LEAF_MAX ? area * (float)P * ORA_C_PRIM : INFINITY;
+  float cint = dist[8] + area * ORA_C_NODE;
+  d->leaf1 = cleaf <= cint; d->c[1] = d->leaf1 ? cleaf : cint;
+  for (int i = 2; i <= 7; ++i) {
+    if (dist[i] < d->c[i - 1]) { d->c[i] = dist[i]; d->same[i] = 0; } else { d->c[i] = d->c[i - 1]; d->same[i] = 1; }
+  }
+}
+/* the roots of the best forest of at most i roots below child k of `parent`, appended left to right */
+static void dp_forest(const ora_ctx* c, const dp_t* dp, const node_t* parent, int k, int i, wchild* list, int* n) {
+  int32_t link = k ? parent->c1 : parent->c0;
+  wchild w = bin_child(parent, k);
+  if (link < 0) { list[(*n)++] = w; return; }
+  const node_t* nd = &c->nodes[link]; const dp_t* d = &dp[link];
+  while (i > 1 && d->same[i]) --i;
+  if (i == 1) {
+    if (d->leaf1) w.code = leaf_code(nd->lo, nd->hi - nd->lo + 1u);
+    list[(*n)++] = w; return;
+  }
+  int kk = d->k[i];
+  dp_forest(c, dp, nd, 0, min7(kk), list, n);
+  dp_forest(c, dp, nd, 1, min7(i - kk), list, n);
+}
+
+static int32_t widen(ora_ctx* c, const dp_t* dp, int32_t bin_idx, uint32_t depth, uint32_t* next, uint32_t* maxd) {
   uint32_t me = (*next)++;
   if (depth > *maxd) *maxd = depth;
-  wchild list[4]; int n = 2;
-  list[0] = bin_child(&c->nodes[bin_idx], 0); list[1] = bin_child(&c->nodes[bin_idx], 1);
-  while (n < 4) {
-    int best = -1; float besta = 0.0f;
-    for (int i = 0; i < n; ++i) {
-      if (list[i].code < 0) continue;
-      float a = half_area(list[i].lo, list[i].hi);
-      if (best < 0 || a > besta) { best = i; besta = a; }
-    }
-    if (best < 0) break;
-    const node_t* bn = &c->nodes[list[best].code];
-    for (int j = n; j > best + 1; --j) list[j] = list[j - 1];
-    list[best] = bin_child(bn, 0); list[best + 1] = bin_child(bn, 1);
-    ++n;
+  wchild list[ORA_W]; int n = 0;
+  {
+    const node_t* nd = &c->nodes[bin_idx]; int kk = dp[bin_idx].k[8];
+    dp_forest(c, dp, nd, 0, min7(kk), list, &n);
+    dp_forest(c, dp, nd, 1, min7(8 - kk), list, &n);
   }
   wnode_t w; memset(&w, 0, sizeof w);
+  float nlo3[3], nhi3[3];
   for (int k = 0; k < 3; ++k) {
-    float nlo = list[0].lo[k], nhi = list[0].hi[k], clo[4], chi[4];
-    for (int i = 0; i < n; ++i) { clo[i] = list[i].lo[k]; chi[i] = list[i].hi[k]; nlo = fmin2(nlo, clo[i]); nhi = fmax2(nhi, chi[i]); }
-    w.org[k] = nlo;
-    quantize_axis(clo, chi, n, nlo, nhi, &w.e[k], w.qlo[k], w.qhi[k]);
+    float nlo = list[0].lo[k], nhi = list[0].hi[k];
+    for (int i = 0; i < n; ++i) { nlo = fmin2(nlo, list[i].lo[k]); nhi = fmax2(nhi, list[i].hi[k]); }
+    nlo3[k] = nlo; nhi3[k] = nhi;
   }
-  for (int i = 0; i < 4; ++i) {
-    if (i >= n) { w.code[i] = ORA_EMPTY; for (int k = 0; k < 3; ++k) { w.qlo[k][i] = 255; w.qhi[k][i] = 0; } continue; }
-    w.code[i] = list[i].code < 0 ? list[i].code : widen(c, list[i].code, depth + 1, next, maxd);
+  int slot_of[ORA_W];
+  assign_slots(list, n, nlo3, nhi3, slot_of);
+  for (int k = 0; k < 3; ++k) {
+    float clo[ORA_W], chi[ORA_W]; uint32_t qlo[ORA_W], qhi[ORA_W];
+    for (int i = 0; i < n; ++i) { clo[i] = list[i].lo[k]; chi[i] = list[i].hi[k]; }
+    w.org[k] = nlo3[k];
+    quantize_axis(clo, chi, n, nlo3[k], nhi3[k], &w.e[k], qlo, qhi);
+    for (int sl = 0; sl < ORA_W; ++sl) { w.qlo[k][sl] = 255; w.qhi[k][sl] = 0; }
+    for (int i = 0; i < n; ++i) { w.qlo[k][slot_of[i]] = qlo[i]; w.qhi[k][slot_of[i]] = qhi[i]; }
+  }
+  /* recurse in slot order */
+  int child_of_slot[ORA_W];
+  for (int sl = 0; sl < ORA_W; ++sl) child_of_slot[sl] = -1;
+  for (int i = 0; i < n; ++i) child_of_slot[slot_of[i]] = i;
+  for (int sl = 0; sl < ORA_W; ++sl) {
+    int i = child_of_slot[sl];
+    if (i < 0) { w.code[sl] = ORA_EMPTY; continue; }
+    w.code[sl] = list[i].code < 0 ? list[i].code : widen(c, dp, list[i].code, depth + 1, next, maxd);
   }
   c->wnodes[me] = w;
   return (int32_t)me;
@@ -658,7 +746,7 @@ int ora_scene_commit(ora_ctx* c) {
   if (n == 1) {                 /* a single triangle: both children are that leaf */
     node_t r; memset(&r, 0, sizeof r);
     range_box(&b, 0, 0, r.lo0, r.hi0); range_box(&b, 0, 0, r.lo1, r.hi1);
-    r.c0 = leaf_code(0, 1); r.c1 = leaf_code(0, 1);
+    r.c0 = leaf_code(0, 1); r.c1 = leaf_code(0, 1); r.lo = 0; r.hi = 0;
     c->nodes[0] = r; b.next = 1;
   } else {
     build_node(&b, 0, n - 1, 0);
@@ -673,7 +761,14 @@ int ora_scene_commit(ora_ctx* c) {
     c->te2[i] = V3(d[0] - a[0], d[1] - a[1], d[2] - a[2]);
   }
   c->wnodes = (wnode_t*)calloc(c->n_nodes, sizeof(wnode_t));
-  { uint32_t next = 0, maxd = 0; widen(c, 0, 0, &next, &maxd); c->n_wnodes = next; c->wdepth = maxd; }
+  {
+    dp_t* dp = (dp_t*)calloc(c->n_nodes, sizeof(dp_t));
+    float rlo[3], rhi[3];
+    for (int k = 0; k < 3; ++k) { rlo[k] = fmin2(c->nodes[0].lo0[k], c->nodes[0].lo1[k]); rhi[k] = fmax2(c->nodes[0].hi0[k], c->nodes[0].hi1[k]); }
+    dp_compute(c, dp, 0, half_area(rlo, rhi));
+    uint32_t next = 0, maxd = 0; widen(c, dp, 0, 0, &next, &maxd); c->n_wnodes = next; c->wdepth = maxd;
+    free(dp);
+  }
   free(tlo); free(thi);
   /* P7: emitter table in original primitive order, power pmf/cdf */
   c->prim_light = (int32_t*)malloc(4u * n);
@@ -774,13 +869,8 @@ static inline int tri_test(const ray_t* r, v3 v0, v3 e1, v3 e2, int cull, float*
 
 typedef struct { float t, u, v; int32_t prim; uint32_t pos; } hit_t;
 
-/* One wide-node step: test the (up to 4) children against [tmin, tlimit], order the hits by
- * key = (bits(tnear) & ~3) | slot  (tnear >= 0, so the bit pattern orders like the value; the two dropped
- * mantissa bits make room for the slot, which also breaks ties), return them nearest first. */
-typedef struct { int32_t code; uint32_t key; } cand_t;
-typedef struct { int32_t code; float tq; } sent_t;
-/* slab test of child i of a quantised node: plane distance = fma(q, scale*inv, fma(org, inv, -ood)) */
-static inline int qbox_hit(const wnode_t* n, int i, const ray_t* r, float tmin, float tlimit, float* tn) {
+/* slab test of child slot i of a quantised node: plane distance = fma(q, scale*inv, fma(org, inv, -ood)) */
+static inline int qbox_hit(const wnode_t* n, int i, const ray_t* r, float tmin, float tlimit) {
   float ax = pow2_biased(n->e[0]) * r->inv.x, ay = pow2_biased(n->e[1]) * r->inv.y, az = pow2_biased(n->e[2]) * r->inv.z;
   float bx = fmaf(n->org[0], r->inv.x, -r->ood.x), by = fmaf(n->org[1], r->inv.y, -r->ood.y), bz = fmaf(n->org[2], r->inv.z, -r->ood.z);
   float x0 = fmaf((float)n->qlo[0][i], ax, bx), x1 = fmaf((float)n->qhi[0][i], ax, bx);
@@ -788,82 +878,86 @@ static inline int qbox_hit(const wnode_t* n, int i, const ray_t* r, float tmin, 
   float z0 = fmaf((float)n->qlo[2][i], az, bz), z1 = fmaf((float)n->qhi[2][i], az, bz);
   float tnear = fmax2(fmax2(fmin2(x0, x1), fmin2(y0, y1)), fmax2(fmin2(z0, z1), tmin));
   float tfar = fmin2(fmin2(fmax2(x0, x1), fmax2(y0, y1)), fmin2(fmax2(z0, z1), tlimit));
-  *tn = tnear;
   return tnear <= tfar;
 }
-static inline int wide_step(const wnode_t* n, const ray_t* r, float tmin, float tlimit, cand_t out[4]) {
-  int nh = 0;
-  for (int i = 0; i < 4; ++i) {
+/* One node visit: the 8 slots against [tmin, tlimit] -> bit masks (bit s = slot s) of the hit interior children and
+ * of the hit leaf children. */
+static inline void node_visit(const wnode_t* n, const ray_t* r, float tmin, float tlimit, uint32_t* ihits, uint32_t* lhits) {
+  uint32_t ih = 0, lh = 0;
+  for (int i = 0; i < ORA_W; ++i) {
     if (n->code[i] == ORA_EMPTY) continue;
-    float tn;
-    if (!qbox_hit(n, i, r, tmin, tlimit, &tn)) continue;
-    union { float f; uint32_t u; } b; b.f = tn;
-    cand_t cd; cd.code = n->code[i]; cd.key = (b.u & 0xfffffffcu) | (uint32_t)i;
-    int j = nh++;
-    while (j > 0 && out[j - 1].key > cd.key) { out[j] = out[j - 1]; --j; }
-    out[j] = cd;
+    if (!qbox_hit(n, i, r, tmin, tlimit)) continue;
+    if (n->code[i] >= 0) ih |= 1u << i; else lh |= 1u << i;
   }
-  return nh;
+  *ihits = ih; *lhits = lh;
 }
-static inline float key_tq(uint32_t key) { union { float f; uint32_t u; } b; b.u = key & 0xfffffffcu; return b.f; }
+/* Direction octant of a ray: bit k set when component k of the direction is >= 0.  A child in slot s lies towards
+ * +axis k when bit k of s is set, so the slots a ray enters first are those whose bits differ from the ray's:
+ * slots are visited in DESCENDING order of (s ^ octant). */
+static inline uint32_t ray_octant(const ray_t* r) { return (r->inv.x >= 0.0f ? 1u : 0u) | (r->inv.y >= 0.0f ? 2u : 0u) | (r->inv.z >= 0.0f ? 4u : 0u); }
+static inline int next_slot(uint32_t hits, uint32_t oct) {
+  int best = -1; uint32_t bk = 0;
+  for (int s = 0; s < ORA_W; ++s) if (hits & (1u << s)) { uint32_t k = (uint32_t)s ^ oct; if (best < 0 || k > bk) { best = s; bk = k; } }
+  return best;
+}
 
+typedef struct { int32_t node; uint32_t hits; } group_t;    /* interior children of `node` still to be visited */
+
+/* Closest hit.  Per node: test the 8 slots against [tmin, best.t]; intersect the triangles of the hit leaf slots (slot order);
+ * then descend into the hit interior children, nearest octant first; the others wait on the stack as one group (no
+ * per-child entry distance is kept: a group is re-examined only through its children's own box tests). */
 static hit_t trace_closest(const ora_ctx* c, v3 o, v3 d, float tmin, float tmax, int cull, trav_count* cnt) {
   hit_t best; best.t = tmax; best.prim = 0x7fffffff; best.u = best.v = 0.0f; best.pos = 0; int found = 0;
   ray_t r = make_ray(o, d);
-  sent_t stack[ORA_STACK]; int sp = 0; int32_t cur = 0;
+  const uint32_t oct = ray_octant(&r);
+  group_t stack[ORA_STACK]; int sp = 0; int32_t cur = 0;
   for (;;) {
-    while (cur >= 0) {
-      cand_t cd[4]; cnt->nodes++;
-      int nh = wide_step(&c->wnodes[cur], &r, tmin, best.t, cd);
-      for (int k = nh - 1; k >= 1; --k) { stack[sp].code = cd[k].code; stack[sp].tq = key_tq(cd[k].key); ++sp; }   /* farthest first */
-      if (nh > 0) { cur = cd[0].code; continue; }
-      cur = ORA_EMPTY;                                        /* pop, skipping entries that are now too far */
-      while (sp > 0) { sent_t e = stack[--sp]; if (e.tq > best.t) continue; cur = e.code; break; }
-      if (cur == ORA_EMPTY) goto done;
-    }
-    {
-      uint32_t code = (uint32_t)~cur; uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
+    const wnode_t* n = &c->wnodes[cur];
+    uint32_t ih, lh; cnt->nodes++;
+    node_visit(n, &r, tmin, best.t, &ih, &lh);
+    for (int s = 0; s < ORA_W; ++s) {
+      if (!(lh & (1u << s))) continue;
+      uint32_t code = (uint32_t)~n->code[s]; uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
       for (uint32_t i = first; i < first + count; ++i) {
         float t, u, v; cnt->tris++;
         if (!tri_test(&r, c->tv0[i], c->te1[i], c->te2[i], cull, &t, &u, &v)) continue;
         int32_t pid = (int32_t)c->order[i];
         if (t > tmin && (t < best.t || (t == best.t && pid < best.prim))) { best.t = t; best.u = u; best.v = v; best.prim = pid; best.pos = i; found = 1; }
       }
-      cur = ORA_EMPTY;
-      while (sp > 0) { sent_t e = stack[--sp]; if (e.tq > best.t) continue; cur = e.code; break; }
-      if (cur == ORA_EMPTY) break;
     }
+    group_t g; g.node = cur; g.hits = ih;
+    if (!g.hits) { if (sp == 0) break; g = stack[--sp]; }
+    int s = next_slot(g.hits, oct);
+    g.hits &= ~(1u << s);
+    cur = c->wnodes[g.node].code[s];
+    if (g.hits) stack[sp++] = g;
   }
-done:
   if (!found) { best.t = -1.0f; best.prim = -1; }
   return best;
 }
+/* Any hit: same nodes; occlusion needs no order, so hit slots are taken in ascending slot order and the first
+ * triangle hit inside (tmin, tmax) ends the ray. */
 static int trace_any(const ora_ctx* c, v3 o, v3 d, float tmin, float tmax, trav_count* cnt) {
-  /* occlusion needs no front-to-back order: hit children are taken in slot order (first one entered, the
-   * others pushed so that they pop in slot order) */
   ray_t r = make_ray(o, d);
-  int32_t stack[ORA_STACK]; int sp = 0; int32_t cur = 0;
+  group_t stack[ORA_STACK]; int sp = 0; int32_t cur = 0;
   for (;;) {
-    while (cur >= 0) {
-      const wnode_t* n = &c->wnodes[cur]; cnt->nodes++;
-      int32_t hit[4]; int nh = 0;
-      for (int i = 0; i < 4; ++i) {
-        if (n->code[i] == ORA_EMPTY) continue;
-        float tn;
-        if (qbox_hit(n, i, &r, tmin, tmax, &tn)) hit[nh++] = n->code[i];
+    const wnode_t* n = &c->wnodes[cur];
+    uint32_t ih, lh; cnt->nodes++;
+    node_visit(n, &r, tmin, tmax, &ih, &lh);
+    for (int s = 0; s < ORA_W; ++s) {
+      if (!(lh & (1u << s))) continue;
+      uint32_t code = (uint32_t)~n->code[s]; uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
+      for (uint32_t i = first; i < first + count; ++i) {
+        float t, u, v; cnt->tris++;
+        if (tri_test(&r, c->tv0[i], c->te1[i], c->te2[i], 0, &t, &u, &v) && t > tmin && t < tmax) return 1;
       }
-      for (int k = nh - 1; k >= 1; --k) stack[sp++] = hit[k];
-      if (nh > 0) { cur = hit[0]; continue; }
-      if (sp == 0) return 0;
-      cur = stack[--sp];
     }
-    uint32_t code = (uint32_t)~cur; uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
-    for (uint32_t i = first; i < first + count; ++i) {
-      float t, u, v; cnt->tris++;
-      if (tri_test(&r, c->tv0[i], c->te1[i], c->te2[i], 0, &t, &u, &v) && t > tmin && t < tmax) return 1;
-    }
-    if (sp == 0) return 0;
-    cur = stack[--sp];
+    group_t g; g.node = cur; g.hits = ih;
+    if (!g.hits) { if (sp == 0) return 0; g = stack[--sp]; }
+    int s = 0; while (!(g.hits & (1u << s))) ++s;
+    g.hits &= ~(1u << s);
+    cur = c->wnodes[g.node].code[s];
+    if (g.hits) stack[sp++] = g;
   }
 }
 
@@ -1234,8 +1328,50 @@ static v3 trace_path(const ora_ctx* c, const camera_t* cam, int w, int h, uint32
   return L;
 }
 
+/* IEEE binary32 -> binary16, round to nearest even, overflow -> inf, half denormals kept (what a Vulkan RGBA16F
+ * render target stores of an fp32 shader output, RTE being one of the two roundings the specification allows; it is
+ * the one v_cvt_f16_f32 performs), and back.  Written out in integer arithmetic: no F16C dependency. */
+static inline uint16_t f32_to_f16(float f) {
+  union { float f; uint32_t u; } b; b.f = f;
+  uint32_t sign = (b.u >> 16) & 0x8000u, x = b.u & 0x7fffffffu;
+  if (x > 0x7f800000u) return (uint16_t)(sign | 0x7e00u | ((x >> 13) & 0x3ffu));     /* NaN: quiet, payload truncated */
+  if (x >= 0x47800000u) return (uint16_t)(sign | 0x7c00u);                           /* >= 2^16 (and inf) -> inf */
+  if (x >= 0x38800000u) {                                                            /* normal half: >= 2^-14 */
+    uint32_t m = x - 0x38000000u;                                                    /* exponent rebias 127 -> 15 */
+    m += 0x0fffu + ((m >> 13) & 1u);                                                 /* round to nearest even; a carry may reach inf */
+    return (uint16_t)(sign | (m >> 13));
+  }
+  if (x < 0x33000000u) return (uint16_t)sign;                                        /* < 2^-25 -> 0 (2^-25 itself ties to even: 0) */
+  {                                                                                  /* half denormal: value = mant * 2^(e-150), unit 2^-24 */
+    uint32_t e = x >> 23, mant = (x & 0x007fffffu) | 0x00800000u;
+    uint32_t shift = 126u - e;                                                       /* 14..23 for e = 112..103; e = 102 -> 24 */
+    uint32_t q = mant >> shift, rem = mant & ((1u << shift) - 1u), half = 1u << (shift - 1u);
+    if (rem > half || (rem == half && (q & 1u))) q += 1u;
+    return (uint16_t)(sign | q);
+  }
+}
+static inline float f16_to_f32(uint16_t h) {
+  uint32_t sign = ((uint32_t)h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3ffu;
+  union { float f; uint32_t u; } b;
+  if (e == 31u) b.u = sign | 0x7f800000u | (m << 13);
+  else if (e) b.u = sign | ((e + 112u) << 23) | (m << 13);
+  else if (!m) b.u = sign;
+  else { b.f = (float)m * 5.9604644775390625e-08f; b.u |= sign; }                    /* m * 2^-24, exact */
+  return b.f;
+}
+uint16_t ora_f32_to_f16(float f) { return f32_to_f16(f); }
+float ora_f16_to_f32(uint16_t h) { return f16_to_f32(h); }
+static inline float round_f16(float v) { return f16_to_f32(f32_to_f16(v)); }
+/* RGBA16 UNORM as a G-buffer stores it: clamp to [0,1] (NaN -> 0), round(v * 65535) / 65535 */
+static inline float round_unorm16(float v) {
+  float cl = fmin2(fmax2(v, 0.0f), 1.0f);
+  return (float)(uint32_t)(cl * 65535.0f + 0.5f) / 65535.0f;
+}
+
 /* Raster-compat: the reference's deferred Blinn-Phong result by ray casting the primary hit.    */
-static void raster_compat_pixel(const ora_ctx* c, const camera_t* cam, int w, int h, uint32_t px, uint32_t py, float out[4], path_count* pc) {
+/* gbuf16: light from what the reference's G-buffer holds (GBuffer.hpp:13-16): positions and normals rounded to RGBA16F, */
+/* albedo to RGBA16 UNORM, the normal not re-normalised (lighting.glsl:21,28).                                              */
+static void raster_compat_pixel(const ora_ctx* c, const camera_t* cam, int w, int h, uint32_t px, uint32_t py, int gbuf16, float out[4], path_count* pc) {
   float fx = ((float)px + 0.5f) / (float)w, fy = ((float)py + 0.5f) / (float)h;
   float dvx = (2.0f * fx - 1.0f) * cam->sx, dvy = (2.0f * fy - 1.0f) * cam->sy;
   v3 dn = vfma(cam->s, dvx, vfma(cam->u, dvy, cam->f));
@@ -1252,6 +1388,11 @@ static void raster_compat_pixel(const ora_ctx* c, const camera_t* cam, int w, in
    * normal)), albedo = color * texel */
   surf_t sf = reconstruct(c, d, &hit, 0);
   v3 P = sf.p, N = sf.ns;
+  if (gbuf16) {
+    P = V3(round_f16(P.x), round_f16(P.y), round_f16(P.z));
+    N = V3(round_f16(N.x), round_f16(N.y), round_f16(N.z));
+    for (int k = 0; k < 4; ++k) sf.base[k] = round_unorm16(sf.base[k]);
+  }
   v3 V = normalize3(vsub(cam->pos, P));                      /* lighting.glsl:25 */
   v3 H = normalize3(vadd(V, V));                             /* L = V; BlinnPhong.lib.glsl:6 */
   float ndv = fmax2(dot3(N, V), 0.0f), ndh = fmax2(dot3(N, H), 0.0f);
@@ -1277,7 +1418,7 @@ static void* worker(void* arg) {
         uint32_t t = j->trank[(uint32_t)(y / ORA_TILE) * j->tiles_x + (uint32_t)(x / ORA_TILE)];
         if ((int)(t % (uint32_t)j->tile_count) != j->tile_rank) { o[0] = o[1] = o[2] = o[3] = 0.0f; continue; }
       }
-      if (j->integrator == 1) { raster_compat_pixel(j->c, &j->cam, j->w, j->h, (uint32_t)x, (uint32_t)y, o, &pc); continue; }
+      if (j->integrator != 0) { raster_compat_pixel(j->c, &j->cam, j->w, j->h, (uint32_t)x, (uint32_t)y, j->integrator == 2, o, &pc); continue; }
       v3 sum = V3(0.0f, 0.0f, 0.0f);
       for (int s = 0; s < j->spp; ++s) {                       /* P10: sample-index order */
         v3 L = trace_path(j->c, &j->cam, j->w, j->h, (uint32_t)x, (uint32_t)y, (uint32_t)s, j->seed, j->max_bounces, &pc);
@@ -1299,7 +1440,7 @@ int ora_render(ora_ctx* c, int w, int h, int spp, uint64_t seed, int max_bounces
                int tile_rank, int tile_count, int n_threads, float* out) {
   if (!c->committed) return fail(c, "render: scene not committed");
   if (w <= 0 || h <= 0 || spp <= 0 || max_bounces < 0 || !out) return fail(c, "render: bad argument");
-  if (integrator != 0 && integrator != 1) return fail(c, "render: unknown integrator");
+  if (integrator < 0 || integrator > 2) return fail(c, "render: unknown integrator");
   if (tile_count < 1 || tile_rank < 0 || tile_rank >= tile_count) return fail(c, "render: bad tile rank/count");
   if (n_threads <= 0) n_threads = ora_hw_threads();
   if (n_threads > 256) n_threads = 256;
@@ -1325,7 +1466,7 @@ int ora_render(ora_ctx* c, int w, int h, int spp, uint64_t seed, int max_bounces
       owned += ((int)(tr[(uint32_t)(y / ORA_TILE) * tx + (uint32_t)(x / ORA_TILE)] % (uint32_t)tile_count) == tile_rank);
     free(tr);
   }
-  s->paths = owned * (uint64_t)(integrator == 1 ? 1 : spp);
+  s->paths = owned * (uint64_t)(integrator != 0 ? 1 : spp);
   s->segments = total.segments; s->shadow_rays = total.shadow_rays; s->hits = total.hits;
   s->node_visits_closest = total.closest.nodes; s->tri_tests_closest = total.closest.tris;
   s->node_visits_any = total.any.nodes; s->tri_tests_any = total.any.tris;

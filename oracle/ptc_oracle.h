@@ -44,7 +44,8 @@ int ora_set_texture_filter(ora_ctx*, int mode);                              /* 
 int ora_scene_commit(ora_ctx*);
 
 /* Renders into out_rgba (w*h*4 floats, y-down).  Pixels not owned by (tile_rank, tile_count)
- * stay 0.  n_threads <= 0 means "all online cores". */
+ * stay 0.  n_threads <= 0 means "all online cores".  integrator: 0 path tracer, 1 raster-compat (the reference's
+ * Blinn-Phong pass from fp32 inputs), 2 the same pass from the reference's G-buffer formats (RGBA16F P/N, UNORM16 albedo). */
 int ora_render(ora_ctx*, int w, int h, int spp, uint64_t seed, int max_bounces, int integrator,
                int tile_rank, int tile_count, int n_threads, float* out_rgba);
 int ora_get_stats(ora_ctx*, ora_stats* out);
@@ -56,9 +57,10 @@ int ora_trace_any(ora_ctx*, const float* origins, const float* dirs, const float
 int ora_get_flat_scene(ora_ctx*, uint32_t* n_verts, uint32_t* n_tris, void* verts48,
                        uint32_t* indices, int32_t* tri_material);
 
-/* BVH as built: 4-wide quantised nodes, n_nodes*34 32-bit words each: org[3] (float bits), e[3], qlo[3][4], qhi[3][4],
- * code[4]  (the product stores the same information packed into 48 bytes; tests decode both), sorted triangles n_tris*12 floats
- * (v0,prim | e1,class | e2,0).  NULL pointers to query sizes. */
+/* BVH as built: 8-wide quantised nodes, n_nodes*62 32-bit words each: org[3] (float bits), e[3], qlo[3][8], qhi[3][8],
+ * code[8] (>= 0 node index, < 0 leaf ~(first | (count-1)<<28), 0x80000000 empty slot; the product stores the same
+ * information packed into 80 bytes; tests decode both), sorted triangles n_tris*12 floats (v0,prim | e1,class | e2,0).
+ * NULL pointers to query sizes. */
 int ora_get_bvh(ora_ctx*, uint32_t* n_nodes, uint32_t* n_tris, float* nodes, float* tris);
 
 /* stand-alone pieces for known-answer tests */
@@ -70,6 +72,8 @@ void ora_tonemap_rgba8(const float* rgba, uint32_t n_pixels, uint8_t* out_rgba8)
 void ora_sincos2pi(float u, float* s, float* c);
 float ora_powf(float x, float y);
 float ora_atan2f(float y, float x);
+uint16_t ora_f32_to_f16(float f);                            /* binary32 -> binary16, round to nearest even */
+float ora_f16_to_f32(uint16_t h);
 uint32_t ora_rng_u32(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t dim);
 /* tile ownership: owner rank of pixel (x,y) for a w×h frame split over tile_count ranks */
 int ora_tile_owner(int w, int h, int x, int y, int tile_count);

@@ -45,7 +45,6 @@
 #define SHADE_WAVES (SHADE_BLOCK / 64)
 #define SHADE_LDS_LIGHTS 64       // emitter table and material table are staged in LDS when they fit
 #define SHADE_LDS_MATS 64
-#define CUR_DONE ((int)0x80000000)
 #define HIT_CLASS_SHIFT 28
 
 // ---- small helpers --------------------------------------------------------------------------------
@@ -107,9 +106,13 @@ __global__ __launch_bounds__(256) void k_raygen(DevCamera cam, DevFrame fr, DevQ
 // =================================================================================================
 // traversal machinery shared by the closest-hit and any-hit kernels
 //
-// Per-lane stack of (child code, entry distance) pairs.  The first `L` entries live in LDS
-// (8-byte entries, stride 64 lanes: ds_read/write_b64 is conflict-free at every mix of depths), deeper
-// entries — rare — go to a global overflow slab laid out [wave][depth][lane].
+// 8-wide BVH, 80-byte nodes (layout: ptc_scene.cpp).  A ray keeps ONE group of pending interior children in
+// registers — (base_child, hits<<8 | imask): the slots of one node that were hit and not yet entered — and the
+// older groups on a per-lane stack of 8-byte entries.  The first `L` entries live in LDS (stride 64 lanes:
+// ds_read/write_b64 is conflict-free at every mix of depths), deeper entries — rare: at most one group per tree level
+// is ever pending — go to a global overflow slab laid out [wave][depth][lane].  No per-child entry distance is kept and
+// nothing is sorted: a child sits in the slot of the octant it lies in (builder), so the order in which a ray enters
+// the hit slots follows from its direction signs alone (descending slot ^ octant; a 2-KiB LDS table gives the next slot).
 struct WStack {
   typedef unsigned int ux2 __attribute__((ext_vector_type(2)));
   typedef __attribute__((address_space(3))) ux2 lds_u2;
@@ -117,8 +120,8 @@ struct WStack {
   lds_u2* lds; glb_u2* ovf; int sp; int L;
   PT_DEV void init(uint2* lds_base, uint2* ovf_base, int l) { lds = (lds_u2*)lds_base; ovf = (glb_u2*)ovf_base; sp = 0; L = l; }
   PT_DEV void reset() { sp = 0; }
-  PT_DEV void push(int code, uint32_t key) {
-    const ux2 e = {(unsigned int)code, key & 0xfffffffcu};
+  PT_DEV void push(uint32_t base, uint32_t mask) {
+    const ux2 e = {base, mask};
     if (sp < L) lds[sp * 64] = e; else ovf[(sp - L) * 64] = e;      // explicit address spaces: ds_write_b64 / global_store_dwordx2
     ++sp;
   }
@@ -131,114 +134,114 @@ struct WStack {
   PT_DEV bool empty() const { return sp == 0; }
 };
 
-PT_DEV void cswap(uint32_t& ka, int& ca, uint32_t& kb, int& cb) {
-  const bool s = kb < ka;
-  const uint32_t tk = s ? kb : ka; const int tc = s ? cb : ca;
-  kb = s ? ka : kb; cb = s ? ca : cb;
-  ka = tk; ca = tc;
-}
-
-#define KEY_MISS 0xffffffffu
-#define CODE_EMPTY ((int)0x80000000)
-
-// Per-ray constants of the slab test: the sign of each direction component says which of a child's two
-// planes on that axis is entered first, so near/far need no min/max (identical values to min(t0,t1) /
-// max(t0,t1): fma is monotonic in the plane coordinate).
-struct Octant { bool px, py, pz; };
-PT_DEV Octant make_octant(const ray_t& r) {
-  Octant o;
-  o.px = r.inv.x >= 0.0f; o.py = r.inv.y >= 0.0f; o.pz = r.inv.z >= 0.0f;
-  return o;
-}
-
 typedef float float2v __attribute__((ext_vector_type(2)));
 PT_DEV float hw_max(float a, float b) { return __builtin_fmaxf(a, b); }   // v_max_f32 / v_max3_f32: same value as
 PT_DEV float hw_min(float a, float b) { return __builtin_fminf(a, b); }   // the ternary for non-NaN operands (±0 aside)
 PT_DEV float ubyte_f(uint32_t w, int i) { return (float)((w >> (8 * i)) & 255u); }   // v_cvt_f32_ubyte{i}
 
-// Decoded 48-byte node (layout: ptc_scene.cpp): entry/exit distances of the four children and their codes.
-struct WideHit { float tn[4], tf[4]; int code[4]; bool used[4]; };
+// lane state of a traversal
+#define CUR_DONE ((int)0x80000000)        // idle lane: wants a new ray
+#define CUR_FINISHED (CUR_DONE + 1)       // ray finished, result not yet published
+#define CUR_LEAF (CUR_DONE + 2)           // triangles of the last visited node pending
 
+// Direction octant of a ray: bit k set when component k of the direction is >= 0 (the oracle's ray_octant).
+PT_DEV uint32_t ray_octant(const ray_t& r) { return (r.inv.x >= 0.0f ? 1u : 0u) | (r.inv.y >= 0.0f ? 2u : 0u) | (r.inv.z >= 0.0f ? 4u : 0u); }
+
+// Slot order table: s_order[oct][hits] = the set bit s of `hits` with the largest (s ^ oct).
+#define ORDER_TABLE_BYTES 2048
+PT_DEV void build_order_table(uint8_t* tab) {
+  for (uint32_t i = threadIdx.x; i < ORDER_TABLE_BYTES; i += TRACE_BLOCK) {
+    const uint32_t oct = i >> 8, hits = i & 255u;
+    uint32_t best = 0, bk = 0;
+    for (uint32_t sl = 0; sl < 8u; ++sl)
+      if ((hits >> sl) & 1u) { const uint32_t k = (sl ^ oct) + 1u; if (k > bk) { bk = k; best = sl; } }
+    tab[i] = (uint8_t)best;
+  }
+}
+
+// One node visit: the 8 slots of node `cur` against [tmin, tlimit].  Returns the hit mask (bit s = slot s, empty slots
+// masked off) and the node's child/triangle bases and slot masks (imask | lmask<<8 | two<<16).
+// Per-ray constants of the slab test: the sign of each direction component says which of a child's two planes on that
+// axis is entered first, so near/far need no min/max (identical values to min(t0,t1) / max(t0,t1): fma is monotonic in
+// the plane coordinate).  plane distance = fma(q, 2^(e-127)·inv, fma(org, inv, -ood)).
 template <bool NODELETS>
-PT_DEV WideHit wide_decode(const DevScene& sc, const float4* lds_nodes, int cur, const ray_t& r, const Octant& oc) {
-  // two explicit address spaces (a single pointer that may be LDS or global would compile to FLAT loads, which occupy both
-  // the LDS and the vector-memory pipe and wait on both counters)
-  // Two explicit address spaces: a pointer that may be LDS or global compiles to FLAT loads, which occupy both the LDS and the
-  // vector-memory pipe and wait on both counters.
+PT_DEV uint32_t node_visit(const DevScene& sc, const float4* lds_nodes, int cur, const ray_t& r, uint32_t oct, float tmin, float tlimit,
+                           uint32_t& base_child, uint32_t& base_tri, uint32_t& masks) {
+  // two explicit address spaces: a pointer that may be LDS or global compiles to FLAT loads, which occupy both the LDS and the
+  // vector-memory pipe and wait on both counters
   typedef float fx4 __attribute__((ext_vector_type(4)));
   typedef __attribute__((address_space(3))) const fx4 lds_f4;
   typedef __attribute__((address_space(1))) const fx4 glb_f4;
-  fx4 f0, f1, f2;
+  fx4 f0, f1, f2, f3, f4;
   if (NODELETS && (uint32_t)cur < sc.n_nodelets) {
-    lds_f4* p = (lds_f4*)lds_nodes + (uint32_t)cur * 3u;          // ds_read_b128 × 3
-    f0 = p[0]; f1 = p[1]; f2 = p[2];
+    lds_f4* p = (lds_f4*)lds_nodes + (uint32_t)cur * 5u;          // ds_read_b128 × 5
+    f0 = p[0]; f1 = p[1]; f2 = p[2]; f3 = p[3]; f4 = p[4];
   } else {
-    glb_f4* p = (glb_f4*)sc.nodes + (size_t)cur * 3;               // global_load_dwordx4 × 3
-    f0 = p[0]; f1 = p[1]; f2 = p[2];
+    glb_f4* p = (glb_f4*)sc.nodes + (size_t)cur * 5;               // global_load_dwordx4 × 5
+    f0 = p[0]; f1 = p[1]; f2 = p[2]; f3 = p[3]; f4 = p[4];
   }
   const uint32_t ew = __float_as_uint(f0.w);
-  // plane distance = fma(q, 2^(e-127)·inv, fma(org, inv, -ood))
   const float ax = __uint_as_float((ew & 255u) << 23) * r.inv.x, ay = __uint_as_float(((ew >> 8) & 255u) << 23) * r.inv.y,
               az = __uint_as_float(((ew >> 16) & 255u) << 23) * r.inv.z;
   const float bx = pt_fma(f0.x, r.inv.x, -r.ood.x), by = pt_fma(f0.y, r.inv.y, -r.ood.y), bz = pt_fma(f0.z, r.inv.z, -r.ood.z);
-  const uint32_t qlx = __float_as_uint(f1.x), qly = __float_as_uint(f1.y), qlz = __float_as_uint(f1.z);
-  const uint32_t qhx = __float_as_uint(f1.w), qhy = __float_as_uint(f2.x), qhz = __float_as_uint(f2.y);
-  const uint32_t nqx = oc.px ? qlx : qhx, fqx = oc.px ? qhx : qlx;
-  const uint32_t nqy = oc.py ? qly : qhy, fqy = oc.py ? qhy : qly;
-  const uint32_t nqz = oc.pz ? qlz : qhz, fqz = oc.pz ? qhz : qlz;
-  const uint32_t w10 = __float_as_uint(f2.z);
-  const uint32_t desc = (ew >> 24) | ((w10 >> 24) << 8);
-  uint32_t next_child = w10 & 0xffffffu, next_tri = __float_as_uint(f2.w);
-  WideHit h;
-  // (packing the 24 plane fmas into 12 v_pk_fma_f32 was measured: 6 % slower)
+  const bool px = (oct & 1u) != 0u, py = (oct & 2u) != 0u, pz = (oct & 4u) != 0u;
+  // [0]: slots 0-3, [1]: slots 4-7
+  const uint32_t lx[2] = {__float_as_uint(f1.x), __float_as_uint(f1.y)}, ly[2] = {__float_as_uint(f1.z), __float_as_uint(f1.w)},
+                 lz[2] = {__float_as_uint(f2.x), __float_as_uint(f2.y)}, hx[2] = {__float_as_uint(f2.z), __float_as_uint(f2.w)},
+                 hy[2] = {__float_as_uint(f3.x), __float_as_uint(f3.y)}, hz[2] = {__float_as_uint(f3.z), __float_as_uint(f3.w)};
+  uint32_t hits = 0;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    h.tn[i] = hw_max(hw_max(pt_fma(ubyte_f(nqx, i), ax, bx), pt_fma(ubyte_f(nqy, i), ay, by)), pt_fma(ubyte_f(nqz, i), az, bz));
-    h.tf[i] = hw_min(hw_min(pt_fma(ubyte_f(fqx, i), ax, bx), pt_fma(ubyte_f(fqy, i), ay, by)), pt_fma(ubyte_f(fqz, i), az, bz));
-    const uint32_t d = (desc >> (4 * i)) & 15u;
-    const uint32_t type = d >> 2, cm1 = d & 3u;
-    h.used[i] = type != 0u;
-    h.code[i] = type == 2u ? (int)next_child : (int)~(next_tri | (cm1 << 28));
-    next_child += type == 2u ? 1u : 0u;
-    next_tri += type == 1u ? cm1 + 1u : 0u;
+  for (int h = 1; h >= 0; --h) {
+    const uint32_t nqx = px ? lx[h] : hx[h], fqx = px ? hx[h] : lx[h];
+    const uint32_t nqy = py ? ly[h] : hy[h], fqy = py ? hy[h] : ly[h];
+    const uint32_t nqz = pz ? lz[h] : hz[h], fqz = pz ? hz[h] : lz[h];
+#pragma unroll
+    for (int i = 3; i >= 0; --i) {      // slot 4h+i; descending, so that shifting the results in leaves slot s in bit s
+      const float tn = hw_max(hw_max(hw_max(pt_fma(ubyte_f(nqx, i), ax, bx), pt_fma(ubyte_f(nqy, i), ay, by)), pt_fma(ubyte_f(nqz, i), az, bz)), tmin);
+      const float tf = hw_min(hw_min(hw_min(pt_fma(ubyte_f(fqx, i), ax, bx), pt_fma(ubyte_f(fqy, i), ay, by)), pt_fma(ubyte_f(fqz, i), az, bz)), tlimit);
+      hits = hits + hits + (tn <= tf ? 1u : 0u);                   // v_cmp + v_addc
+    }
   }
-  return h;
+  const uint32_t w18 = __float_as_uint(f4.z);
+  const uint32_t imask = ew >> 24;
+  masks = imask | (w18 << 8);
+  base_child = __float_as_uint(f4.x); base_tri = __float_as_uint(f4.y);
+  return hits & (imask | (w18 & 255u));
 }
 
-// One closest-hit step at wide node `cur`: order the hit children by key = (bits(tnear) & ~3) | slot, push
-// all but the nearest (farthest first), return the nearest child's code or CODE_EMPTY when nothing was hit.
-template <bool NODELETS>
-PT_DEV int wide_step(const DevScene& sc, const float4* lds_nodes, int cur, const ray_t& r, const Octant& oc, float tmin, float tlimit, WStack& st) {
-  const WideHit h = wide_decode<NODELETS>(sc, lds_nodes, cur, r, oc);
-  int c[4] = {h.code[0], h.code[1], h.code[2], h.code[3]};
-  uint32_t k[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float tn = hw_max(h.tn[i], tmin), tf = hw_min(h.tf[i], tlimit);
-    k[i] = (tn <= tf && h.used[i]) ? ((__float_as_uint(tn) & 0xfffffffcu) | (uint32_t)i) : KEY_MISS;
+// Pending-group bookkeeping.  G = (gbase, gmask = hits<<8 | imask) is the group in registers; `nh` are the interior hits of
+// the node just visited.  A non-empty new group goes on top (the old one is saved), then the next child is taken from the
+// top group: slot by the order table (closest hit) or the lowest set bit (any hit).  Returns the next node or CUR_FINISHED.
+template <bool ORDERED>
+PT_DEV int advance(uint32_t& gbase, uint32_t& gmask, WStack& st, const uint8_t* order_tab, uint32_t oct) {
+  typedef __attribute__((address_space(3))) const uint8_t lds_u8c;
+  if ((gmask >> 8) == 0u) {
+    if (st.empty()) return CUR_FINISHED;
+    const uint2 e = st.pop();
+    gbase = e.x; gmask = e.y;
   }
-  cswap(k[0], c[0], k[1], c[1]); cswap(k[2], c[2], k[3], c[3]);
-  cswap(k[0], c[0], k[2], c[2]); cswap(k[1], c[1], k[3], c[3]);
-  cswap(k[1], c[1], k[2], c[2]);
-  if (k[3] != KEY_MISS) st.push(c[3], k[3]);
-  if (k[2] != KEY_MISS) st.push(c[2], k[2]);
-  if (k[1] != KEY_MISS) st.push(c[1], k[1]);
-  return k[0] != KEY_MISS ? c[0] : CODE_EMPTY;
+  const uint32_t hits = gmask >> 8;
+  const uint32_t sl = ORDERED ? (uint32_t)((lds_u8c*)order_tab)[(oct << 8) | hits] : (uint32_t)__builtin_ctz(hits);
+  gmask &= ~(256u << sl);
+  return (int)(gbase + (uint32_t)__builtin_popcount(gmask & 255u & ((1u << sl) - 1u)));
+}
+PT_DEV void enter_group(uint32_t& gbase, uint32_t& gmask, WStack& st, uint32_t nbase, uint32_t nhits, uint32_t nimask) {
+  if (nhits == 0u) return;
+  if ((gmask >> 8) != 0u) st.push(gbase, gmask);
+  gbase = nbase; gmask = (nhits << 8) | nimask;
 }
 
-// Any-hit variant: occlusion needs no front-to-back order, so the hits are taken in slot order — the first
-// hit child is entered, the others pushed so that they pop in slot order — and the sorting network is saved.
-template <bool NODELETS>
-PT_DEV int wide_step_any(const DevScene& sc, const float4* lds_nodes, int cur, const ray_t& r, const Octant& oc, float tmax, WStack& st) {
-  const WideHit h = wide_decode<NODELETS>(sc, lds_nodes, cur, r, oc);
-  const bool h0 = h.used[0] && hw_max(h.tn[0], 0.0f) <= hw_min(h.tf[0], tmax);
-  const bool h1 = h.used[1] && hw_max(h.tn[1], 0.0f) <= hw_min(h.tf[1], tmax);
-  const bool h2 = h.used[2] && hw_max(h.tn[2], 0.0f) <= hw_min(h.tf[2], tmax);
-  const bool h3 = h.used[3] && hw_max(h.tn[3], 0.0f) <= hw_min(h.tf[3], tmax);
-  if (h3 && (h0 || h1 || h2)) st.push(h.code[3], 0u);
-  if (h2 && (h0 || h1)) st.push(h.code[2], 0u);
-  if (h1 && h0) st.push(h.code[1], 0u);
-  return h0 ? h.code[0] : (h1 ? h.code[1] : (h2 ? h.code[2] : (h3 ? h.code[3] : CODE_EMPTY)));
+// Pending triangles of the last visited node: tmask = lhits | lmask<<8 | two<<16 | second<<24.  Returns the record index of
+// the next triangle to test and removes it from the set: the hit leaf slots in ascending order, a 2-triangle leaf's
+// second triangle right after its first.
+PT_DEV uint32_t next_triangle(uint32_t tbase, uint32_t& tmask) {
+  const uint32_t sl = (uint32_t)__builtin_ctz(tmask & 255u);
+  const uint32_t below = (1u << sl) - 1u;
+  const uint32_t second = tmask >> 24;
+  const uint32_t k = tbase + (uint32_t)__builtin_popcount((tmask >> 8) & 255u & below) + (uint32_t)__builtin_popcount((tmask >> 16) & 255u & below) + second;
+  const bool more = second == 0u && ((tmask >> (16u + sl)) & 1u) != 0u;
+  tmask = more ? (tmask | (1u << 24)) : ((tmask & 0x00ffffffu) & ~(1u << sl));
+  return k;
 }
 
 // Wave-private reservoir of input slots: one atomic fetches TRACE_CHUNK consecutive rays, idle lanes are
@@ -270,38 +273,40 @@ struct Reservoir {
   }
 };
 
-#define CUR_FINISHED (CUR_DONE + 1)
-
 #ifdef PT_DIAG
 #define DIAG_ITER(var) do { const uint64_t m_ = __ballot(true); if ((int)lane == __ffsll((unsigned long long)m_) - 1) ++(var); } while (0)
 #else
 #define DIAG_ITER(var) do { } while (0)
 #endif
 
+// LDS of a trace block: [n_nodelets × 80 B nodes][waves × L × 64 stack entries of 8 B][2 KiB slot-order table (closest hit only)]
+PT_DEV uint2* trace_lds_stack(float4* lds_raw, const DevScene& sc, bool nodelets) { return reinterpret_cast<uint2*>(lds_raw + (nodelets ? (size_t)sc.n_nodelets * 5 : 0)); }
+
 // =================================================================================================
-// P3 closest-hit traversal + triangle intersection: persistent waves, dynamic lane refill, 4-wide BVH.
-// Children are visited nearest first (order key above); a popped entry whose entry distance exceeds the
-// current best hit is skipped.  Closest hit = lexicographic minimum of (t, original primitive id).
+// P3 closest-hit traversal + triangle intersection: persistent waves, dynamic lane refill, 8-wide BVH.
+// Per node: the 8 slots are tested against [tmin, best_t]; the triangles of the hit leaf slots are intersected (slot
+// order) before the ray descends into the hit interior children, nearest octant first.
+// Closest hit = lexicographic minimum of (t, original primitive id).
 // The hit record (t, prim | class<<28, u, v) is written IN PLACE at the ray's slot (miss: prim = -1).
 // CULL: R6 back-face culling + per-ray [tmin,tmax] from B.zw (raster-compat primary rays).
 template <bool CULL, bool NODELETS>
 __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_closest(DevScene sc, DevQueues q, int qi, int stack_lds) {
   extern __shared__ float4 lds_raw[];
-  __shared__ uint8_t s_pair[2][TRACE_WAVES][64];   // leaf phase: k-th two-triangle lane <-> k-th idle lane
-  float4* lds_nodes = lds_raw;                                                       // [n_nodelets × 48 B]
-  uint2* lds_stack = reinterpret_cast<uint2*>(lds_raw + (NODELETS ? (size_t)sc.n_nodelets * 3 : 0));   // [waves][L][64]
+  float4* lds_nodes = lds_raw;                                                       // [n_nodelets × 80 B]
+  uint2* lds_stack = trace_lds_stack(lds_raw, sc, NODELETS);                         // [waves][L][64]
+  uint8_t* order_tab = reinterpret_cast<uint8_t*>(lds_stack + (size_t)TRACE_WAVES * (size_t)stack_lds * 64u);
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
-  if (NODELETS) {
-    for (uint32_t i = threadIdx.x; i < sc.n_nodelets * 3u; i += TRACE_BLOCK) lds_nodes[i] = sc.nodes[i];
-    __syncthreads();
-  }
+  if (NODELETS)
+    for (uint32_t i = threadIdx.x; i < sc.n_nodelets * 5u; i += TRACE_BLOCK) lds_nodes[i] = sc.nodes[i];
+  build_order_table(order_tab);
+  __syncthreads();
   const RayQ rq = q.ray[qi];
   const uint32_t n = q.cnt[CNT_RAYS];
   unsigned long long nv = 0, nr = 0, nh = 0;   // wave totals, only updated at wave-uniform points: they live in SGPRs
-  uint32_t nt = 0;                               // per lane (updated inside the divergent leaf loop)
-  uint32_t d_node = 0, d_tri = 0, d_leaf = 0, d_round = 0;
-  (void)d_node; (void)d_tri; (void)d_leaf; (void)d_round;
+  uint32_t nt = 0;                               // per lane (updated inside the divergent leaf phase)
+  uint32_t d_node = 0, d_tri = 0, d_round = 0;
+  (void)d_node; (void)d_tri; (void)d_round;
 #ifdef PT_STAMP
   unsigned long long t_refill = 0, t_node = 0, t_leaf = 0, t_fin = 0, t_mark = __builtin_amdgcn_s_memtime();
 #define STAMP(acc) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - t_mark; t_mark = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -313,9 +318,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_closest(
   st.init(lds_stack + (size_t)wave * (size_t)stack_lds * 64u + lane,
           sc.stack_ovf + ((size_t)(blockIdx.x * TRACE_WAVES + wave) * sc.ovf_depth) * 64u + lane, stack_lds);
   int cur = CUR_DONE;
-  uint32_t ri = 0;
+  uint32_t ri = 0, oct = 0, gbase = 0, gmask = 0, tbase = 0, tmask = 0;
   ray_t r = make_ray(V3(0, 0, 0), V3(0, 0, 1));
-  Octant oc = make_octant(r);
   float tmin = 0.0f, best_t = PT_T_INF, best_u = 0.0f, best_v = 0.0f;
   int best_prim = 0x7fffffff, best_cls = 0;
   bool found = false;
@@ -326,10 +330,11 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_closest(
     if (got) {
       const float4 A = rq.A[ri], Bq = rq.B[ri];
       r = make_ray(V3(A.x, A.y, A.z), V3(A.w, Bq.x, Bq.y));
-      oc = make_octant(r);
+      oct = ray_octant(r);
       tmin = CULL ? Bq.z : 0.0f;
       best_t = CULL ? Bq.w : PT_T_INF; best_u = 0.0f; best_v = 0.0f; best_prim = 0x7fffffff; best_cls = 0; found = false;
       st.reset();
+      gmask = 0; tmask = 0;
       cur = 0;
     }
     STAMP(t_refill);
@@ -343,80 +348,34 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_closest(
       for (;;) {
         const uint64_t mn = __ballot(cur >= 0);
         if (!mn) break;
-        if (__popcll(mn) < TRACE_NODE_MIN && __ballot(cur < 0 && cur > CUR_FINISHED)) break;   // few walkers, leaves waiting
+        if (__popcll(mn) < TRACE_NODE_MIN && __ballot(cur == CUR_LEAF)) break;   // few walkers, triangles waiting
         nv += (unsigned long long)__popcll(mn);
         if (cur >= 0) {
           DIAG_ITER(d_node);
-          cur = wide_step<NODELETS>(sc, lds_nodes, cur, r, oc, tmin, best_t, st);
-          if (cur == CODE_EMPTY) {                                     // nothing hit: pop, skipping culled entries
-            cur = CUR_FINISHED;
-            while (!st.empty()) { const uint2 e = st.pop(); if (__uint_as_float(e.y) > best_t) continue; cur = (int)e.x; break; }
-          }
+          uint32_t nb, masks;
+          const uint32_t hits = node_visit<NODELETS>(sc, lds_nodes, cur, r, oct, tmin, best_t, nb, tbase, masks);
+          const uint32_t imask = masks & 255u, lhits = hits & (masks >> 8);
+          enter_group(gbase, gmask, st, nb, hits & imask, imask);
+          tmask = lhits | (masks & 0x00ffff00u);
+          cur = lhits ? CUR_LEAF : advance<true>(gbase, gmask, st, order_tab, oct);
         }
       }
       STAMP(t_node);
-      {
-        // ---- leaf phase.  A leaf holds 1 or 2 triangles (PT_LEAF_MAX).  The second triangle of a leaf is tested in the
-        // SAME pass by an idle lane (a lane that is not at a leaf) with the owner's ray fetched through ds_bpermute, instead
-        // of a second pass over the few lanes that have one: same tests, same order of the hit updates, half the passes.
-        const bool leaf = cur < 0 && cur > CUR_FINISHED;
-        const uint64_t m_leaf = __ballot(leaf);
-        if (m_leaf) {
-          const uint32_t code = leaf ? (uint32_t)~cur : 0u;
-          const uint32_t first = code & 0x0fffffffu, count = leaf ? (code >> 28) + 1u : 0u;
-          const bool two = count == 2u;
-          const uint64_t m_two = __ballot(two), m_free = ~m_leaf;
-          const uint32_t n_two = (uint32_t)__popcll(m_two);
-          if (__ballot(count > 2u) == 0 && n_two <= (uint32_t)__popcll(m_free)) {
-            const uint32_t rank_two = mbcnt64(m_two), rank_free = mbcnt64(m_free);
-            const bool helper = !leaf && rank_free < n_two;
-            typedef __attribute__((address_space(3))) volatile uint8_t lds_u8;
-            lds_u8* tab_owner = (lds_u8*)s_pair[0][wave];
-            lds_u8* tab_helper = (lds_u8*)s_pair[1][wave];
-            if (two) tab_owner[rank_two] = (uint8_t)lane;
-            if (helper) tab_helper[rank_free] = (uint8_t)lane;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int src = helper ? (int)tab_owner[rank_free] : (int)lane;      // whose ray this lane tests with
-            ray_t rr;
-            rr.o = V3(__shfl(r.o.x, src), __shfl(r.o.y, src), __shfl(r.o.z, src));
-            rr.d = V3(__shfl(r.d.x, src), __shfl(r.d.y, src), __shfl(r.d.z, src));
-            const uint32_t first_src = (uint32_t)__shfl((int)first, src);         // unconditional: a shuffle inside ?: would run with the owners masked off
-            const uint32_t k = helper ? first_src + 1u : first;
-            bool hit = false; float t = 0.0f, u = 0.0f, v = 0.0f; int pid = 0, cls = 0;
-            if (leaf || helper) {
-              const float4 a = sc.tris[(size_t)k * 3 + 0], b = sc.tris[(size_t)k * 3 + 1], c = sc.tris[(size_t)k * 3 + 2];
-              ++nt;
-              hit = tri_test<CULL>(rr, V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), t, u, v);
-              pid = __float_as_int(a.w); cls = __float_as_int(b.w);
-            }
-            if (leaf && hit && t > tmin && (t < best_t || (t == best_t && pid < best_prim))) {
-              best_t = t; best_u = u; best_v = v; best_prim = pid; best_cls = cls; found = true;
-            }
-            const int hsrc = two ? (int)tab_helper[rank_two] : (int)lane;        // the lane that tested this leaf's second triangle
-            const int h2 = __shfl(hit ? 1 : 0, hsrc);
-            const float t2 = __shfl(t, hsrc), u2 = __shfl(u, hsrc), v2 = __shfl(v, hsrc);
-            const int pid2 = __shfl(pid, hsrc), cls2 = __shfl(cls, hsrc);
-            if (two && h2 && t2 > tmin && (t2 < best_t || (t2 == best_t && pid2 < best_prim))) {
-              best_t = t2; best_u = u2; best_v = v2; best_prim = pid2; best_cls = cls2; found = true;
-            }
-          } else if (leaf) {                                                      // no spare lanes (or wider leaves): one triangle per pass
-            for (uint32_t k = first; k < first + count; ++k) {
-              const float4 a = sc.tris[(size_t)k * 3 + 0], b = sc.tris[(size_t)k * 3 + 1], c = sc.tris[(size_t)k * 3 + 2];
-              ++nt;
-              float t, u, v;
-              if (!tri_test<CULL>(r, V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), t, u, v)) continue;
-              const int pid = __float_as_int(a.w);
-              if (t > tmin && (t < best_t || (t == best_t && pid < best_prim))) {
-                best_t = t; best_u = u; best_v = v; best_prim = pid; best_cls = __float_as_int(b.w); found = true;
-              }
+      // ---- leaf phase: every lane with pending triangles tests one ----
+      if (__ballot(cur == CUR_LEAF)) {
+        DIAG_ITER(d_tri);
+        if (cur == CUR_LEAF) {
+          const uint32_t k = next_triangle(tbase, tmask);
+          const float4 a = sc.tris[(size_t)k * 3 + 0], b = sc.tris[(size_t)k * 3 + 1], c = sc.tris[(size_t)k * 3 + 2];
+          ++nt;
+          float t, u, v;
+          if (tri_test<CULL>(r, V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), t, u, v)) {
+            const int pid = __float_as_int(a.w);
+            if (t > tmin && (t < best_t || (t == best_t && pid < best_prim))) {
+              best_t = t; best_u = u; best_v = v; best_prim = pid; best_cls = __float_as_int(b.w); found = true;
             }
           }
-          if (leaf) {
-            cur = CUR_FINISHED;
-            while (!st.empty()) { const uint2 e = st.pop(); if (__uint_as_float(e.y) > best_t) continue; cur = (int)e.x; break; }
-          }
+          if ((tmask & 255u) == 0u) cur = advance<true>(gbase, gmask, st, order_tab, oct);
         }
       }
       STAMP(t_leaf);
@@ -438,26 +397,25 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_closest(
 #endif
 #ifdef PT_DIAG
   {
-    unsigned long long a0 = wave_sum(d_node), a1 = wave_sum(d_tri), a2 = wave_sum(d_leaf), a3 = wave_sum(d_round);
-    if (lane == 0) { atomicAdd(&q.stats[ST_DIAG_NODE_ITERS], a0); atomicAdd(&q.stats[ST_DIAG_TRI_ITERS], a1); atomicAdd(&q.stats[ST_DIAG_LEAF_VISITS], a2); atomicAdd(&q.stats[ST_DIAG_ROUNDS], a3); }
+    unsigned long long a0 = wave_sum(d_node), a1 = wave_sum(d_tri), a3 = wave_sum(d_round);
+    if (lane == 0) { atomicAdd(&q.stats[ST_DIAG_NODE_ITERS], a0); atomicAdd(&q.stats[ST_DIAG_TRI_ITERS], a1); atomicAdd(&q.stats[ST_DIAG_ROUNDS], a3); }
   }
 #endif
 }
 
 // =================================================================================================
-// P4 any-hit traversal for the NEE shadow rays (same machinery, no distance culling: the interval is
-// fixed); an unoccluded ray adds its contribution to the path's radiance word (single owner: one shadow
-// ray per path per bounce).
+// P4 any-hit traversal for the NEE shadow rays: same nodes and machinery, the interval is fixed, hit slots are taken in
+// ascending slot order (occlusion needs no front-to-back order) and the first triangle hit inside (0, tmax) ends the ray.
+// An unoccluded ray adds its contribution to the path's radiance word (single owner: one shadow ray per path per bounce).
 template <bool NODELETS, bool DEBUG_OUT>
 __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_any(DevScene sc, DevQueues q, int stack_lds, uint8_t* debug_out) {
   extern __shared__ float4 lds_raw[];
-  __shared__ uint8_t s_pair[2][TRACE_WAVES][64];   // leaf phase: k-th two-triangle lane <-> k-th idle lane
   float4* lds_nodes = lds_raw;
-  uint2* lds_stack = reinterpret_cast<uint2*>(lds_raw + (NODELETS ? (size_t)sc.n_nodelets * 3 : 0));
+  uint2* lds_stack = trace_lds_stack(lds_raw, sc, NODELETS);
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
   if (NODELETS) {
-    for (uint32_t i = threadIdx.x; i < sc.n_nodelets * 3u; i += TRACE_BLOCK) lds_nodes[i] = sc.nodes[i];
+    for (uint32_t i = threadIdx.x; i < sc.n_nodelets * 5u; i += TRACE_BLOCK) lds_nodes[i] = sc.nodes[i];
     __syncthreads();
   }
   const uint32_t n = q.cnt[CNT_SHADOW];
@@ -468,9 +426,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_any(DevS
   st.init(lds_stack + (size_t)wave * (size_t)stack_lds * 64u + lane,
           sc.stack_ovf + ((size_t)(blockIdx.x * TRACE_WAVES + wave) * sc.ovf_depth) * 64u + lane, stack_lds);
   int cur = CUR_DONE;
-  uint32_t ri = 0, path = 0;
+  uint32_t ri = 0, path = 0, oct = 0, gbase = 0, gmask = 0, tbase = 0, tmask = 0;
   ray_t r = make_ray(V3(0, 0, 0), V3(0, 0, 1));
-  Octant oc = make_octant(r);
   float tmax = 0.0f;
   bool occluded = false;
   for (;;) {
@@ -479,10 +436,11 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_any(DevS
     if (got) {
       const float4 A = q.shadow.A[ri], Bq = q.shadow.B[ri];
       r = make_ray(V3(A.x, A.y, A.z), V3(A.w, Bq.x, Bq.y));
-      oc = make_octant(r);
+      oct = ray_octant(r);
       tmax = Bq.z; path = __float_as_uint(Bq.w);
       occluded = false;
       st.reset();
+      gmask = 0; tmask = 0;
       cur = 0;
     }
     if (!__ballot(cur != CUR_DONE)) {
@@ -493,66 +451,25 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_any(DevS
       for (;;) {
         const uint64_t mn = __ballot(cur >= 0);
         if (!mn) break;
-        if (__popcll(mn) < TRACE_NODE_MIN && __ballot(cur < 0 && cur > CUR_FINISHED)) break;
+        if (__popcll(mn) < TRACE_NODE_MIN && __ballot(cur == CUR_LEAF)) break;
         nv += (unsigned long long)__popcll(mn);
         if (cur >= 0) {
-          cur = wide_step_any<NODELETS>(sc, lds_nodes, cur, r, oc, tmax, st);
-          if (cur == CODE_EMPTY) cur = st.empty() ? CUR_FINISHED : (int)st.pop().x;
+          uint32_t nb, masks;
+          const uint32_t hits = node_visit<NODELETS>(sc, lds_nodes, cur, r, oct, 0.0f, tmax, nb, tbase, masks);
+          const uint32_t imask = masks & 255u, lhits = hits & (masks >> 8);
+          enter_group(gbase, gmask, st, nb, hits & imask, imask);
+          tmask = lhits | (masks & 0x00ffff00u);
+          cur = lhits ? CUR_LEAF : advance<false>(gbase, gmask, st, nullptr, 0u);
         }
       }
-      {
-        // ---- leaf phase: as in k_trace_closest, the second triangle of a 2-triangle leaf is tested in the same pass by an idle
-        // lane.  The counter stays the sequential one: the second test is counted only when the first one missed.
-        const bool leaf = cur < 0 && cur > CUR_FINISHED;
-        const uint64_t m_leaf = __ballot(leaf);
-        if (m_leaf) {
-          const uint32_t code = leaf ? (uint32_t)~cur : 0u;
-          const uint32_t first = code & 0x0fffffffu, count = leaf ? (code >> 28) + 1u : 0u;
-          const bool two = count == 2u;
-          const uint64_t m_two = __ballot(two), m_free = ~m_leaf;
-          const uint32_t n_two = (uint32_t)__popcll(m_two);
-          if (__ballot(count > 2u) == 0 && n_two <= (uint32_t)__popcll(m_free)) {
-            const uint32_t rank_two = mbcnt64(m_two), rank_free = mbcnt64(m_free);
-            const bool helper = !leaf && rank_free < n_two;
-            typedef __attribute__((address_space(3))) volatile uint8_t lds_u8;
-            lds_u8* tab_owner = (lds_u8*)s_pair[0][wave];
-            lds_u8* tab_helper = (lds_u8*)s_pair[1][wave];
-            if (two) tab_owner[rank_two] = (uint8_t)lane;
-            if (helper) tab_helper[rank_free] = (uint8_t)lane;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int src = helper ? (int)tab_owner[rank_free] : (int)lane;
-            ray_t rr;
-            rr.o = V3(__shfl(r.o.x, src), __shfl(r.o.y, src), __shfl(r.o.z, src));
-            rr.d = V3(__shfl(r.d.x, src), __shfl(r.d.y, src), __shfl(r.d.z, src));
-            const float tmax_src = __shfl(tmax, src);
-            const uint32_t first_src = (uint32_t)__shfl((int)first, src);         // unconditional (see k_trace_closest)
-            const uint32_t k = helper ? first_src + 1u : first;
-            bool hit = false;
-            if (leaf || helper) {
-              const float4 a = sc.tris[(size_t)k * 3 + 0], b = sc.tris[(size_t)k * 3 + 1], c = sc.tris[(size_t)k * 3 + 2];
-              float t, u, v;
-              hit = tri_test<false>(rr, V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), t, u, v) && t > 0.0f && t < tmax_src;
-            }
-            const int hsrc = two ? (int)tab_helper[rank_two] : (int)lane;
-            const int h2 = __shfl(hit ? 1 : 0, hsrc);
-            if (leaf) {
-              nt += 1u + ((two && !hit) ? 1u : 0u);
-              if (hit || (two && h2)) occluded = true;
-            }
-          } else if (leaf) {
-            for (uint32_t k = first; k < first + count; ++k) {
-              const float4 a = sc.tris[(size_t)k * 3 + 0], b = sc.tris[(size_t)k * 3 + 1], c = sc.tris[(size_t)k * 3 + 2];
-              ++nt;
-              float t, u, v;
-              if (tri_test<false>(r, V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), t, u, v) && t > 0.0f && t < tmax) {
-                occluded = true;
-                break;
-              }
-            }
-          }
-          if (leaf) cur = (occluded || st.empty()) ? CUR_FINISHED : (int)st.pop().x;
+      if (__ballot(cur == CUR_LEAF)) {
+        if (cur == CUR_LEAF) {
+          const uint32_t k = next_triangle(tbase, tmask);
+          const float4 a = sc.tris[(size_t)k * 3 + 0], b = sc.tris[(size_t)k * 3 + 1], c = sc.tris[(size_t)k * 3 + 2];
+          ++nt;
+          float t, u, v;
+          if (tri_test<false>(r, V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), t, u, v) && t > 0.0f && t < tmax) { occluded = true; cur = CUR_FINISHED; }
+          else if ((tmask & 255u) == 0u) cur = advance<false>(gbase, gmask, st, nullptr, 0u);
         }
       }
       if (cur == CUR_FINISHED) {
@@ -940,6 +857,15 @@ __global__ __launch_bounds__(256) void k_resolve(DevFrame fr, const float4* accu
 // Raster-compat shading (R6–R8): the reference's deferred Blinn-Phong result at the primary hit.
 //   fragment.glsl:24-27 with the flat normal texel (0.5,0.5,1): N = normalize(interpolated normal)
 //   lighting.glsl:25-28: V = normalize(cam − P), L = V;  BlinnPhong.lib.glsl:4-10
+// GBUF16 (PTC_INTEGRATOR_RASTER_GBUFFER16): the lighting pass reads what the reference's G-buffer holds
+// (GBuffer.hpp:13-16): positions and normals as RGBA16F (fp32 → fp16, round to nearest even), albedo as RGBA16 UNORM
+// (clamp to [0,1], round(v·65535)/65535); the normal is NOT re-normalised after the rounding (lighting.glsl:21,28).
+PT_DEV float round_f16(float v) { return (float)(_Float16)v; }                       // v_cvt_f16_f32 (RTE, denormals kept) + v_cvt_f32_f16
+PT_DEV float round_unorm16(float v) {
+  const float c = fmin2(fmax2(v, 0.0f), 1.0f);                                       // NaN → 0 (fmax2(NaN, 0) = 0)
+  return (float)(uint32_t)(c * 65535.0f + 0.5f) / 65535.0f;
+}
+template <bool GBUF16>
 __global__ __launch_bounds__(256) void k_shade_raster(DevScene sc, DevCamera cam, DevFrame fr, DevQueues q, float4* accum) {
   const uint32_t j = blockIdx.x * 256u + threadIdx.x;
   if (j >= fr.n_owned) return;
@@ -951,7 +877,7 @@ __global__ __launch_bounds__(256) void k_shade_raster(DevScene sc, DevCamera cam
     const float hu = H.z, hv = H.w, hw = 1.0f - hu - hv;
     const float4* rec = sc.shade + (size_t)prim * 5;
     const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4];
-    const v3 P = V3(pt_fma(r2.x, hv, pt_fma(r1.x, hu, r0.x * hw)), pt_fma(r2.y, hv, pt_fma(r1.y, hu, r0.y * hw)), pt_fma(r2.z, hv, pt_fma(r1.z, hu, r0.z * hw)));
+    v3 P = V3(pt_fma(r2.x, hv, pt_fma(r1.x, hu, r0.x * hw)), pt_fma(r2.y, hv, pt_fma(r1.y, hu, r0.y * hw)), pt_fma(r2.z, hv, pt_fma(r1.z, hu, r0.z * hw)));
     const v3 ni = V3(pt_fma(r4.y, hv, pt_fma(r3.z, hu, r2.w * hw)), pt_fma(r4.z, hv, pt_fma(r3.w, hu, r3.x * hw)), pt_fma(r4.w, hv, pt_fma(r4.x, hu, r3.y * hw)));
     v3 N = normalize3(ni);
     const int mat = __float_as_int(r0.w);
@@ -960,6 +886,12 @@ __global__ __launch_bounds__(256) void k_shade_raster(DevScene sc, DevCamera cam
     float metallic = M0.w, roughness = M1.w;
     if (__float_as_int(M2.y) >= 0 || __float_as_int(M2.z) >= 0 || __float_as_int(M2.w) >= 0)
       apply_textures(sc, (uint32_t)prim, hu, hv, hw, M2, ni, base, metallic, roughness, N);
+    if (GBUF16) {
+      P = V3(round_f16(P.x), round_f16(P.y), round_f16(P.z));
+      N = V3(round_f16(N.x), round_f16(N.y), round_f16(N.z));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) base[k] = round_unorm16(base[k]);
+    }
     const v3 V = normalize3(V3(cam.pos[0], cam.pos[1], cam.pos[2]) - P);
     const v3 Hh = normalize3(V + V);
     const float ndv = fmax2(dot3(N, V), 0.0f), ndh = fmax2(dot3(N, Hh), 0.0f);
@@ -967,6 +899,18 @@ __global__ __launch_bounds__(256) void k_shade_raster(DevScene sc, DevCamera cam
     o = make_float4(pt_fma(base[0], ndv, spec), pt_fma(base[1], ndv, spec), pt_fma(base[2], ndv, spec), pt_fma(base[3], ndv, spec));
   }
   accum[j] = o;
+}
+
+// RGBA32F → RGBA16F (the reference's HdrImage / lighting-pass target format, PbrRenderSystem.hpp:21, HdrImage.cpp:20):
+// round to nearest even, overflow → inf, half denormals kept.  One pixel (8 bytes out) per thread.
+__global__ __launch_bounds__(256) void k_to_half(const float4* in, uint2* out, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const float4 c = in[i];
+  const _Float16 hx = (_Float16)c.x, hy = (_Float16)c.y, hz = (_Float16)c.z, hw = (_Float16)c.w;
+  const uint32_t bx = __builtin_bit_cast(unsigned short, hx), by = __builtin_bit_cast(unsigned short, hy),
+                 bz = __builtin_bit_cast(unsigned short, hz), bw = __builtin_bit_cast(unsigned short, hw);
+  out[i] = make_uint2(bx | (by << 16), bz | (bw << 16));
 }
 
 // =================================================================================================
@@ -1002,11 +946,30 @@ __global__ __launch_bounds__(256) void k_tonemap(const float4* radiance, uint32_
 
 // =================================================================================================
 // launchers
-static size_t trace_lds_bytes(const LaunchCfg& cfg, const DevScene& sc) {
-  return (size_t)sc.n_nodelets * 48 + (size_t)TRACE_WAVES * cfg.stack_lds * 64 * 8;
+static size_t trace_lds_bytes(const LaunchCfg& cfg, const DevScene& sc, bool closest) {
+  return (size_t)sc.n_nodelets * 80 + (size_t)TRACE_WAVES * cfg.stack_lds * 64 * 8 + (closest ? ORDER_TABLE_BYTES : 0);
 }
 
 int pt_trace_block_threads() { return TRACE_BLOCK; }
+
+size_t pt_trace_lds_bytes(const LaunchCfg& cfg, const DevScene& sc) { return trace_lds_bytes(cfg, sc, true); }
+
+// Resident blocks per CU of the trace kernels with `lds` bytes of dynamic LDS (registers, static LDS and the launch bounds
+// included: the runtime's own occupancy calculation), minimum over the closest-hit and any-hit kernels; <= 0 on error.
+// Dynamic LDS above the default 64 KiB limit is enabled on every variant first.
+int pt_trace_blocks_per_cu(size_t lds) {
+  const void* fns[] = {(const void*)k_trace_closest<false, true>, (const void*)k_trace_closest<false, false>, (const void*)k_trace_closest<true, true>,
+                       (const void*)k_trace_closest<true, false>, (const void*)k_trace_any<true, false>, (const void*)k_trace_any<false, false>,
+                       (const void*)k_trace_any<true, true>, (const void*)k_trace_any<false, true>};
+  int best = 1 << 30;
+  for (const void* f : fns) {
+    if (lds > 64u * 1024u && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f, TRACE_BLOCK, lds) != hipSuccess) return -1;
+    if (nb < best) best = nb;
+  }
+  return best;
+}
 
 void pt_launch_set_counts(hipStream_t s, const DevQueues& q, uint32_t n_rays, uint32_t n_shadow) { hipLaunchKernelGGL(k_set_counts, dim3(1), dim3(64), 0, s, q.cnt, n_rays, n_shadow); }
 void pt_launch_advance(hipStream_t s, const DevQueues& q) { hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, s, q.cnt); }
@@ -1021,7 +984,7 @@ void pt_launch_raygen(hipStream_t s, const DevCamera& cam, const DevFrame& fr, c
 void pt_launch_trace_closest(hipStream_t s, const LaunchCfg& cfg, const DevScene& sc, const DevQueues& q, int qi, bool cull) {
   const bool nodelets = sc.n_nodelets > 0;
   const dim3 grid((unsigned)(cfg.n_cu * cfg.trace_blocks_per_cu));
-  const size_t lds = trace_lds_bytes(cfg, sc);
+  const size_t lds = trace_lds_bytes(cfg, sc, true);
 #define TC(C, N) hipLaunchKernelGGL((k_trace_closest<C, N>), grid, dim3(TRACE_BLOCK), lds, s, sc, q, qi, cfg.stack_lds)
   if (cull) { if (nodelets) TC(true, true); else TC(true, false); }
   else { if (nodelets) TC(false, true); else TC(false, false); }
@@ -1031,7 +994,7 @@ void pt_launch_trace_closest(hipStream_t s, const LaunchCfg& cfg, const DevScene
 void pt_launch_trace_any(hipStream_t s, const LaunchCfg& cfg, const DevScene& sc, const DevQueues& q, uint8_t* debug_out) {
   const bool nodelets = sc.n_nodelets > 0;
   const dim3 grid((unsigned)(cfg.n_cu * cfg.trace_blocks_per_cu));
-  const size_t lds = trace_lds_bytes(cfg, sc);
+  const size_t lds = trace_lds_bytes(cfg, sc, false);
 #define TA(N, D) hipLaunchKernelGGL((k_trace_any<N, D>), grid, dim3(TRACE_BLOCK), lds, s, sc, q, cfg.stack_lds, debug_out)
   if (debug_out) { if (nodelets) TA(true, true); else TA(false, true); }
   else { if (nodelets) TA(true, false); else TA(false, false); }
@@ -1044,8 +1007,12 @@ void pt_launch_shade(hipStream_t s, const LaunchCfg& cfg, const DevScene& sc, co
 void pt_launch_accumulate(hipStream_t s, const DevFrame& fr, const DevQueues& q, float4* accum, uint32_t n_samples) {
   hipLaunchKernelGGL(k_accumulate, dim3((fr.n_owned + 255u) / 256u), dim3(256), 0, s, fr, (const float4*)q.lpath, accum, n_samples);
 }
-void pt_launch_shade_raster(hipStream_t s, const DevScene& sc, const DevCamera& cam, const DevFrame& fr, const DevQueues& q, float4* accum) {
-  hipLaunchKernelGGL(k_shade_raster, dim3((fr.n_owned + 255u) / 256u), dim3(256), 0, s, sc, cam, fr, q, accum);
+void pt_launch_shade_raster(hipStream_t s, const DevScene& sc, const DevCamera& cam, const DevFrame& fr, const DevQueues& q, float4* accum, bool gbuffer16) {
+  if (gbuffer16) hipLaunchKernelGGL(k_shade_raster<true>, dim3((fr.n_owned + 255u) / 256u), dim3(256), 0, s, sc, cam, fr, q, accum);
+  else hipLaunchKernelGGL(k_shade_raster<false>, dim3((fr.n_owned + 255u) / 256u), dim3(256), 0, s, sc, cam, fr, q, accum);
+}
+void pt_launch_to_half(hipStream_t s, const float4* radiance, uint2* out, uint32_t n_pixels) {
+  hipLaunchKernelGGL(k_to_half, dim3((n_pixels + 255u) / 256u), dim3(256), 0, s, radiance, out, n_pixels);
 }
 void pt_launch_resolve(hipStream_t s, const DevFrame& fr, const float4* accum, float4* radiance, float spp, bool raster) {
   hipLaunchKernelGGL(k_resolve, dim3((fr.n_owned + 255u) / 256u), dim3(256), 0, s, fr, accum, radiance, spp, raster ? 1 : 0);

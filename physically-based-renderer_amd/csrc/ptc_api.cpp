@@ -1,13 +1,18 @@
 // ptc_api.cpp — the C-ABI of include/ptc.h over the HIP wavefront path tracer.
 //
-// One context = one HIP device + one stream.  Everything a frame needs is enqueued on that stream
-// without host synchronisation: queue sizes live in device memory and the persistent kernels read
-// them there, so a whole batch (raygen → [trace, shade, shadow, advance] × bounces → accumulate) is
-// a single asynchronous burst.  The host blocks only in ptc_sync / read-backs / ptc_get_stats.
+// One context = one HIP device + `n_lanes` streams ("lanes").  Everything a frame needs is enqueued without host
+// synchronisation: queue sizes live in device memory and the persistent kernels read them there, so a whole batch
+// (raygen → [trace, shade, shadow, advance] × bounces → accumulate) is a single asynchronous burst.  Successive batches
+// of a frame alternate between the lanes, so one batch's launch tails overlap another batch's full-occupancy phases;
+// only the per-pixel accumulation is ordered (sample order), by events.  The host blocks only in ptc_sync / read-backs /
+// ptc_get_stats.
 //
 // There is no CPU path in this library: without a usable HIP device ptc_create fails.
 #include "../../include/ptc.h"
 #include "ptc_internal.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <chrono>
 #include <cstdlib>
@@ -24,14 +29,57 @@ template <class T> struct DevBuf {
   T* p = nullptr; size_t n = 0;
   void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
+
+// One lane: a stream with its own wavefront queues.  cnt/stats are allocated once; the large arrays grow on demand.
+struct Lane {
+  hipStream_t stream = nullptr;
+  DevQueues q{};
+  std::vector<void*> allocs;        // the large queue arrays (sized q.cap)
+  uint2* stack_ovf = nullptr;       // traversal-stack overflow slab (belongs to the committed scene)
+  hipEvent_t acc_done = nullptr;    // "this lane's last accumulate finished"
+};
+
+// ---- RCCL, loaded on first use (a renderer that never reduces does not need librccl at load time) -------------------
+struct Rccl {
+  void* so = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string err;
+};
+Rccl g_rccl;
+bool rccl_load() {
+  if (g_rccl.so) return true;
+  void* so = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!so) so = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!so) so = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!so) { const char* e = dlerror(); g_rccl.err = std::string("librccl.so not loadable: ") + (e ? e : "?"); return false; }
+  bool ok = true;
+  auto sym = [&](const char* name) { void* p = dlsym(so, name); if (!p) { ok = false; g_rccl.err = std::string("librccl.so lacks ") + name; } return p; };
+  g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId");
+  g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");
+  g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))sym("ncclCommInitAll");
+  g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+  g_rccl.Reduce = (decltype(g_rccl.Reduce))sym("ncclReduce");
+  g_rccl.GroupStart = (decltype(g_rccl.GroupStart))sym("ncclGroupStart");
+  g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))sym("ncclGroupEnd");
+  g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+  if (!ok) { dlclose(so); return false; }
+  g_rccl.so = so;
+  return true;
+}
 }  // namespace
 
 struct ptc_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
   std::string err;
   LaunchCfg cfg{};
-  uint32_t nodelet_budget = 85;   // wide nodes staged in LDS: the top four levels (1+4+16+64) of the tree, 48 B each = 4 KB
+  uint32_t nodelet_budget = 73;   // wide nodes staged in LDS: the top three levels (1+8+64) of the tree, 80 B each = 5.7 KB
   size_t max_batch_paths = (size_t)1 << 28;   // paths in flight over all lanes: large batches amortise launch tails (sized for 288 GB of HBM:
                                               // 176 B per path -> 47 GB of queues at 1080p x 64 spp x 2 lanes; 2^27 is 2 % slower, 2^29 1 % faster)
   bool timing = true;
@@ -50,39 +98,55 @@ struct ptc_ctx {
   DevScene dsc{};
   DevCamera cam{};
   std::vector<void*> scene_allocs;
-  // queues (lane 0); further lanes run independent batches on their own streams so that one batch's
-  // launch tails overlap another batch's full-occupancy phases
-  DevQueues q{};
-  std::vector<void*> queue_allocs;
-  struct Lane { hipStream_t stream = nullptr; DevQueues q{}; std::vector<void*> allocs; uint2* stack_ovf = nullptr; hipEvent_t acc_done = nullptr; };
-  std::vector<Lane> extra;          // lanes 1..n_lanes-1
+  // lanes: lane 0 is the context's primary stream (resolve, tonemap, conversions, the reduce)
+  std::vector<Lane> lanes;
   int n_lanes = 2;
-  hipEvent_t acc_done0 = nullptr;   // lane 0's "accumulate finished" event
   uint64_t batches_issued = 0;
   // frame
   bool in_frame = false;
   DevFrame fr{};
   int spp_total = 0, integrator = 0;
-  uint32_t samples_done = 0;
+  uint32_t samples_done = 0;        // samples issued to the device
+  uint32_t pending = 0;             // samples accepted by frame_add_samples and not yet issued (deferred batching)
+  uint32_t per_batch = 1;           // samples of one full batch = max_batch_paths / owned pixels / lanes
   DevBuf<uint32_t> owned;
   DevBuf<float4> accum, radiance;
   DevBuf<uint32_t> ldr;
+  DevBuf<uint2> half;               // RGBA16F copy of the radiance buffer
   int rad_w = 0, rad_h = 0;
+  // multi-GPU
+  ncclComm_t comm = nullptr;
+  int comm_rank = 0, comm_size = 0;
+  bool comm_owned = true;           // false: the communicator belongs to a ptc_group
   // stats
   ptc_stats stats{};
   std::vector<Span> spans;
-  std::vector<hipEvent_t> event_pool;
-  size_t events_used = 0;
+  std::vector<hipEvent_t> free_events;
+  size_t events_created = 0;
+};
+
+struct ptc_group {
+  std::vector<ptc_ctx*> ctx;
+  std::vector<ncclComm_t> comms;
+  std::string err;
 };
 
 namespace {
 
+constexpr size_t kMaxSpans = 1024;   // timing spans (event pairs) kept at most; see run_batch
 int fail(ptc_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
+const char* const kNoDevice = "this context has no device (PTC_DEVICE_NONE): the call needs a gfx950 GPU; there is no CPU path";
 
 #define HIP_TRY(c, expr)                                                                                 \
   do {                                                                                                   \
     hipError_t e_ = (expr);                                                                              \
-    if (e_ != hipSuccess) return fail((c), PTC_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    if (e_ != hipSuccess)                                                                                \
+      return fail((c), e_ == hipErrorOutOfMemory ? PTC_E_NOMEM : PTC_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+#define NCCL_TRY(c, expr)                                                                                \
+  do {                                                                                                   \
+    ncclResult_t r_ = (expr);                                                                            \
+    if (r_ != ncclSuccess) return fail((c), PTC_E_DEVICE, std::string(#expr) + ": " + g_rccl.GetErrorString(r_)); \
   } while (0)
 
 template <class T> int dev_alloc(ptc_ctx* c, std::vector<void*>& owner, T** out, size_t count) {
@@ -102,113 +166,132 @@ template <class T> int dev_upload(ptc_ctx* c, std::vector<void*>& owner, const T
 }
 void free_all(std::vector<void*>& v) { for (void* p : v) (void)hipFree(p); v.clear(); }
 
-int ensure_buf_u32(ptc_ctx* c, DevBuf<uint32_t>& b, size_t n) {
+template <class T> int ensure_buf(ptc_ctx* c, DevBuf<T>& b, size_t n) {
   if (b.n >= n && b.p) return PTC_OK;
   b.release();
-  HIP_TRY(c, hipMalloc((void**)&b.p, (n ? n : 1) * sizeof(uint32_t)));
-  b.n = n;
-  return PTC_OK;
-}
-int ensure_buf_f4(ptc_ctx* c, DevBuf<float4>& b, size_t n) {
-  if (b.n >= n && b.p) return PTC_OK;
-  b.release();
-  HIP_TRY(c, hipMalloc((void**)&b.p, (n ? n : 1) * sizeof(float4)));
+  HIP_TRY(c, hipMalloc((void**)&b.p, (n ? n : 1) * sizeof(T)));
   b.n = n;
   return PTC_OK;
 }
 
-int ensure_queues_in(ptc_ctx* c, DevQueues& dst, std::vector<void*>& allocs, uint32_t cap) {
-  if (dst.cap >= cap && dst.cnt) return PTC_OK;
-  free_all(allocs);
-  DevQueues q{};
-  int rc = 0;
-  for (int k = 0; k < 2; ++k) {
-    rc |= dev_alloc(c, allocs, &q.ray[k].A, cap); rc |= dev_alloc(c, allocs, &q.ray[k].B, cap);
-    rc |= dev_alloc(c, allocs, &q.ray[k].C, cap);
+int sync_all_lanes(ptc_ctx* c) {
+  for (auto& ln : c->lanes) HIP_TRY(c, hipStreamSynchronize(ln.stream));
+  return PTC_OK;
+}
+
+// Every lane gets queues for at least `cap` paths (grow only; all lanes keep the same capacity, so a batch fits whichever
+// lane it is routed to).  Growing waits for the work in flight first: the old arrays may still be in use.
+int ensure_lane_queues(ptc_ctx* c, uint32_t cap) {
+  bool grow = false;
+  for (auto& ln : c->lanes) grow = grow || ln.q.cap < cap;
+  if (!grow) return PTC_OK;
+  { int rs = sync_all_lanes(c); if (rs) return rs; }
+  for (auto& ln : c->lanes) {
+    if (ln.q.cap >= cap) continue;
+    free_all(ln.allocs);
+    ln.q.cap = 0;
+    DevQueues q = ln.q;   // keeps cnt / stats
+    int rc = 0;
+    for (int k = 0; k < 2 && !rc; ++k) {
+      rc = dev_alloc(c, ln.allocs, &q.ray[k].A, cap); if (!rc) rc = dev_alloc(c, ln.allocs, &q.ray[k].B, cap);
+      if (!rc) rc = dev_alloc(c, ln.allocs, &q.ray[k].C, cap);
+    }
+    if (!rc) rc = dev_alloc(c, ln.allocs, &q.shadow.A, cap);
+    if (!rc) rc = dev_alloc(c, ln.allocs, &q.shadow.B, cap);
+    if (!rc) rc = dev_alloc(c, ln.allocs, &q.shadow.C, cap);
+    if (!rc) rc = dev_alloc(c, ln.allocs, &q.hit, cap);
+    if (!rc) rc = dev_alloc(c, ln.allocs, &q.lpath, cap);
+    if (rc) { free_all(ln.allocs); return rc; }
+    q.cap = cap;
+    ln.q = q;
   }
-  rc |= dev_alloc(c, allocs, &q.shadow.A, cap); rc |= dev_alloc(c, allocs, &q.shadow.B, cap);
-  rc |= dev_alloc(c, allocs, &q.shadow.C, cap);
-  rc |= dev_alloc(c, allocs, &q.hit, cap); rc |= dev_alloc(c, allocs, &q.lpath, cap);
-  rc |= dev_alloc(c, allocs, &q.cnt, (size_t)CNT_N);
-  rc |= dev_alloc(c, allocs, &q.stats, (size_t)ST_N);
-  if (rc) { free_all(allocs); dst = DevQueues{}; return rc < 0 ? PTC_E_DEVICE : rc; }
-  HIP_TRY(c, hipMemset(q.cnt, 0, CNT_N * sizeof(uint32_t)));
-  HIP_TRY(c, hipMemset(q.stats, 0, ST_N * sizeof(unsigned long long)));
-  q.cap = cap;
-  dst = q;
   return PTC_OK;
 }
-int ensure_queues(ptc_ctx* c, uint32_t cap) { return ensure_queues_in(c, c->q, c->queue_allocs, cap); }
 
-// lane accessors: lane 0 is the context's primary stream / queues
-hipStream_t lane_stream(ptc_ctx* c, int l) { return l == 0 ? c->stream : c->extra[(size_t)l - 1].stream; }
-DevQueues& lane_q(ptc_ctx* c, int l) { return l == 0 ? c->q : c->extra[(size_t)l - 1].q; }
-hipEvent_t lane_acc_event(ptc_ctx* c, int l) { return l == 0 ? c->acc_done0 : c->extra[(size_t)l - 1].acc_done; }
-DevScene lane_scene(ptc_ctx* c, int l) { DevScene d = c->dsc; if (l > 0) d.stack_ovf = c->extra[(size_t)l - 1].stack_ovf; return d; }
-
+// ---- timing spans: event pairs around the kernels of a batch; events are recycled as soon as they have completed, so a
+// progressive loop that never asks for statistics does not grow the pool -----------------------------------------------
 hipEvent_t next_event(ptc_ctx* c) {
-  if (c->events_used == c->event_pool.size()) {
-    hipEvent_t e;
-    if (hipEventCreate(&e) != hipSuccess) return nullptr;
-    c->event_pool.push_back(e);
+  if (!c->free_events.empty()) { hipEvent_t e = c->free_events.back(); c->free_events.pop_back(); return e; }
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  c->events_created++;
+  return e;
+}
+void collect_times(ptc_ctx* c, bool all_done) {
+  size_t keep = 0;
+  for (size_t i = 0; i < c->spans.size(); ++i) {
+    const Span s = c->spans[i];
+    if (!all_done && hipEventQuery(s.b) != hipSuccess) { c->spans[keep++] = s; continue; }
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+      const double sec = 1e-3 * (double)ms;
+      if (s.kind == 0) c->stats.seconds_trace_closest += sec;
+      else if (s.kind == 1) c->stats.seconds_trace_any += sec;
+      else if (s.kind == 2) c->stats.seconds_shade += sec;
+      else c->stats.seconds_render += sec;
+    }
+    c->free_events.push_back(s.a); c->free_events.push_back(s.b);
   }
-  return c->event_pool[c->events_used++];
+  c->spans.resize(keep);
 }
 struct ScopedSpan {   // records a start/stop event pair around launches on one of the context's streams
   ptc_ctx* c; hipStream_t st; Span s{}; bool on;
   ScopedSpan(ptc_ctx* c_, hipStream_t st_, int kind) : c(c_), st(st_), on(c_->timing) {
     if (!on) return;
     s.kind = kind; s.a = next_event(c); s.b = next_event(c);
-    if (!s.a || !s.b) { on = false; return; }
+    if (!s.a || !s.b) { if (s.a) c->free_events.push_back(s.a); on = false; return; }
     (void)hipEventRecord(s.a, st);
   }
   ~ScopedSpan() { if (on) { (void)hipEventRecord(s.b, st); c->spans.push_back(s); } }
 };
 
 int configure_launch(ptc_ctx* c) {
-  // Traversal stack: a 4-wide node defers up to 3 children per level, so a ray needs at most
-  // 3·(depth+1) entries.  `stack_lds` of them live in LDS (8 B each, 512 B per level and wave), the rest in
-  // a global overflow slab.  LDS per block = nodelets·48 B + waves·stack_lds·512 B.
-  const int need = 3 * ((int)c->built.max_depth + 1);
-  int l = 8;    // stack entries per lane kept in LDS (2 KB per entry and block): with 85 nodelets 8 entries leave room for 7 blocks (28 waves) per CU, +3.5 % over 10 entries / 6 blocks
+  // Traversal stack: at most one group of pending children per tree level, so a ray needs at most depth+1 entries.
+  // `stack_lds` of them live in LDS (8 B each, 512 B per level and wave), the rest in a global overflow slab.
+  // LDS per block = nodelets·80 B + waves·stack_lds·512 B + the 2-KiB slot-order table.
+  const int need = (int)c->built.max_depth + 2;
+  int l = 6;    // stack entries per lane kept in LDS: with 73 nodelets, 6 entries leave room for 7 blocks (28 waves) per CU
   if (const char* e = std::getenv("PTC_STACK_LDS")) { int v = std::atoi(e); if (v >= 1 && v <= 64) l = v; }
   if (l > need) l = need;
   c->cfg.stack_lds = l;
-  const int waves = pt_trace_block_threads() / 64;
-  const size_t lds = (size_t)c->built.n_nodelets * 48 + (size_t)waves * l * 512;
-  int per_cu = (int)((160u * 1024u) / lds);
-  const int max_per_cu = 32 / waves;                             // 32 waves per CU
-  if (per_cu > max_per_cu) per_cu = max_per_cu;
-  if (per_cu < 1) return fail(c, PTC_E_ARG, "configure_launch: nodelets + stack exceed the 160 KiB of LDS");
+  const size_t lds = pt_trace_lds_bytes(c->cfg, c->dsc);
+  if (lds > 160u * 1024u) return fail(c, PTC_E_ARG, "configure_launch: nodelets + stack exceed the 160 KiB of LDS");
+  int per_cu = pt_trace_blocks_per_cu(lds);     // registers, static LDS and launch bounds included
+  if (per_cu < 1) return fail(c, PTC_E_DEVICE, "configure_launch: the trace kernels do not fit a CU with this LDS size");
   if (const char* e = std::getenv("PTC_TRACE_BLOCKS_PER_CU")) { int v = std::atoi(e); if (v >= 1 && v <= per_cu) per_cu = v; }
   c->cfg.trace_blocks_per_cu = per_cu;
   const uint32_t ovf = (uint32_t)(need - l > 0 ? need - l : 1);
-  const size_t total_waves = (size_t)c->cfg.n_cu * 32;           // upper bound on resident trace waves
-  uint2* p = nullptr;
-  int rc = dev_alloc(c, c->scene_allocs, &p, total_waves * ovf * 64);
-  if (rc) return rc;
-  c->dsc.stack_ovf = p; c->dsc.ovf_depth = ovf;
-  for (auto& ln : c->extra) {                                    // concurrent kernels must not share a slab
+  const size_t total_waves = (size_t)c->cfg.n_cu * (size_t)per_cu * (size_t)(pt_trace_block_threads() / 64);   // the persistent grid
+  c->dsc.ovf_depth = ovf;
+  for (auto& ln : c->lanes) {                                    // concurrent kernels must not share a slab
     uint2* pl = nullptr;
-    if ((rc = dev_alloc(c, c->scene_allocs, &pl, total_waves * ovf * 64))) return rc;
+    int rc = dev_alloc(c, c->scene_allocs, &pl, total_waves * ovf * 64);
+    if (rc) return rc;
     ln.stack_ovf = pl;
   }
   return PTC_OK;
 }
 
-// One wavefront batch of n samples per owned pixel on lane `l`, fully asynchronous.  Batches on different
-// lanes overlap; only the per-pixel accumulation is ordered (sample order), through the acc_done events.
+DevScene lane_scene(ptc_ctx* c, int l) { DevScene d = c->dsc; d.stack_ovf = c->lanes[(size_t)l].stack_ovf; return d; }
+bool is_raster(int integrator) { return integrator == PTC_INTEGRATOR_RASTER_COMPAT || integrator == PTC_INTEGRATOR_RASTER_GBUFFER16; }
+
+// One wavefront batch of n samples per owned pixel on lane `l`, fully asynchronous.
 int run_batch(ptc_ctx* c, int l, uint32_t first_sample, uint32_t n_samples) {
   const uint32_t n_paths = c->fr.n_owned * n_samples;
-  hipStream_t st = lane_stream(c, l);
-  const DevQueues& q = lane_q(c, l);
+  Lane& ln = c->lanes[(size_t)l];
+  hipStream_t st = ln.stream;
+  const DevQueues& q = ln.q;
   const DevScene sc = lane_scene(c, l);
+  if (c->spans.size() > kMaxSpans) {      // bounded event pool: harvest what has completed; if the host runs far ahead of
+    collect_times(c, false);              // the device, wait for the oldest batch (back-pressure) instead of growing
+    if (c->spans.size() > kMaxSpans) { (void)hipEventSynchronize(c->spans[c->spans.size() - kMaxSpans].b); collect_times(c, false); }
+  }
   ScopedSpan whole(c, st, 3);
   pt_launch_set_counts(st, q, n_paths, 0);
-  if (c->integrator == PTC_INTEGRATOR_RASTER_COMPAT) {
+  if (is_raster(c->integrator)) {
     pt_launch_raygen(st, c->cam, c->fr, q, 0, 1, true);
     { ScopedSpan t(c, st, 0); pt_launch_trace_closest(st, c->cfg, sc, q, 0, true); c->stats.launches_trace_closest++; }
-    pt_launch_shade_raster(st, sc, c->cam, c->fr, q, c->accum.p);
+    pt_launch_shade_raster(st, sc, c->cam, c->fr, q, c->accum.p, c->integrator == PTC_INTEGRATOR_RASTER_GBUFFER16);
   } else {
     pt_launch_raygen(st, c->cam, c->fr, q, first_sample, n_samples, false);
     for (int b = 0; b <= c->fr.max_bounces; ++b) {
@@ -222,34 +305,96 @@ int run_batch(ptc_ctx* c, int l, uint32_t first_sample, uint32_t n_samples) {
     // sample-order accumulation: wait for the previous batch's accumulate (it ran on the previous lane)
     if (c->n_lanes > 1 && c->batches_issued > 0) {
       const int prev = (int)((c->batches_issued - 1) % (uint64_t)c->n_lanes);
-      if (prev != l) HIP_TRY(c, hipStreamWaitEvent(st, lane_acc_event(c, prev), 0));
+      if (prev != l) HIP_TRY(c, hipStreamWaitEvent(st, c->lanes[(size_t)prev].acc_done, 0));
     }
     pt_launch_accumulate(st, c->fr, q, c->accum.p, n_samples);
-    if (c->n_lanes > 1) HIP_TRY(c, hipEventRecord(lane_acc_event(c, l), st));
+    if (c->n_lanes > 1) HIP_TRY(c, hipEventRecord(ln.acc_done, st));
   }
   c->batches_issued++;
   HIP_TRY(c, hipGetLastError());
   return PTC_OK;
 }
 
-int sync_all_lanes(ptc_ctx* c) {
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  for (auto& ln : c->extra) HIP_TRY(c, hipStreamSynchronize(ln.stream));
+// Issue `k` samples (k <= per_batch) as one batch on the next lane.
+int issue(ptc_ctx* c, uint32_t k) {
+  if (is_raster(c->integrator)) {
+    if (c->samples_done == 0) {
+      int rc = ensure_lane_queues(c, c->fr.n_owned);
+      if (rc) return rc;
+      if ((rc = run_batch(c, 0, 0, 1))) return rc;
+      c->stats.paths = c->fr.n_owned;
+    }
+    c->samples_done += k;
+    return PTC_OK;
+  }
+  const uint64_t cap = (uint64_t)c->fr.n_owned * k;
+  int rc = ensure_lane_queues(c, (uint32_t)cap);
+  if (rc) return rc;
+  if ((rc = run_batch(c, (int)(c->batches_issued % (uint64_t)c->n_lanes), c->samples_done, k))) return rc;
+  c->samples_done += k;
+  c->stats.paths += cap;
+  return PTC_OK;
+}
+// Issue everything frame_add_samples has accepted so far.
+int flush(ptc_ctx* c) {
+  if (!c->in_frame) return PTC_OK;
+  while (c->pending) {
+    const uint32_t k = c->pending < c->per_batch ? c->pending : c->per_batch;
+    c->pending -= k;
+    if (c->fr.n_owned == 0) { c->samples_done += k; continue; }
+    int rc = issue(c, k);
+    if (rc) return rc;
+  }
   return PTC_OK;
 }
 
-void collect_times(ptc_ctx* c) {
-  for (const Span& s : c->spans) {
-    float ms = 0.0f;
-    if (hipEventElapsedTime(&ms, s.a, s.b) != hipSuccess) continue;
-    const double sec = 1e-3 * (double)ms;
-    if (s.kind == 0) c->stats.seconds_trace_closest += sec;
-    else if (s.kind == 1) c->stats.seconds_trace_any += sec;
-    else if (s.kind == 2) c->stats.seconds_shade += sec;
-    else c->stats.seconds_render += sec;
+// stream 0 waits for the accumulates of all lanes (the last batches may have run elsewhere)
+int join_lanes_on_stream0(ptc_ctx* c) {
+  if (c->n_lanes > 1 && !is_raster(c->integrator))
+    for (int l = 1; l < c->n_lanes; ++l)
+      if ((uint64_t)l < c->batches_issued) HIP_TRY(c, hipStreamWaitEvent(c->lanes[0].stream, c->lanes[(size_t)l].acc_done, 0));
+  return PTC_OK;
+}
+
+int need_device(ptc_ctx* c) {
+  if (!c) return PTC_E_ARG;
+  if (c->device < 0) return fail(c, PTC_E_DEVICE, kNoDevice);
+  HIP_TRY(c, hipSetDevice(c->device));
+  return PTC_OK;
+}
+
+int sum_lane_stats(ptc_ctx* c, unsigned long long st[ST_N]) {
+  for (int i = 0; i < ST_N; ++i) st[i] = 0;
+  for (auto& ln : c->lanes) {
+    if (!ln.q.stats) continue;
+    unsigned long long one[ST_N];
+    HIP_TRY(c, hipMemcpy(one, ln.q.stats, sizeof one, hipMemcpyDeviceToHost));
+    for (int i = 0; i < ST_N; ++i) st[i] += one[i];
   }
-  c->spans.clear();
-  c->events_used = 0;
+  return PTC_OK;
+}
+
+// RGBA16F view of the radiance buffer, converted on stream 0 (after everything queued there: resolve, reduce, write).
+int convert_half(ptc_ctx* c) {
+  if (!c->radiance.p || c->rad_w == 0) return fail(c, PTC_E_STATE, "radiance_rgba16f: nothing rendered");
+  const size_t n = (size_t)c->rad_w * c->rad_h;
+  int rc = ensure_buf(c, c->half, n);
+  if (rc) return rc;
+  pt_launch_to_half(c->lanes[0].stream, c->radiance.p, c->half.p, (uint32_t)n);
+  HIP_TRY(c, hipGetLastError());
+  return PTC_OK;
+}
+
+int debug_prepare(ptc_ctx* c, uint32_t n, const char* who) {
+  { int rd = need_device(c); if (rd) return rd; }
+  if (!c->committed) return fail(c, PTC_E_STATE, std::string(who) + ": scene not committed");
+  { int rf = flush(c); if (rf) return rf; }
+  { int rs = sync_all_lanes(c); if (rs) return rs; }
+  c->in_frame = false; c->pending = 0;
+  int rc = ensure_lane_queues(c, n);
+  if (rc) return rc;
+  for (auto& ln : c->lanes) HIP_TRY(c, hipMemset(ln.q.stats, 0, ST_N * sizeof(unsigned long long)));
+  return PTC_OK;
 }
 
 }  // namespace
@@ -276,19 +421,21 @@ ptc_ctx* ptc_create(int device_id) {
   if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) { g_create_error = std::string("ptc_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only"; return nullptr; }
   ptc_ctx* c = new ptc_ctx();
   c->device = device_id;
-  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { g_create_error = std::string("ptc_create: ") + hipGetErrorString(e); delete c; return nullptr; }
   c->cfg.n_cu = prop.multiProcessorCount;
   c->cfg.trace_blocks_per_cu = 4;
-  c->cfg.stack_lds = 12;
+  c->cfg.stack_lds = 6;
   if (const char* s = std::getenv("PTC_NODELETS")) c->nodelet_budget = (uint32_t)std::strtoul(s, nullptr, 10);
   if (const char* s = std::getenv("PTC_BATCH_PATHS")) { size_t v = std::strtoull(s, nullptr, 10); if (v >= 1024) c->max_batch_paths = v; }
   if (const char* s = std::getenv("PTC_TIMING")) c->timing = std::atoi(s) != 0;
   if (const char* s = std::getenv("PTC_LANES")) { int v = std::atoi(s); if (v >= 1 && v <= 8) c->n_lanes = v; }
-  bool ok = hipEventCreateWithFlags(&c->acc_done0, hipEventDisableTiming) == hipSuccess;
-  c->extra.resize((size_t)c->n_lanes - 1);
-  for (auto& ln : c->extra)
+  c->lanes.resize((size_t)c->n_lanes);
+  bool ok = true;
+  for (auto& ln : c->lanes) {
     ok = ok && hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ln.acc_done, hipEventDisableTiming) == hipSuccess;
-  if (!ok) { g_create_error = "ptc_create: could not create the lane streams / events"; ptc_destroy(c); return nullptr; }
+    ok = ok && hipMalloc((void**)&ln.q.cnt, CNT_N * sizeof(uint32_t)) == hipSuccess && hipMalloc((void**)&ln.q.stats, ST_N * sizeof(unsigned long long)) == hipSuccess;
+    ok = ok && hipMemset(ln.q.cnt, 0, CNT_N * sizeof(uint32_t)) == hipSuccess && hipMemset(ln.q.stats, 0, ST_N * sizeof(unsigned long long)) == hipSuccess;
+  }
+  if (!ok) { g_create_error = "ptc_create: could not create the lane streams / events / counters"; ptc_destroy(c); return nullptr; }
   return c;
 }
 
@@ -296,17 +443,19 @@ void ptc_destroy(ptc_ctx* c) {
   if (!c) return;
   if (c->device < 0) { delete c; return; }
   (void)hipSetDevice(c->device);
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (auto& ln : c->extra) {
-    if (ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); }
+  for (auto& ln : c->lanes) if (ln.stream) (void)hipStreamSynchronize(ln.stream);
+  if (c->comm && c->comm_owned && g_rccl.so) (void)g_rccl.CommDestroy(c->comm);
+  for (const Span& s : c->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+  for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
+  for (auto& ln : c->lanes) {
     if (ln.acc_done) (void)hipEventDestroy(ln.acc_done);
     free_all(ln.allocs);
+    if (ln.q.cnt) (void)hipFree(ln.q.cnt);
+    if (ln.q.stats) (void)hipFree(ln.q.stats);
+    if (ln.stream) (void)hipStreamDestroy(ln.stream);
   }
-  if (c->acc_done0) (void)hipEventDestroy(c->acc_done0);
-  free_all(c->scene_allocs); free_all(c->queue_allocs);
-  c->owned.release(); c->accum.release(); c->radiance.release(); c->ldr.release();
-  for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  free_all(c->scene_allocs);
+  c->owned.release(); c->accum.release(); c->radiance.release(); c->ldr.release(); c->half.release();
   delete c;
 }
 
@@ -319,8 +468,9 @@ int ptc_scene_begin(ptc_ctx* c) {
     { int rs = sync_all_lanes(c); if (rs) return rs; }
   }
   c->mats.clear(); c->meshes.clear(); c->insts.clear(); c->texs.clear(); c->env = HostEnv{}; c->tex_linear = 0;
-  c->have_cam = false; c->committed = false; c->in_frame = false;
+  c->have_cam = false; c->committed = false; c->in_frame = false; c->pending = 0;
   free_all(c->scene_allocs);
+  for (auto& ln : c->lanes) ln.stack_ovf = nullptr;
   return PTC_OK;
 }
 
@@ -410,45 +560,48 @@ int ptc_set_env_latlong_rgb32f(ptc_ctx* c, const float* rgb, int w, int h) {
 int ptc_scene_commit(ptc_ctx* c) {
   if (!c) return PTC_E_ARG;
   if (!c->have_cam) return fail(c, PTC_E_STATE, "scene_commit: no camera");
-  if (c->device >= 0) HIP_TRY(c, hipSetDevice(c->device));
+  if (c->device >= 0) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    { int rs = sync_all_lanes(c); if (rs) return rs; }
+  }
   const auto t0 = std::chrono::steady_clock::now();
   const std::string e = ptc_build_scene(c->mats, c->meshes, c->insts, c->texs, c->env, c->nodelet_budget, c->built);
   if (!e.empty()) return fail(c, PTC_E_STATE, e);
   ptc_make_camera(c->cam_pos, c->cam_target, c->cam_fov, c->cam_aspect, c->cam);
+  c->in_frame = false; c->pending = 0;
   if (c->device < 0) {   // description-only context: nothing to upload
-    c->committed = true; c->in_frame = false;
+    c->committed = true;
     std::memset(&c->stats, 0, sizeof c->stats);
     c->stats.seconds_commit = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     c->stats.n_triangles = c->built.n_tris; c->stats.n_bvh_nodes = c->built.n_nodes; c->stats.n_emitters = c->built.n_lights;
     c->stats.bvh_max_depth = c->built.max_depth;
     return PTC_OK;
   }
+  c->committed = false;
   free_all(c->scene_allocs);
+  for (auto& ln : c->lanes) ln.stack_ovf = nullptr;
   const HostBuilt& B = c->built;
   DevScene d{};
   int rc = 0;
   {
     const float* p = nullptr;
-    rc |= dev_upload(c, c->scene_allocs, &p, B.nodes); d.nodes = (const float4*)p;
-    rc |= dev_upload(c, c->scene_allocs, &p, B.tris); d.tris = (const float4*)p;
-    rc |= dev_upload(c, c->scene_allocs, &p, B.mats); d.mats = (const float4*)p;
-    rc |= dev_upload(c, c->scene_allocs, &p, B.lights); d.lights = (const float4*)p;
-    rc |= dev_upload(c, c->scene_allocs, &d.cdf, B.cdf);
-    rc |= dev_upload(c, c->scene_allocs, &p, B.shade); d.shade = (const float4*)p;
-    rc |= dev_upload(c, c->scene_allocs, &p, B.shade_tex); d.shade_tex = (const float4*)p;
-    rc |= dev_upload(c, c->scene_allocs, &d.texels, B.texels);
-    { const int32_t* ti = nullptr; rc |= dev_upload(c, c->scene_allocs, &ti, B.tex_info); d.tex_info = (const int4*)ti; }
-    rc |= dev_upload(c, c->scene_allocs, &p, B.env); d.env = (const float4*)p;
-    rc |= dev_upload(c, c->scene_allocs, &d.env_marg, B.env_marg);
-    rc |= dev_upload(c, c->scene_allocs, &d.env_cond, B.env_cond);
+    auto up = [&](const std::vector<float>& v, const float4** out) { if (!rc) { rc = dev_upload(c, c->scene_allocs, &p, v); *out = (const float4*)p; } };
+    up(B.nodes, &d.nodes); up(B.tris, &d.tris); up(B.mats, &d.mats); up(B.lights, &d.lights);
+    if (!rc) rc = dev_upload(c, c->scene_allocs, &d.cdf, B.cdf);
+    up(B.shade, &d.shade); up(B.shade_tex, &d.shade_tex);
+    if (!rc) rc = dev_upload(c, c->scene_allocs, &d.texels, B.texels);
+    if (!rc) { const int32_t* ti = nullptr; rc = dev_upload(c, c->scene_allocs, &ti, B.tex_info); d.tex_info = (const int4*)ti; }
+    up(B.env, &d.env);
+    if (!rc) rc = dev_upload(c, c->scene_allocs, &d.env_marg, B.env_marg);
+    if (!rc) rc = dev_upload(c, c->scene_allocs, &d.env_cond, B.env_cond);
   }
-  if (rc) { free_all(c->scene_allocs); return PTC_E_DEVICE; }
+  if (rc) { free_all(c->scene_allocs); return rc; }
   d.env_w = B.env_w; d.env_h = B.env_h; d.env_ok = B.env_ok;
   d.tex_linear = c->tex_linear;
   d.n_lights = B.n_lights; d.n_mats = (uint32_t)c->mats.size(); d.n_nodelets = B.n_nodelets; d.ray_eps = B.ray_eps;
   c->dsc = d;
   { int rc2 = configure_launch(c); if (rc2) { free_all(c->scene_allocs); return rc2; } }
-  c->committed = true; c->in_frame = false;
+  c->committed = true;
   std::memset(&c->stats, 0, sizeof c->stats);
   c->stats.seconds_commit = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   c->stats.n_triangles = B.n_tris; c->stats.n_bvh_nodes = B.n_nodes; c->stats.n_emitters = B.n_lights; c->stats.bvh_max_depth = B.max_depth;
@@ -456,94 +609,84 @@ int ptc_scene_commit(ptc_ctx* c) {
 }
 
 int ptc_frame_begin(ptc_ctx* c, int w, int h, int spp_total, uint64_t seed, int max_bounces, int integrator, int tile_rank, int tile_count) {
-  if (!c) return PTC_E_ARG;
-  if (c->device < 0) return fail(c, PTC_E_DEVICE, "this context has no device (PTC_DEVICE_NONE): the call needs a gfx950 GPU; there is no CPU path");
+  { int rd = need_device(c); if (rd) return rd; }
+  c->in_frame = false; c->pending = 0;      // whatever happens below, the previous frame is over
   if (!c->committed) return fail(c, PTC_E_STATE, "frame_begin: scene not committed");
   if (w <= 0 || h <= 0 || spp_total <= 0 || max_bounces < 0 || (uint64_t)w * (uint64_t)h > 0x7fffffffull) return fail(c, PTC_E_ARG, "frame_begin: bad size");
-  if (integrator != PTC_INTEGRATOR_PATH && integrator != PTC_INTEGRATOR_RASTER_COMPAT) return fail(c, PTC_E_ARG, "frame_begin: unknown integrator");
+  if (integrator != PTC_INTEGRATOR_PATH && !is_raster(integrator)) return fail(c, PTC_E_ARG, "frame_begin: unknown integrator");
   if (tile_count < 1 || tile_rank < 0 || tile_rank >= tile_count) return fail(c, PTC_E_ARG, "frame_begin: bad tile rank/count");
-  HIP_TRY(c, hipSetDevice(c->device));
   { int rs = sync_all_lanes(c); if (rs) return rs; }
   std::vector<uint32_t> owned;
   ptc_owned_pixels(w, h, tile_rank, tile_count, owned);
   int rc;
-  if ((rc = ensure_buf_u32(c, c->owned, owned.size()))) return rc;
+  if ((rc = ensure_buf(c, c->owned, owned.size()))) return rc;
   if (!owned.empty()) HIP_TRY(c, hipMemcpy(c->owned.p, owned.data(), owned.size() * 4, hipMemcpyHostToDevice));
-  if ((rc = ensure_buf_f4(c, c->accum, owned.size()))) return rc;
-  if ((rc = ensure_buf_f4(c, c->radiance, (size_t)w * h))) return rc;
-  HIP_TRY(c, hipMemsetAsync(c->accum.p, 0, (owned.size() ? owned.size() : 1) * sizeof(float4), c->stream));
-  HIP_TRY(c, hipMemsetAsync(c->radiance.p, 0, (size_t)w * h * sizeof(float4), c->stream));
+  if ((rc = ensure_buf(c, c->accum, owned.size()))) return rc;
+  if ((rc = ensure_buf(c, c->radiance, (size_t)w * h))) return rc;
+  hipStream_t s0 = c->lanes[0].stream;
+  HIP_TRY(c, hipMemsetAsync(c->accum.p, 0, (owned.size() ? owned.size() : 1) * sizeof(float4), s0));
+  HIP_TRY(c, hipMemsetAsync(c->radiance.p, 0, (size_t)w * h * sizeof(float4), s0));
   c->rad_w = w; c->rad_h = h;
   c->fr.w = w; c->fr.h = h; c->fr.max_bounces = max_bounces; c->fr.n_owned = (uint32_t)owned.size(); c->fr.owned = c->owned.p;
   {  // seed_hash = pcg(seed_lo + pcg(seed_hi)), same hash as pt_device.h
     auto pcg = [](uint32_t v) { uint32_t s = v * 747796405u + 2891336453u; uint32_t x = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u; return (x >> 22) ^ x; };
     c->fr.seed_hash = pcg((uint32_t)seed + pcg((uint32_t)(seed >> 32)));
   }
-  c->spp_total = integrator == PTC_INTEGRATOR_RASTER_COMPAT ? 1 : spp_total;
+  c->spp_total = is_raster(integrator) ? 1 : spp_total;
   c->integrator = integrator; c->samples_done = 0;
-  // queue capacity per lane: as many samples per batch as fit max_batch_paths split over the lanes
+  // samples of one full batch: as many as fit max_batch_paths split over the lanes.  The queues themselves are sized by the
+  // batches actually issued (frame_add_samples), not by spp_total: a progressive loop adding one sample at a time needs
+  // queues for one sample per pixel only.
   size_t per = owned.empty() ? 1 : c->max_batch_paths / owned.size() / (size_t)c->n_lanes;
   if (per < 1) per = 1;
-  if (per > (size_t)c->spp_total) per = (size_t)c->spp_total;
-  const size_t cap = (owned.empty() ? 1 : owned.size()) * per;
-  if (cap > 0xfffffff0ull) return fail(c, PTC_E_ARG, "frame_begin: batch too large");
-  if ((rc = ensure_queues(c, (uint32_t)cap))) return rc;
-  for (auto& ln : c->extra) if ((rc = ensure_queues_in(c, ln.q, ln.allocs, (uint32_t)cap))) return rc;
-  for (int l = 0; l < c->n_lanes; ++l) HIP_TRY(c, hipMemsetAsync(lane_q(c, l).stats, 0, ST_N * sizeof(unsigned long long), lane_stream(c, l)));
+  if (per > 0x7fffffffu) per = 0x7fffffffu;
+  if (!owned.empty() && (uint64_t)owned.size() * per > 0xfffffff0ull) per = 0xfffffff0ull / owned.size();
+  c->per_batch = (uint32_t)per;
+  for (auto& ln : c->lanes) HIP_TRY(c, hipMemsetAsync(ln.q.stats, 0, ST_N * sizeof(unsigned long long), ln.stream));
   { int rs = sync_all_lanes(c); if (rs) return rs; }     // accum/radiance/statistics are cleared before any lane starts
   c->batches_issued = 0;
+  collect_times(c, true);      // all lanes are idle: every span is complete; the previous frame's times are dropped below
   ptc_stats keep = c->stats;
   std::memset(&c->stats, 0, sizeof c->stats);
   c->stats.seconds_commit = keep.seconds_commit; c->stats.n_triangles = keep.n_triangles; c->stats.n_bvh_nodes = keep.n_bvh_nodes;
   c->stats.n_emitters = keep.n_emitters; c->stats.bvh_max_depth = keep.bvh_max_depth;
-  c->spans.clear(); c->events_used = 0;
   c->in_frame = true;
   return PTC_OK;
 }
 
 int ptc_frame_add_samples(ptc_ctx* c, int n_samples) {
-  if (!c) return PTC_E_ARG;
-  if (c->device < 0) return fail(c, PTC_E_DEVICE, "this context has no device (PTC_DEVICE_NONE): the call needs a gfx950 GPU; there is no CPU path");
+  { int rd = need_device(c); if (rd) return rd; }
   if (!c->in_frame) return fail(c, PTC_E_STATE, "frame_add_samples: no frame");
   if (n_samples <= 0) return fail(c, PTC_E_ARG, "frame_add_samples: n_samples <= 0");
-  HIP_TRY(c, hipSetDevice(c->device));
-  if (c->fr.n_owned == 0) { c->samples_done += (uint32_t)n_samples; return PTC_OK; }
-  if (c->integrator == PTC_INTEGRATOR_RASTER_COMPAT) {
-    if (c->samples_done == 0) { int rc = run_batch(c, 0, 0, 1); if (rc) return rc; }
-    c->samples_done += (uint32_t)n_samples;
-    c->stats.paths = c->fr.n_owned;
-    return PTC_OK;
-  }
-  uint32_t left = (uint32_t)n_samples;
-  const uint32_t per = c->q.cap / c->fr.n_owned;
-  while (left) {
-    const uint32_t k = left < per ? left : per;
-    int rc = run_batch(c, (int)(c->batches_issued % (uint64_t)c->n_lanes), c->samples_done, k);
+  if (!is_raster(c->integrator) && (uint64_t)c->samples_done + c->pending + (uint64_t)n_samples > (uint64_t)c->spp_total)
+    return fail(c, PTC_E_ARG, "frame_add_samples: more samples than the spp_total given to frame_begin");
+  c->pending += (uint32_t)n_samples;
+  // full batches go out at once; a remainder waits for more samples (or for resolve / sync / a read-back), so that many
+  // small calls still produce full-width launches
+  while (c->pending >= c->per_batch) {
+    c->pending -= c->per_batch;
+    if (c->fr.n_owned == 0) { c->samples_done += c->per_batch; continue; }
+    int rc = issue(c, c->per_batch);
     if (rc) return rc;
-    c->samples_done += k; left -= k;
-    c->stats.paths += (uint64_t)c->fr.n_owned * k;
   }
   return PTC_OK;
 }
 
 int ptc_frame_resolve(ptc_ctx* c) {
-  if (!c) return PTC_E_ARG;
-  if (c->device < 0) return fail(c, PTC_E_DEVICE, "this context has no device (PTC_DEVICE_NONE): the call needs a gfx950 GPU; there is no CPU path");
+  { int rd = need_device(c); if (rd) return rd; }
   if (!c->in_frame) return fail(c, PTC_E_STATE, "frame_resolve: no frame");
-  HIP_TRY(c, hipSetDevice(c->device));
-  // the last accumulate may have run on another lane: stream 0 waits for every lane's accumulate event
-  if (c->n_lanes > 1 && c->integrator == PTC_INTEGRATOR_PATH && c->batches_issued > 0)
-    for (int l = 1; l < c->n_lanes && (uint64_t)l < c->batches_issued + 1; ++l)
-      if ((uint64_t)l < c->batches_issued) HIP_TRY(c, hipStreamWaitEvent(c->stream, lane_acc_event(c, l), 0));
-  if (c->fr.n_owned) pt_launch_resolve(c->stream, c->fr, c->accum.p, c->radiance.p, (float)c->spp_total, c->integrator == PTC_INTEGRATOR_RASTER_COMPAT);
+  { int rf = flush(c); if (rf) return rf; }
+  { int rj = join_lanes_on_stream0(c); if (rj) return rj; }
+  // divisor: the samples accumulated so far, so a progressive viewer sees a correctly exposed image after every call
+  if (c->fr.n_owned && c->samples_done)
+    pt_launch_resolve(c->lanes[0].stream, c->fr, c->accum.p, c->radiance.p, (float)c->samples_done, is_raster(c->integrator));
   HIP_TRY(c, hipGetLastError());
   return PTC_OK;
 }
 
 int ptc_sync(ptc_ctx* c) {
-  if (!c) return PTC_E_ARG;
-  if (c->device < 0) return fail(c, PTC_E_DEVICE, "this context has no device (PTC_DEVICE_NONE): the call needs a gfx950 GPU; there is no CPU path");
-  HIP_TRY(c, hipSetDevice(c->device));
+  { int rd = need_device(c); if (rd) return rd; }
+  { int rf = flush(c); if (rf) return rf; }
   return sync_all_lanes(c);
 }
 
@@ -556,11 +699,9 @@ int ptc_render(ptc_ctx* c, int w, int h, int spp, uint64_t seed, int max_bounces
 }
 
 int ptc_read_radiance_rgba32f(ptc_ctx* c, float* out) {
-  if (!c) return PTC_E_ARG;
-  if (c->device < 0) return fail(c, PTC_E_DEVICE, "this context has no device (PTC_DEVICE_NONE): the call needs a gfx950 GPU; there is no CPU path");
+  { int rd = need_device(c); if (rd) return rd; }
   if (!out) return fail(c, PTC_E_ARG, "read_radiance: null pointer");
   if (!c->radiance.p || c->rad_w == 0) return fail(c, PTC_E_STATE, "read_radiance: nothing rendered");
-  HIP_TRY(c, hipSetDevice(c->device));
   { int rs = sync_all_lanes(c); if (rs) return rs; }
   HIP_TRY(c, hipMemcpy(out, c->radiance.p, (size_t)c->rad_w * c->rad_h * sizeof(float4), hipMemcpyDeviceToHost));
   return PTC_OK;
@@ -568,28 +709,40 @@ int ptc_read_radiance_rgba32f(ptc_ctx* c, float* out) {
 
 void* ptc_radiance_device_ptr(ptc_ctx* c) { return (c && c->device >= 0) ? (void*)c->radiance.p : nullptr; }
 
+int ptc_read_radiance_rgba16f(ptc_ctx* c, uint16_t* out) {
+  { int rd = need_device(c); if (rd) return rd; }
+  if (!out) return fail(c, PTC_E_ARG, "read_radiance_rgba16f: null pointer");
+  { int rc = convert_half(c); if (rc) return rc; }
+  HIP_TRY(c, hipStreamSynchronize(c->lanes[0].stream));
+  HIP_TRY(c, hipMemcpy(out, c->half.p, (size_t)c->rad_w * c->rad_h * sizeof(uint2), hipMemcpyDeviceToHost));
+  return PTC_OK;
+}
+void* ptc_radiance_rgba16f_device_ptr(ptc_ctx* c) {
+  if (need_device(c)) return nullptr;
+  if (convert_half(c)) return nullptr;
+  if (hipStreamSynchronize(c->lanes[0].stream) != hipSuccess) return nullptr;
+  return (void*)c->half.p;
+}
+
 int ptc_write_radiance_rgba32f(ptc_ctx* c, const float* in) {
-  if (!c) return PTC_E_ARG;
-  if (c->device < 0) return fail(c, PTC_E_DEVICE, "this context has no device (PTC_DEVICE_NONE): the call needs a gfx950 GPU; there is no CPU path");
+  { int rd = need_device(c); if (rd) return rd; }
   if (!in) return fail(c, PTC_E_ARG, "write_radiance: null pointer");
   if (!c->radiance.p || c->rad_w == 0) return fail(c, PTC_E_STATE, "write_radiance: no frame");
-  HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  { int rs = sync_all_lanes(c); if (rs) return rs; }     // every lane: a resolve or a reduce may still be writing the buffer
   HIP_TRY(c, hipMemcpy(c->radiance.p, in, (size_t)c->rad_w * c->rad_h * sizeof(float4), hipMemcpyHostToDevice));
   return PTC_OK;
 }
 
 int ptc_tonemap_rgba8(ptc_ctx* c, uint8_t* out) {
-  if (!c) return PTC_E_ARG;
-  if (c->device < 0) return fail(c, PTC_E_DEVICE, "this context has no device (PTC_DEVICE_NONE): the call needs a gfx950 GPU; there is no CPU path");
+  { int rd = need_device(c); if (rd) return rd; }
   if (!out) return fail(c, PTC_E_ARG, "tonemap: null pointer");
   if (!c->radiance.p || c->rad_w == 0) return fail(c, PTC_E_STATE, "tonemap: nothing rendered");
-  HIP_TRY(c, hipSetDevice(c->device));
   int rc;
-  if ((rc = ensure_buf_u32(c, c->ldr, (size_t)c->rad_w * c->rad_h))) return rc;
-  pt_launch_tonemap(c->stream, c->radiance.p, c->ldr.p, c->rad_w, c->rad_h);
+  if ((rc = ensure_buf(c, c->ldr, (size_t)c->rad_w * c->rad_h))) return rc;
+  hipStream_t s0 = c->lanes[0].stream;
+  pt_launch_tonemap(s0, c->radiance.p, c->ldr.p, c->rad_w, c->rad_h);
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipStreamSynchronize(s0));
   HIP_TRY(c, hipMemcpy(out, c->ldr.p, (size_t)c->rad_w * c->rad_h * 4, hipMemcpyDeviceToHost));
   return PTC_OK;
 }
@@ -599,54 +752,139 @@ int ptc_get_stats(ptc_ctx* c, ptc_stats* out) {
   if (!out) return fail(c, PTC_E_ARG, "get_stats: null pointer");
   if (c->device < 0) { *out = c->stats; return PTC_OK; }
   HIP_TRY(c, hipSetDevice(c->device));
+  { int rf = flush(c); if (rf) return rf; }
   { int rs = sync_all_lanes(c); if (rs) return rs; }
-  if (c->q.stats) {
-    unsigned long long st[ST_N] = {0};
-    for (int l = 0; l < c->n_lanes; ++l) {
-      if (!lane_q(c, l).stats) continue;
-      unsigned long long one[ST_N];
-      HIP_TRY(c, hipMemcpy(one, lane_q(c, l).stats, sizeof one, hipMemcpyDeviceToHost));
-      for (int i = 0; i < ST_N; ++i) st[i] += one[i];
-    }
-    ptc_stats& s = c->stats;
-    s.segments = st[ST_SEGMENTS]; s.shadow_rays = st[ST_SHADOW]; s.hits = st[ST_HITS];
-    s.node_visits_closest = st[ST_NODES_C]; s.tri_tests_closest = st[ST_TRIS_C];
-    s.node_visits_any = st[ST_NODES_A]; s.tri_tests_any = st[ST_TRIS_A];
-    // SURVEY §8d byte model with this build's record sizes (DESIGN.md §"Algorithmic bytes")
-    s.algorithmic_bytes = s.segments * (2u * 56u + 2u * 16u) + s.node_visits_closest * 48u + s.tri_tests_closest * 48u + s.hits * 176u +
-                          s.shadow_rays * (2u * 44u) + s.node_visits_any * 48u + s.tri_tests_any * 48u + s.paths * (2u * 16u);
-  }
-  collect_times(c);
+  unsigned long long st[ST_N];
+  { int rc = sum_lane_stats(c, st); if (rc) return rc; }
+  ptc_stats& s = c->stats;
+  s.segments = st[ST_SEGMENTS]; s.shadow_rays = st[ST_SHADOW]; s.hits = st[ST_HITS];
+  s.node_visits_closest = st[ST_NODES_C]; s.tri_tests_closest = st[ST_TRIS_C];
+  s.node_visits_any = st[ST_NODES_A]; s.tri_tests_any = st[ST_TRIS_A];
+  // SURVEY §8d byte model with this build's record sizes (DESIGN.md §"Algorithmic bytes")
+  s.algorithmic_bytes = s.segments * (2u * 56u + 2u * 16u) + s.node_visits_closest * 80u + s.tri_tests_closest * 48u + s.hits * 176u +
+                        s.shadow_rays * (2u * 44u) + s.node_visits_any * 80u + s.tri_tests_any * 48u + s.paths * (2u * 16u);
+  collect_times(c, true);
   *out = c->stats;
   return PTC_OK;
 }
 
+// ---- multi-GPU: RCCL reduce of the framebuffer ----------------------------------------------------------
+int ptc_comm_unique_id(uint8_t out[PTC_COMM_ID_BYTES]) {
+  static_assert(PTC_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "ptc.h mirrors NCCL_UNIQUE_ID_BYTES");
+  if (!out) return PTC_E_ARG;
+  if (!rccl_load()) { g_create_error = g_rccl.err; return PTC_E_DEVICE; }
+  ncclUniqueId id;
+  const ncclResult_t r = g_rccl.GetUniqueId(&id);
+  if (r != ncclSuccess) { g_create_error = std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r); return PTC_E_DEVICE; }
+  std::memcpy(out, id.internal, PTC_COMM_ID_BYTES);
+  return PTC_OK;
+}
+
+int ptc_comm_init(ptc_ctx* c, const uint8_t id[PTC_COMM_ID_BYTES], int rank, int n_ranks) {
+  { int rd = need_device(c); if (rd) return rd; }
+  if (!id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(c, PTC_E_ARG, "comm_init: bad argument");
+  if (c->comm) return fail(c, PTC_E_STATE, "comm_init: this context already has a communicator");
+  if (!rccl_load()) return fail(c, PTC_E_DEVICE, g_rccl.err);
+  ncclUniqueId uid;
+  std::memcpy(uid.internal, id, PTC_COMM_ID_BYTES);
+  NCCL_TRY(c, g_rccl.CommInitRank(&c->comm, n_ranks, uid, rank));
+  c->comm_rank = rank; c->comm_size = n_ranks; c->comm_owned = true;
+  return PTC_OK;
+}
+
+int ptc_comm_reduce_radiance(ptc_ctx* c, int root) {
+  { int rd = need_device(c); if (rd) return rd; }
+  if (!c->comm) return fail(c, PTC_E_STATE, "comm_reduce_radiance: no communicator (ptc_comm_init / ptc_group_create)");
+  if (root < 0 || root >= c->comm_size) return fail(c, PTC_E_ARG, "comm_reduce_radiance: bad root");
+  if (!c->radiance.p || c->rad_w == 0) return fail(c, PTC_E_STATE, "comm_reduce_radiance: nothing rendered");
+  // in place on stream 0, behind the resolve: ranks own disjoint tiles and hold zeros elsewhere, so the fp32 sum is x + 0
+  NCCL_TRY(c, g_rccl.Reduce(c->radiance.p, c->radiance.p, (size_t)c->rad_w * c->rad_h * 4, ncclFloat32, ncclSum, root, c->comm, c->lanes[0].stream));
+  return PTC_OK;
+}
+
+int ptc_comm_destroy(ptc_ctx* c) {
+  { int rd = need_device(c); if (rd) return rd; }
+  if (!c->comm) return PTC_OK;
+  if (!c->comm_owned) return fail(c, PTC_E_STATE, "comm_destroy: the communicator belongs to a ptc_group");
+  { int rs = sync_all_lanes(c); if (rs) return rs; }
+  NCCL_TRY(c, g_rccl.CommDestroy(c->comm));
+  c->comm = nullptr; c->comm_size = 0;
+  return PTC_OK;
+}
+
+ptc_group* ptc_group_create(const int* device_ids, int n_devices) {
+  if (!device_ids || n_devices < 1 || n_devices > 64) { g_create_error = "ptc_group_create: bad argument"; return nullptr; }
+  if (!rccl_load()) { g_create_error = g_rccl.err; return nullptr; }
+  ptc_group* g = new ptc_group();
+  for (int i = 0; i < n_devices; ++i) {
+    ptc_ctx* c = ptc_create(device_ids[i]);
+    if (!c) { ptc_group_destroy(g); return nullptr; }
+    g->ctx.push_back(c);
+  }
+  g->comms.resize((size_t)n_devices, nullptr);
+  const ncclResult_t r = g_rccl.CommInitAll(g->comms.data(), n_devices, device_ids);
+  if (r != ncclSuccess) { g_create_error = std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r); g->comms.clear(); ptc_group_destroy(g); return nullptr; }
+  for (int i = 0; i < n_devices; ++i) {
+    ptc_ctx* c = g->ctx[(size_t)i];
+    c->comm = g->comms[(size_t)i]; c->comm_rank = i; c->comm_size = n_devices; c->comm_owned = false;
+  }
+  return g;
+}
+
+int ptc_group_size(const ptc_group* g) { return g ? (int)g->ctx.size() : 0; }
+ptc_ctx* ptc_group_ctx(ptc_group* g, int i) { return (g && i >= 0 && (size_t)i < g->ctx.size()) ? g->ctx[(size_t)i] : nullptr; }
+const char* ptc_group_last_error(const ptc_group* g) { return g ? g->err.c_str() : g_create_error.c_str(); }
+
+int ptc_group_render(ptc_group* g, int w, int h, int spp, uint64_t seed, int max_bounces, int integrator) {
+  if (!g || g->ctx.empty()) return PTC_E_ARG;
+  const int n = (int)g->ctx.size();
+  auto bail = [&](int i, int rc) { g->err = std::string("device ") + std::to_string(i) + ": " + ptc_last_error(g->ctx[(size_t)i]); return rc; };
+  // every device traces all samples of its tiles; all of it is queued before anything is waited for
+  for (int i = 0; i < n; ++i) { int rc = ptc_frame_begin(g->ctx[(size_t)i], w, h, spp, seed, max_bounces, integrator, i, n); if (rc) return bail(i, rc); }
+  for (int i = 0; i < n; ++i) { int rc = ptc_frame_add_samples(g->ctx[(size_t)i], spp); if (rc) return bail(i, rc); }
+  for (int i = 0; i < n; ++i) { int rc = ptc_frame_resolve(g->ctx[(size_t)i]); if (rc) return bail(i, rc); }
+  if (n > 1) {
+    ncclResult_t r = g_rccl.GroupStart();
+    for (int i = 0; i < n && r == ncclSuccess; ++i) {
+      ptc_ctx* c = g->ctx[(size_t)i];
+      if (hipSetDevice(c->device) != hipSuccess) { g->err = "ptc_group_render: hipSetDevice failed"; (void)g_rccl.GroupEnd(); return PTC_E_DEVICE; }
+      r = g_rccl.Reduce(c->radiance.p, c->radiance.p, (size_t)w * h * 4, ncclFloat32, ncclSum, 0, c->comm, c->lanes[0].stream);
+    }
+    const ncclResult_t r2 = g_rccl.GroupEnd();
+    if (r != ncclSuccess || r2 != ncclSuccess) { g->err = std::string("ptc_group_render: ncclReduce: ") + g_rccl.GetErrorString(r != ncclSuccess ? r : r2); return PTC_E_DEVICE; }
+  }
+  for (int i = 0; i < n; ++i) { int rc = ptc_sync(g->ctx[(size_t)i]); if (rc) return bail(i, rc); }
+  return PTC_OK;
+}
+
+void ptc_group_destroy(ptc_group* g) {
+  if (!g) return;
+  for (ptc_ctx* c : g->ctx)
+    if (c && c->device >= 0) { (void)hipSetDevice(c->device); for (auto& ln : c->lanes) if (ln.stream) (void)hipStreamSynchronize(ln.stream); }
+  for (ncclComm_t cm : g->comms) if (cm && g_rccl.so) (void)g_rccl.CommDestroy(cm);
+  for (ptc_ctx* c : g->ctx) { if (c) { c->comm = nullptr; ptc_destroy(c); } }
+  delete g;
+}
+
 // ---- test hooks -----------------------------------------------------------------------------------
 int ptc_debug_trace_closest(ptc_ctx* c, const float* origins, const float* dirs, uint32_t n, float* out_t, int32_t* out_prim, float* out_uv) {
-  if (c && c->device >= 0) { int rs = sync_all_lanes(c); if (rs) return rs; }
   if (!c) return PTC_E_ARG;
-  if (c->device < 0) return fail(c, PTC_E_DEVICE, "this context has no device (PTC_DEVICE_NONE): the call needs a gfx950 GPU; there is no CPU path");
-  if (!c->committed) return fail(c, PTC_E_STATE, "debug_trace_closest: scene not committed");
-  if (!origins || !dirs || !out_t || !out_prim || !out_uv || n == 0) return fail(c, PTC_E_ARG, "debug_trace_closest: bad argument");
-  HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  c->in_frame = false;
-  int rc;
-  if ((rc = ensure_queues(c, n))) return rc;
+  if (c->device >= 0 && (!origins || !dirs || !out_t || !out_prim || !out_uv || n == 0)) return fail(c, PTC_E_ARG, "debug_trace_closest: bad argument");
+  { int rc = debug_prepare(c, n, "debug_trace_closest"); if (rc) return rc; }
+  const Lane& ln = c->lanes[0];
   std::vector<float4> A(n), B(n);
   for (uint32_t i = 0; i < n; ++i) {
     A[i] = make_float4(origins[i * 3], origins[i * 3 + 1], origins[i * 3 + 2], dirs[i * 3]);
     B[i] = make_float4(dirs[i * 3 + 1], dirs[i * 3 + 2], 0.0f, 0.0f);
   }
-  HIP_TRY(c, hipMemcpy(c->q.ray[0].A, A.data(), n * sizeof(float4), hipMemcpyHostToDevice));
-  HIP_TRY(c, hipMemcpy(c->q.ray[0].B, B.data(), n * sizeof(float4), hipMemcpyHostToDevice));
-  for (int l = 0; l < c->n_lanes; ++l) if (lane_q(c, l).stats) HIP_TRY(c, hipMemset(lane_q(c, l).stats, 0, ST_N * sizeof(unsigned long long)));
-  pt_launch_set_counts(c->stream, c->q, n, 0);
-  pt_launch_trace_closest(c->stream, c->cfg, c->dsc, c->q, 0, false);
+  HIP_TRY(c, hipMemcpy(ln.q.ray[0].A, A.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(ln.q.ray[0].B, B.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+  pt_launch_set_counts(ln.stream, ln.q, n, 0);
+  pt_launch_trace_closest(ln.stream, c->cfg, lane_scene(c, 0), ln.q, 0, false);
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipStreamSynchronize(ln.stream));
   std::vector<float4> H(n);
-  HIP_TRY(c, hipMemcpy(H.data(), c->q.hit, n * sizeof(float4), hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(H.data(), ln.q.hit, n * sizeof(float4), hipMemcpyDeviceToHost));
   for (uint32_t i = 0; i < n; ++i) {
     int32_t pc; std::memcpy(&pc, &H[i].y, 4);   // prim | class<<28, or -1
     out_t[i] = H[i].x; out_prim[i] = pc < 0 ? -1 : (pc & 0x0fffffff); out_uv[i * 2] = H[i].z; out_uv[i * 2 + 1] = H[i].w;
@@ -655,30 +893,23 @@ int ptc_debug_trace_closest(ptc_ctx* c, const float* origins, const float* dirs,
 }
 
 int ptc_debug_trace_any(ptc_ctx* c, const float* origins, const float* dirs, const float* tmax, uint32_t n, uint8_t* out_occluded) {
-  if (c && c->device >= 0) { int rs = sync_all_lanes(c); if (rs) return rs; }
   if (!c) return PTC_E_ARG;
-  if (c->device < 0) return fail(c, PTC_E_DEVICE, "this context has no device (PTC_DEVICE_NONE): the call needs a gfx950 GPU; there is no CPU path");
-  if (!c->committed) return fail(c, PTC_E_STATE, "debug_trace_any: scene not committed");
-  if (!origins || !dirs || !tmax || !out_occluded || n == 0) return fail(c, PTC_E_ARG, "debug_trace_any: bad argument");
-  HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  c->in_frame = false;
-  int rc;
-  if ((rc = ensure_queues(c, n))) return rc;
+  if (c->device >= 0 && (!origins || !dirs || !tmax || !out_occluded || n == 0)) return fail(c, PTC_E_ARG, "debug_trace_any: bad argument");
+  { int rc = debug_prepare(c, n, "debug_trace_any"); if (rc) return rc; }
+  const Lane& ln = c->lanes[0];
   std::vector<float4> A(n), B(n);
   for (uint32_t i = 0; i < n; ++i) {
     A[i] = make_float4(origins[i * 3], origins[i * 3 + 1], origins[i * 3 + 2], dirs[i * 3]);
     B[i] = make_float4(dirs[i * 3 + 1], dirs[i * 3 + 2], tmax[i], 0.0f);
   }
-  HIP_TRY(c, hipMemcpy(c->q.shadow.A, A.data(), n * sizeof(float4), hipMemcpyHostToDevice));
-  HIP_TRY(c, hipMemcpy(c->q.shadow.B, B.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(ln.q.shadow.A, A.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(ln.q.shadow.B, B.data(), n * sizeof(float4), hipMemcpyHostToDevice));
   uint8_t* d_out = nullptr;
   HIP_TRY(c, hipMalloc((void**)&d_out, n));
-  for (int l = 0; l < c->n_lanes; ++l) if (lane_q(c, l).stats) HIP_TRY(c, hipMemset(lane_q(c, l).stats, 0, ST_N * sizeof(unsigned long long)));
-  pt_launch_set_counts(c->stream, c->q, 0, n);
-  pt_launch_trace_any(c->stream, c->cfg, c->dsc, c->q, d_out);
+  pt_launch_set_counts(ln.stream, ln.q, 0, n);
+  pt_launch_trace_any(ln.stream, c->cfg, lane_scene(c, 0), ln.q, d_out);
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ln.stream);
   if (e == hipSuccess) e = hipMemcpy(out_occluded, d_out, n, hipMemcpyDeviceToHost);
   (void)hipFree(d_out);
   if (e != hipSuccess) return fail(c, PTC_E_DEVICE, std::string("debug_trace_any: ") + hipGetErrorString(e));
@@ -724,19 +955,12 @@ int ptc_debug_get_texture(ptc_ctx* c, int index, int* w, int* h, uint8_t* rgba) 
 }
 
 int ptc_debug_get_counters(ptc_ctx* c, uint64_t* out, int n) {
-  if (!c) return PTC_E_ARG;
-  if (c->device < 0) return fail(c, PTC_E_DEVICE, "this context has no device (PTC_DEVICE_NONE): the call needs a gfx950 GPU; there is no CPU path");
+  { int rd = need_device(c); if (rd) return rd; }
   if (!out || n <= 0) return fail(c, PTC_E_ARG, "debug_get_counters: bad argument");
-  if (!c->q.stats) return fail(c, PTC_E_STATE, "debug_get_counters: nothing rendered");
-  HIP_TRY(c, hipSetDevice(c->device));
+  { int rf = flush(c); if (rf) return rf; }
   { int rs = sync_all_lanes(c); if (rs) return rs; }
-  unsigned long long st[ST_N] = {0};
-  for (int l = 0; l < c->n_lanes; ++l) {
-    if (!lane_q(c, l).stats) continue;
-    unsigned long long one[ST_N];
-    HIP_TRY(c, hipMemcpy(one, lane_q(c, l).stats, sizeof one, hipMemcpyDeviceToHost));
-    for (int i = 0; i < ST_N; ++i) st[i] += one[i];
-  }
+  unsigned long long st[ST_N];
+  { int rc = sum_lane_stats(c, st); if (rc) return rc; }
   for (int i = 0; i < n; ++i) out[i] = i < ST_N ? st[i] : 0;
   return ST_N;
 }
@@ -749,6 +973,17 @@ int ptc_debug_get_bvh(ptc_ctx* c, uint32_t* n_nodes, uint32_t* n_tris, float* no
   if (n_tris) *n_tris = B.n_tri_records;
   if (nodes) std::memcpy(nodes, B.nodes.data(), B.nodes.size() * 4);
   if (tris) std::memcpy(tris, B.tris.data(), B.tris.size() * 4);
+  return PTC_OK;
+}
+
+// Context internals for tests of the host logic: [0] HIP events created so far, [1] timing spans waiting to be collected,
+// [2] queue capacity (paths) of lane 0, [3] samples of one full batch, [4] samples accepted but not yet issued,
+// [5] trace blocks per CU, [6] stack entries per lane kept in LDS.
+int ptc_debug_get_internals(ptc_ctx* c, uint64_t out[8]) {
+  if (!c || !out) return PTC_E_ARG;
+  for (int i = 0; i < 8; ++i) out[i] = 0;
+  out[0] = c->events_created; out[1] = c->spans.size(); out[2] = c->lanes.empty() ? 0 : c->lanes[0].q.cap; out[3] = c->per_batch; out[4] = c->pending;
+  out[5] = (uint64_t)c->cfg.trace_blocks_per_cu; out[6] = (uint64_t)c->cfg.stack_lds;
   return PTC_OK;
 }
 

@@ -9,7 +9,7 @@
 
 // ---- HBM layout of the committed scene (DESIGN.md §"Data layout in HBM") -----------------------
 struct DevScene {
-  const float4* nodes;        // 3 × 16 B per 4-wide node (48 B): org+exponents, 8-bit child planes, child/triangle bases (ptc_scene.cpp)
+  const float4* nodes;        // 5 × 16 B per 8-wide node (80 B): org+exponents+imask, 8-bit child planes of the 8 slots, child/triangle bases, leaf masks (ptc_scene.cpp)
   const float4* tris;         // 3 × float4 per triangle record (48 B): (v0,prim) (e1,class) (e2,-), grouped by owning node
   const float4* shade;        // 5 × float4 per original primitive id (80 B): the three R1 vertex records de-indexed to what
                               // shading reads: (Pa,mat) (Pb,light) (Pc,Na.x) (Na.yz,Nb.xy) (Nb.z,Nc.xyz)
@@ -27,7 +27,7 @@ struct DevScene {
   uint32_t n_lights;
   uint32_t n_mats;
   uint32_t n_nodelets;        // leading nodes (BFS order) that the trace kernels stage in LDS
-  uint2* stack_ovf;           // per-lane traversal-stack overflow: [wave][ovf_depth][64] entries of (code, tnear)
+  uint2* stack_ovf;           // per-lane traversal-stack overflow: [wave][ovf_depth][64] entries of (base_child, hits<<8 | imask)
   uint32_t ovf_depth;
   float ray_eps;
 };
@@ -70,6 +70,8 @@ struct LaunchCfg { int n_cu; int trace_blocks_per_cu; int stack_lds; /* stack en
 
 // ---- kernel launchers (pt_kernels.hip) ------------------------------------------------------------
 int pt_trace_block_threads();   // threads per block of the trace kernels (compile-time constant of pt_kernels.hip)
+size_t pt_trace_lds_bytes(const LaunchCfg&, const DevScene&);   // dynamic LDS of a trace block (the larger, closest-hit, figure)
+int pt_trace_blocks_per_cu(size_t lds_bytes);                    // resident trace blocks per CU at that LDS size (runtime occupancy query)
 void pt_launch_set_counts(hipStream_t, const DevQueues&, uint32_t n_rays, uint32_t n_shadow);
 void pt_launch_advance(hipStream_t, const DevQueues&);
 void pt_launch_raygen(hipStream_t, const DevCamera&, const DevFrame&, const DevQueues&, uint32_t first_sample, uint32_t n_samples, bool raster);
@@ -77,7 +79,8 @@ void pt_launch_trace_closest(hipStream_t, const LaunchCfg&, const DevScene&, con
 void pt_launch_shade(hipStream_t, const LaunchCfg&, const DevScene&, const DevFrame&, const DevQueues&, int qi, uint32_t bounce);   // every ray of a wavefront launch is at the same bounce
 void pt_launch_trace_any(hipStream_t, const LaunchCfg&, const DevScene&, const DevQueues&, uint8_t* debug_out /*or null*/);
 void pt_launch_accumulate(hipStream_t, const DevFrame&, const DevQueues&, float4* accum, uint32_t n_samples);
-void pt_launch_shade_raster(hipStream_t, const DevScene&, const DevCamera&, const DevFrame&, const DevQueues&, float4* accum);
+void pt_launch_shade_raster(hipStream_t, const DevScene&, const DevCamera&, const DevFrame&, const DevQueues&, float4* accum, bool gbuffer16);
+void pt_launch_to_half(hipStream_t, const float4* radiance, uint2* out_rgba16f, uint32_t n_pixels);
 void pt_launch_resolve(hipStream_t, const DevFrame&, const float4* accum, float4* radiance, float inv_spp_divisor, bool raster);
 void pt_launch_tonemap(hipStream_t, const float4* radiance, uint32_t* rgba8, int w, int h);
 
@@ -100,7 +103,7 @@ struct HostBuilt {
   std::vector<int32_t> tex_info; // 4 ints per texture
   std::vector<float> env, env_marg, env_cond;   // 4 floats per texel; cdfs
   int env_w = 0, env_h = 0, env_ok = 0;
-  std::vector<float> nodes;      // 12 words per 4-wide node
+  std::vector<float> nodes;      // 20 words per 8-wide node
   std::vector<float> tris;       // 12 floats per triangle record (node order)
   std::vector<float> mats;       // 12 floats per material
   std::vector<float> lights;     // 20 floats per emitter

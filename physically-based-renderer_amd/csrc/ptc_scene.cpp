@@ -1,4 +1,4 @@
-// ptc_scene.cpp — host side of ptc_scene_commit: flatten instances to world space, build the SAH BVH,
+// ptc_scene.cpp — host side of ptc_scene_commit: flatten instances to world space, build the 8-wide SAH BVH,
 // lay it out for the trace kernels, build the emitter table.
 //
 // Reference conventions implemented here (file:line under the reference checkout):
@@ -18,6 +18,9 @@
 namespace {
 
 constexpr int kLeafMax = 2;
+constexpr int kWide = 8;      // child slots per BVH node
+constexpr int kNodeWords = 20; // 80-byte node
+constexpr float kCostNode = 1.0f, kCostPrim = 1.0f;   // surface-area cost of one node visit / one triangle test (collapse)
 constexpr int kTile = 32;
 
 struct Mat34 { float m[16]; float n[9]; };  // column-major model (glm layout) + normal matrix
@@ -78,8 +81,8 @@ inline void grow(Box& b, const Box& o) {
 // SplitNode covers positions [lo,hi] of `ord`; child >= 0: node index; < 0: ~position of a single triangle.
 // Per range: kSahBins equal bins over the centroid bounds on each axis, cost = half_area(L)·nL + half_area(R)·nR,
 // minimum over (axis, boundary) with ties to the lowest axis then boundary, STABLE partition; coincident
-// centroids → cut at the middle index.  Ranges of <= kLeafMax triangles are not split by cost (they become the
-// wide tree's leaves) and are only chained down to single positions for the box pass.
+// centroids → cut at the middle index.  The binary tree goes down to single triangles; which subtrees become the
+// wide tree's leaves is decided by the collapse (ptc_build_scene).
 struct SplitNode { uint32_t lo, hi; int32_t left, right; };
 constexpr int kSahBins = 32;
 
@@ -104,11 +107,8 @@ void build_split_tree(const std::vector<Box>& tbox, std::vector<uint32_t>& ord, 
   while (!todo.empty()) {
     const Work w = todo.back();
     todo.pop_back();
-    const uint32_t count = w.hi - w.lo + 1u;
     uint32_t last_left;   // last position of the left part
-    if (count <= (uint32_t)kLeafMax && w.node != 0) {
-      last_left = w.lo;   // a leaf range: chain, no reordering
-    } else {
+    {
       float cl[3], ch[3];
       for (int k = 0; k < 3; ++k) { cl[k] = std::numeric_limits<float>::infinity(); ch[k] = -cl[k]; }
       for (uint32_t i = w.lo; i <= w.hi; ++i) {
@@ -319,59 +319,92 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
     o[8] = c[0] - a[0]; o[9] = c[1] - a[1]; o[10] = c[2] - a[2]; o[11] = 0.0f;
   };
   // ---- hierarchy --------------------------------------------------------------------------------------
-  // Binary tree by binned surface-area splits → ranges of <= kLeafMax triangles are leaves → 4-wide collapse,
-  // greedy by surface area: a node starts from its two binary children and keeps replacing the interior
-  // child with the largest half-area (ties: lowest slot) by that child's two children, in place, until it
-  // has 4 children or only leaves are left.
+  // Binary tree by binned surface-area splits (down to single triangles) → 8-wide collapse by dynamic programming over
+  // the surface-area cost (Ylitie, Karras, Laine 2017, sec. 3.1): for a binary node n with box half-area A_n and P_n
+  // triangles, C(n,i) = least cost of representing its subtree by at most i roots (a root = a leaf or an 8-wide node):
+  //   C(n,1) = min(C_leaf, C_int)   C(n,i) = min(C_dist(n,i), C(n,i-1))   C_dist(n,j) = min_k C(left,k) + C(right,j-k)
+  //   C_leaf = A_n·P_n·kCostPrim if P_n <= kLeafMax else inf            C_int = C_dist(n,8) + A_n·kCostNode
+  // ties: leaf over interior, fewer roots over more, smallest k.  A node's children are the roots of C_dist(n,8), left to
+  // right.  The (<= 8) children are then placed into the node's 8 SLOTS so that a
+  // child in slot s lies in octant s of the node (bit k of s set = towards +axis k): repeatedly the (child, free
+  // slot) pair with the largest  (+-)dx + (+-)dy + (+-)dz,  d = child centre - node centre, ties to the lowest child
+  // then the lowest slot.  A ray then orders the slots by its direction signs alone (descending slot ^ octant), with
+  // no per-child distance sort.
   //
-  // Storage: 48-byte nodes (3 × 16-byte loads per visit — the trace kernels are bound by the number of
-  // vector-memory instructions, not by bytes), child boxes quantised to 8 bits against the node's own box:
-  //   w0..2  org.xyz (float)           w3   ex | ey<<8 | ez<<16 | desc[7:0]<<24
-  //   w4..6  qlo.x/y/z (4 × u8 each)   w7   qhi.x          plane = org + q · 2^(e-127)
-  //   w8,w9  qhi.y, qhi.z              w10  base_child (24 bits) | desc[15:8]<<24      w11  base_tri
-  // desc: 4 bits per child = type (0 empty, 1 leaf, 2 interior) << 2 | (triangle count - 1).  A node's
-  // interior children are consecutive nodes from base_child and its leaf children's triangles are consecutive
-  // records from base_tri, both in slot order, so no per-child index is stored.
+  // Storage: 80-byte nodes (5 × 16-byte loads per visit), child boxes quantised to 8 bits against the node's own box:
+  //   w0..2   org.xyz (float)            w3    ex | ey<<8 | ez<<16 | imask<<24     plane = org + q · 2^(e-127)
+  //   w4,5    qlo.x slots 0-3 / 4-7      w6,7  qlo.y     w8,9   qlo.z
+  //   w10,11  qhi.x                      w12,13 qhi.y    w14,15 qhi.z               (empty slot: qlo 255, qhi 0)
+  //   w16     base_child                 w17   base_tri  w18    lmask | two<<8      w19    0
+  // imask / lmask: slots holding an interior / a leaf child; two: leaf slots with 2 triangles.  A node's interior
+  // children are consecutive nodes from base_child and its leaf children's triangles are consecutive records from
+  // base_tri, both in slot order, so a child's index is base + popcount(mask below its slot).
   // Layout: breadth-first until `nodelet_budget` nodes exist (the trace kernels stage those in LDS), then
   // depth-first, always allocating a node's children as one block.
   struct WChild { bool leaf; uint32_t lo, hi; int32_t radix; Box box; };
   std::vector<SplitNode> radix;
   std::vector<Box> radix_box;
-  auto range_box = [&](uint32_t lo, uint32_t hi) {
-    Box b = empty_box();
-    for (uint32_t i = lo; i <= hi; ++i) grow(b, tbox[ord[i]]);
-    return b;
-  };
-  auto child_of = [&](int32_t link) {
-    WChild c;
-    if (link < 0) { c.leaf = true; c.lo = c.hi = (uint32_t)~link; c.radix = -1; c.box = range_box(c.lo, c.hi); return c; }
-    const SplitNode& r = radix[(size_t)link];
-    c.lo = r.lo; c.hi = r.hi; c.radix = link;
-    c.leaf = (r.hi - r.lo + 1u) <= (uint32_t)kLeafMax;
-    c.box = radix_box[(size_t)link];
-    return c;
-  };
-  struct Wide { WChild kid[4]; int n; };
-  auto expand = [&](int32_t r) {
-    Wide w;
-    w.n = 2;
-    w.kid[0] = child_of(radix[(size_t)r].left);
-    w.kid[1] = child_of(radix[(size_t)r].right);
-    while (w.n < 4) {
-      int best = -1; float besta = 0.0f;
-      for (int i = 0; i < w.n; ++i) {
-        if (w.kid[i].leaf) continue;
-        const float a = box_half_area(w.kid[i].box);
-        if (best < 0 || a > besta) { best = i; besta = a; }
+  struct Dp { float c[8]; uint8_t leaf1, same[8], k[9]; };   // c[i], same[i]: i = 1..7; k[j]: j = 2..8
+  std::vector<Dp> dp;
+  auto link_box = [&](int32_t link) { return link < 0 ? tbox[ord[(size_t)~link]] : radix_box[(size_t)link]; };
+  auto dp_cost = [&](int32_t link, int i) { return link < 0 ? box_half_area(link_box(link)) * 1.0f * kCostPrim : dp[(size_t)link].c[i]; };
+  auto min7 = [](int k) { return k > 7 ? 7 : k; };
+  struct Wide { WChild slot[kWide]; bool used[kWide]; int n; };
+  auto assign_slots = [&](const WChild* kid, int n, int* slot_of) {
+    Box nb = empty_box();
+    for (int i = 0; i < n; ++i) grow(nb, kid[i].box);
+    float d[kWide][3];
+    for (int i = 0; i < n; ++i)
+      for (int k = 0; k < 3; ++k) d[i][k] = 0.5f * (kid[i].box.lo[k] + kid[i].box.hi[k]) - 0.5f * (nb.lo[k] + nb.hi[k]);
+    bool child_done[kWide] = {false}, slot_used[kWide] = {false};
+    for (int round = 0; round < n; ++round) {
+      int bi = -1, bs = -1; float bsc = 0.0f;
+      for (int i = 0; i < n; ++i) {
+        if (child_done[i]) continue;
+        for (int sl = 0; sl < kWide; ++sl) {
+          if (slot_used[sl]) continue;
+          const float sc = ((sl & 1) ? d[i][0] : -d[i][0]) + ((sl & 2) ? d[i][1] : -d[i][1]) + ((sl & 4) ? d[i][2] : -d[i][2]);
+          if (bi < 0 || sc > bsc) { bi = i; bs = sl; bsc = sc; }
+        }
       }
-      if (best < 0) break;
-      const SplitNode& rn = radix[(size_t)w.kid[best].radix];
-      for (int j = w.n; j > best + 1; --j) w.kid[j] = w.kid[j - 1];
-      const WChild l = child_of(rn.left), rr = child_of(rn.right);
-      w.kid[best] = l; w.kid[best + 1] = rr;
-      ++w.n;
+      child_done[bi] = true; slot_used[bs] = true; slot_of[bi] = bs;
     }
+  };
+  // the roots of the best forest of at most i roots below `link`, appended left to right
+  struct ForestJob { int32_t link; int i; };
+  auto forest = [&](int32_t link0, int i0, WChild* kid, int& n) {
+    ForestJob stk[64]; int sp = 0;
+    stk[sp++] = {link0, i0};
+    while (sp > 0) {
+      const ForestJob j = stk[--sp];
+      WChild c;
+      c.box = link_box(j.link);
+      if (j.link < 0) { c.leaf = true; c.lo = c.hi = (uint32_t)~j.link; c.radix = -1; kid[n++] = c; continue; }
+      const SplitNode& r = radix[(size_t)j.link]; const Dp& d = dp[(size_t)j.link];
+      int i = j.i;
+      while (i > 1 && d.same[i]) --i;
+      if (i == 1) { c.leaf = d.leaf1 != 0; c.lo = r.lo; c.hi = r.hi; c.radix = j.link; kid[n++] = c; continue; }
+      const int kk = d.k[i];
+      stk[sp++] = {r.right, min7(i - kk)};      // left first
+      stk[sp++] = {r.left, min7(kk)};
+    }
+  };
+  auto make_wide = [&](const WChild* kid, int n) {
+    int slot_of[kWide];
+    assign_slots(kid, n, slot_of);
+    Wide w;
+    w.n = n;
+    for (int sl = 0; sl < kWide; ++sl) w.used[sl] = false;
+    for (int i = 0; i < n; ++i) { w.slot[slot_of[i]] = kid[i]; w.used[slot_of[i]] = true; }
     return w;
+  };
+  auto expand = [&](int32_t r) {
+    WChild kid[kWide];
+    int n = 0;
+    const int kk = dp[(size_t)r].k[8];
+    forest(radix[(size_t)r].left, min7(kk), kid, n);
+    forest(radix[(size_t)r].right, min7(8 - kk), kid, n);
+    return make_wide(kid, n);
   };
   // 8-bit quantisation of the children's [lo,hi] on one axis against the node's [org, nhi]: scale 2^(e-127)
   // is the smallest power of two with (nhi-org)/scale <= 255; lower planes floor, upper planes ceil, each
@@ -410,8 +443,9 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
   std::vector<Wide> wide;           // node index → its children
   std::vector<uint32_t> child_base; // node index → index of its first interior child
   if (n == 1) {   // a single triangle: two identical leaf children (mirrors the binary special case)
-    Wide w; w.n = 2;
-    for (int k = 0; k < 2; ++k) { w.kid[k].leaf = true; w.kid[k].lo = w.kid[k].hi = 0; w.kid[k].radix = -1; w.kid[k].box = range_box(0, 0); }
+    WChild kid[2];
+    for (int k = 0; k < 2; ++k) { kid[k].leaf = true; kid[k].lo = kid[k].hi = 0; kid[k].radix = -1; kid[k].box = tbox[0]; }
+    const Wide w = make_wide(kid, 2);
     order.push_back({-1, 0}); wide.push_back(w); child_base.push_back(1);
   } else {
     build_split_tree(tbox, ord, radix);
@@ -430,17 +464,40 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
         stk.pop_back();
       }
     }
+    // cost tables, bottom-up: radix nodes are numbered parents-first, so descending index order is a valid post-order
+    dp.assign(radix.size(), Dp());
+    for (size_t idx = radix.size(); idx-- > 0;) {
+      const SplitNode& r = radix[idx];
+      Dp& d = dp[idx];
+      float dist[9];
+      for (int j = 2; j <= 8; ++j) {
+        float best = std::numeric_limits<float>::infinity(); int bk = 1;
+        for (int k = 1; k < j; ++k) {
+          const float v = dp_cost(r.left, min7(k)) + dp_cost(r.right, min7(j - k));
+          if (v < best) { best = v; bk = k; }
+        }
+        dist[j] = best; d.k[j] = (uint8_t)bk;
+      }
+      const uint32_t P = r.hi - r.lo + 1u;
+      const float area = box_half_area(radix_box[idx]);
+      const float cleaf = P <= (uint32_t)kLeafMax ? area * (float)P * kCostPrim : std::numeric_limits<float>::infinity();
+      const float cint = dist[8] + area * kCostNode;
+      d.leaf1 = cleaf <= cint; d.c[1] = d.leaf1 ? cleaf : cint;
+      for (int i = 2; i <= 7; ++i) {
+        if (dist[i] < d.c[i - 1]) { d.c[i] = dist[i]; d.same[i] = 0; } else { d.c[i] = d.c[i - 1]; d.same[i] = 1; }
+      }
+    }
     auto number = [&](int32_t r, uint32_t depth) {
       order.push_back({r, depth});
       wide.push_back(expand(r));
       child_base.push_back(0xffffffffu);
     };
-    // allocate the children of node `idx` as one consecutive block
+    // allocate the interior children of node `idx` as one consecutive block, in slot order
     auto alloc_children = [&](uint32_t idx) {
       child_base[idx] = (uint32_t)order.size();
       const Wide w = wide[idx];
-      for (int i = 0; i < w.n; ++i)
-        if (!w.kid[i].leaf) number(w.kid[i].radix, order[idx].depth + 1);
+      for (int sl = 0; sl < kWide; ++sl)
+        if (w.used[sl] && !w.slot[sl].leaf) number(w.slot[sl].radix, order[idx].depth + 1);
     };
     number(0, 0);
     size_t head = 0;
@@ -455,7 +512,7 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
           stack.pop_back();
           alloc_children(idx);
           int k = 0;
-          for (int j = 0; j < wide[idx].n; ++j) k += wide[idx].kid[j].leaf ? 0 : 1;
+          for (int sl = 0; sl < kWide; ++sl) k += (wide[idx].used[sl] && !wide[idx].slot[sl].leaf) ? 1 : 0;
           for (int j = k - 1; j >= 0; --j) stack.push_back(child_base[idx] + (uint32_t)j);   // first child on top
         }
       }
@@ -463,42 +520,47 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
   }
   // ---- emit nodes (index order) and triangles (each node's leaf children in slot order) ----------------
   B.n_nodes = (uint32_t)order.size();
-  if (B.n_nodes >= (1u << 24)) return "scene_commit: too many BVH nodes";
-  B.nodes.assign((size_t)B.n_nodes * 12, 0.0f);
+  if (B.n_nodes >= (1u << 28)) return "scene_commit: too many BVH nodes";
+  B.nodes.assign((size_t)B.n_nodes * kNodeWords, 0.0f);
   B.tris.clear();
   uint32_t maxd = 0;
   for (uint32_t idx = 0; idx < B.n_nodes; ++idx) {
     if (order[idx].depth > maxd) maxd = order[idx].depth;
     const Wide& w = wide[idx];
-    uint32_t word[12] = {0};
-    uint32_t e[3], qlo[3][4], qhi[3][4];
+    uint32_t word[kNodeWords] = {0};
+    uint32_t e[3], qlo[3][kWide], qhi[3][kWide];
+    int sl_of[kWide], nk = 0;                      // used slots in ascending order
+    for (int sl = 0; sl < kWide; ++sl) if (w.used[sl]) sl_of[nk++] = sl;
     for (int k = 0; k < 3; ++k) {
-      float clo[4], chi[4], nlo = w.kid[0].box.lo[k], nhi = w.kid[0].box.hi[k];
-      for (int i = 0; i < w.n; ++i) {
-        clo[i] = w.kid[i].box.lo[k]; chi[i] = w.kid[i].box.hi[k];
+      float clo[kWide], chi[kWide], nlo = w.slot[sl_of[0]].box.lo[k], nhi = w.slot[sl_of[0]].box.hi[k];
+      uint32_t ql[kWide], qh[kWide];
+      for (int i = 0; i < nk; ++i) {
+        clo[i] = w.slot[sl_of[i]].box.lo[k]; chi[i] = w.slot[sl_of[i]].box.hi[k];
         nlo = clo[i] < nlo ? clo[i] : nlo; nhi = chi[i] > nhi ? chi[i] : nhi;
       }
-      for (int i = w.n; i < 4; ++i) { qlo[k][i] = 255; qhi[k][i] = 0; }
-      quantize_axis(clo, chi, w.n, nlo, nhi, e[k], qlo[k], qhi[k]);
+      for (int sl = 0; sl < kWide; ++sl) { qlo[k][sl] = 255; qhi[k][sl] = 0; }
+      quantize_axis(clo, chi, nk, nlo, nhi, e[k], ql, qh);
+      for (int i = 0; i < nk; ++i) { qlo[k][sl_of[i]] = ql[i]; qhi[k][sl_of[i]] = qh[i]; }
       std::memcpy(&word[k], &nlo, 4);
     }
-    uint32_t desc = 0;
-    for (int i = 0; i < w.n; ++i) {
-      const uint32_t cnt = w.kid[i].hi - w.kid[i].lo + 1u;
-      desc |= (w.kid[i].leaf ? ((1u << 2) | (cnt - 1u)) : (2u << 2)) << (4 * i);
-    }
+    uint32_t imask = 0, lmask = 0, two = 0;
     const uint32_t base_tri = (uint32_t)(B.tris.size() / 12);
-    for (int i = 0; i < w.n; ++i) {
-      if (!w.kid[i].leaf) continue;
-      for (uint32_t t = w.kid[i].lo; t <= w.kid[i].hi; ++t) { B.tris.resize(B.tris.size() + 12); tri_record(t, &B.tris[B.tris.size() - 12]); }
+    for (int sl = 0; sl < kWide; ++sl) {
+      if (!w.used[sl]) continue;
+      const WChild& ch = w.slot[sl];
+      if (!ch.leaf) { imask |= 1u << sl; continue; }
+      lmask |= 1u << sl;
+      if (ch.hi - ch.lo + 1u == 2u) two |= 1u << sl;
+      for (uint32_t t = ch.lo; t <= ch.hi; ++t) { B.tris.resize(B.tris.size() + 12); tri_record(t, &B.tris[B.tris.size() - 12]); }
     }
-    word[3] = e[0] | (e[1] << 8) | (e[2] << 16) | ((desc & 0xffu) << 24);
+    word[3] = e[0] | (e[1] << 8) | (e[2] << 16) | (imask << 24);
     auto pack4 = [](const uint32_t* q) { return q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24); };
-    word[4] = pack4(qlo[0]); word[5] = pack4(qlo[1]); word[6] = pack4(qlo[2]); word[7] = pack4(qhi[0]);
-    word[8] = pack4(qhi[1]); word[9] = pack4(qhi[2]);
-    word[10] = (child_base[idx] & 0xffffffu) | ((desc >> 8) << 24);
-    word[11] = base_tri;
-    std::memcpy(&B.nodes[(size_t)idx * 12], word, 48);
+    for (int k = 0; k < 3; ++k) {
+      word[4 + 2 * k] = pack4(&qlo[k][0]); word[5 + 2 * k] = pack4(&qlo[k][4]);
+      word[10 + 2 * k] = pack4(&qhi[k][0]); word[11 + 2 * k] = pack4(&qhi[k][4]);
+    }
+    word[16] = child_base[idx]; word[17] = base_tri; word[18] = lmask | (two << 8);
+    std::memcpy(&B.nodes[(size_t)idx * kNodeWords], word, sizeof word);
   }
   B.max_depth = maxd;
   B.n_tri_records = (uint32_t)(B.tris.size() / 12);

@@ -6,4 +6,5 @@
   pbr_amd.dist    one-process-per-GPU tile sharding + RCCL framebuffer reduce
 """
 from . import dist, gltf, scene, scenes  # noqa: F401
-from .ptc import DEVICE_NONE, INTEGRATOR_PATH, INTEGRATOR_RASTER_COMPAT, PathTracer, PtcError, load_library  # noqa: F401
+from .ptc import (DEVICE_NONE, INTEGRATOR_PATH, INTEGRATOR_RASTER_COMPAT, INTEGRATOR_RASTER_GBUFFER16, Group, PathTracer, PtcError,  # noqa: F401
+                  comm_unique_id, load_library)

@@ -17,11 +17,15 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libptc.so")
+# PTC_LIB selects another build of the same library (the -DPT_STAMP / -DPT_DIAG diagnostic builds of tools/)
+LIB_PATH = os.environ.get("PTC_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libptc.so")
 
 DEVICE_NONE = -1  # PTC_DEVICE_NONE: description-only context (host flatten + BVH build; renders nothing)
 INTEGRATOR_PATH = 0
 INTEGRATOR_RASTER_COMPAT = 1
+INTEGRATOR_RASTER_GBUFFER16 = 2   # raster-compat lit from the reference's G-buffer formats (RGBA16F P/N, UNORM16 albedo)
+COMM_ID_BYTES = 128
+ABI_VERSION = 2
 
 # every symbol include/ptc.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
@@ -30,7 +34,10 @@ ABI_SYMBOLS = [
     "ptc_frame_begin", "ptc_frame_add_samples", "ptc_frame_resolve", "ptc_sync", "ptc_read_radiance_rgba32f",
     "ptc_radiance_device_ptr", "ptc_write_radiance_rgba32f", "ptc_tonemap_rgba8", "ptc_get_stats",
     "ptc_debug_trace_closest", "ptc_debug_trace_any", "ptc_debug_get_flat_scene", "ptc_debug_get_bvh", "ptc_debug_get_counters",
-    "ptc_debug_get_description", "ptc_debug_get_material", "ptc_debug_get_texture",
+    "ptc_debug_get_description", "ptc_debug_get_material", "ptc_debug_get_texture", "ptc_debug_get_internals",
+    "ptc_read_radiance_rgba16f", "ptc_radiance_rgba16f_device_ptr",
+    "ptc_comm_unique_id", "ptc_comm_init", "ptc_comm_reduce_radiance", "ptc_comm_destroy",
+    "ptc_group_create", "ptc_group_size", "ptc_group_ctx", "ptc_group_render", "ptc_group_last_error", "ptc_group_destroy",
 ]
 
 
@@ -103,6 +110,24 @@ def load_library():
     L.ptc_debug_get_description.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.ptc_debug_get_material.argtypes = [vp, C.c_int, fp, C.POINTER(C.c_int)]
     L.ptc_debug_get_texture.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), vp]
+    L.ptc_debug_get_internals.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.ptc_read_radiance_rgba16f.argtypes = [vp, C.POINTER(C.c_uint16)]
+    L.ptc_radiance_rgba16f_device_ptr.argtypes = [vp]
+    L.ptc_radiance_rgba16f_device_ptr.restype = vp
+    L.ptc_comm_unique_id.argtypes = [u8p]
+    L.ptc_comm_init.argtypes = [vp, u8p, C.c_int, C.c_int]
+    L.ptc_comm_reduce_radiance.argtypes = [vp, C.c_int]
+    L.ptc_comm_destroy.argtypes = [vp]
+    L.ptc_group_create.argtypes = [C.POINTER(C.c_int), C.c_int]
+    L.ptc_group_create.restype = vp
+    L.ptc_group_size.argtypes = [vp]
+    L.ptc_group_ctx.argtypes = [vp, C.c_int]
+    L.ptc_group_ctx.restype = vp
+    L.ptc_group_render.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int]
+    L.ptc_group_last_error.argtypes = [vp]
+    L.ptc_group_last_error.restype = C.c_char_p
+    L.ptc_group_destroy.argtypes = [vp]
+    L.ptc_group_destroy.restype = None
     _lib = L
     return L
 
@@ -112,10 +137,20 @@ def _f(a):
     return a, a.ctypes.data_as(C.POINTER(C.c_float))
 
 
+def comm_unique_id() -> bytes:
+    """ptc_comm_unique_id: the 128 bytes rank 0 ships to the other ranks before ptc_comm_init."""
+    L = load_library()
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    if L.ptc_comm_unique_id(buf) < 0:
+        raise PtcError(L.ptc_last_error(None).decode())
+    return bytes(buf)
+
+
 class PathTracer:
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, _handle=None):
         self._L = load_library()
-        self._h = self._L.ptc_create(int(device))
+        self._owned = _handle is None
+        self._h = self._L.ptc_create(int(device)) if _handle is None else _handle
         if not self._h:
             raise PtcError(self._L.ptc_last_error(None).decode())
         self.device = int(device)
@@ -123,7 +158,8 @@ class PathTracer:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._L.ptc_destroy(self._h)
+            if self._owned:
+                self._L.ptc_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -202,6 +238,26 @@ class PathTracer:
     def radiance_device_ptr(self) -> int:
         return int(self._L.ptc_radiance_device_ptr(self._h) or 0)
 
+    def read_radiance_f16(self):
+        """The radiance buffer as the reference's RGBA16F HdrImage holds it: (h, w, 4) float16."""
+        out = np.empty((self._h_px, self._w, 4), np.uint16)
+        self._ck(self._L.ptc_read_radiance_rgba16f(self._h, out.ctypes.data_as(C.POINTER(C.c_uint16))))
+        return out.view(np.float16)
+
+    def radiance_f16_device_ptr(self) -> int:
+        return int(self._L.ptc_radiance_rgba16f_device_ptr(self._h) or 0)
+
+    # ---- multi-GPU (RCCL through the C-ABI) ---------------------------------------------------------
+    def comm_init(self, unique_id: bytes, rank: int, n_ranks: int):
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        self._ck(self._L.ptc_comm_init(self._h, buf, rank, n_ranks))
+
+    def comm_reduce_radiance(self, root: int = 0):
+        self._ck(self._L.ptc_comm_reduce_radiance(self._h, root))
+
+    def comm_destroy(self):
+        self._ck(self._L.ptc_comm_destroy(self._h))
+
     def tonemap(self):
         out = np.empty((self._h_px, self._w, 4), np.uint8)
         self._ck(self._L.ptc_tonemap_rgba8(self._h, out.ctypes.data_as(C.POINTER(C.c_uint8))))
@@ -264,12 +320,64 @@ class PathTracer:
     def bvh(self):
         nn, nt = C.c_uint32(), C.c_uint32()
         self._ck(self._L.ptc_debug_get_bvh(self._h, C.byref(nn), C.byref(nt), None, None))
-        nodes = np.zeros((nn.value, 12), np.float32)
+        nodes = np.zeros((nn.value, 20), np.float32)     # 80-byte nodes
         tris = np.zeros((nt.value, 12), np.float32)
         self._ck(self._L.ptc_debug_get_bvh(self._h, None, None, nodes.ctypes.data_as(C.POINTER(C.c_float)), tris.ctypes.data_as(C.POINTER(C.c_float))))
         return nodes, tris
+
+    def internals(self):
+        buf = (C.c_uint64 * 8)()
+        self._ck(self._L.ptc_debug_get_internals(self._h, buf))
+        keys = ("events_created", "spans_waiting", "queue_cap", "per_batch", "pending", "trace_blocks_per_cu", "stack_lds")
+        return {k: int(buf[i]) for i, k in enumerate(keys)}
 
     def raw_counters(self):
         buf = (C.c_uint64 * 32)()
         n = self._ck(self._L.ptc_debug_get_counters(self._h, buf, 32))
         return [int(buf[i]) for i in range(n)]
+
+
+class Group:
+    """ptc_group: one process driving several GPUs (n contexts + ncclCommInitAll).  `ctx(i)` is a PathTracer view of
+    device i's context; load the same scene into each, then `render` (tiles sharded, RCCL reduce onto device 0)."""
+
+    def __init__(self, device_ids):
+        self._L = load_library()
+        ids = (C.c_int * len(device_ids))(*[int(d) for d in device_ids])
+        self._g = self._L.ptc_group_create(ids, len(device_ids))
+        if not self._g:
+            raise PtcError(self._L.ptc_group_last_error(None).decode())
+        self.device_ids = [int(d) for d in device_ids]
+        self._ctx = [PathTracer(d, _handle=self._L.ptc_group_ctx(self._g, i)) for i, d in enumerate(self.device_ids)]
+
+    def __len__(self):
+        return int(self._L.ptc_group_size(self._g))
+
+    def ctx(self, i) -> PathTracer:
+        return self._ctx[i]
+
+    def load_scene(self, desc):
+        for c in self._ctx:
+            c.load_scene(desc)
+        return self
+
+    def render(self, w, h, spp, seed=1, max_bounces=8, integrator=INTEGRATOR_PATH):
+        rc = self._L.ptc_group_render(self._g, w, h, spp, seed, max_bounces, integrator)
+        if rc < 0:
+            raise PtcError(f"ptc error {rc}: {self._L.ptc_group_last_error(self._g).decode()}")
+        for c in self._ctx:
+            c._w, c._h_px = w, h
+        return self._ctx[0].read_radiance()
+
+    def close(self):
+        if getattr(self, "_g", None):
+            for c in self._ctx:
+                c._h = None
+            self._L.ptc_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

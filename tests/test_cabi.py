@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol(pbr):
     for sym in declared:
         assert hasattr(L, sym), f"libptc.so does not export {sym}"
     assert sorted(pbr.ptc.ABI_SYMBOLS) == declared
-    assert L.ptc_abi_version() == 1
+    assert L.ptc_abi_version() == pbr.ptc.ABI_VERSION == 2
     gl = open(os.path.join(ROOT, "include", "ptc_gltf.h")).read()
     for sym in set(re.findall(r"\b(ptc_(?:gltf|png)_[a-z0-9_]+)\s*\(", gl)):
         assert hasattr(pbr.gltf._load(), sym), f"libptc_gltf.so does not export {sym}"
@@ -40,7 +40,11 @@ def test_no_cpu_fallback(pbr):
                  lambda: pt.trace_closest(np.zeros((1, 3)), np.array([[0, 0, -1.0]]))):
         with pytest.raises(pbr.PtcError, match="no device|needs a gfx950"):
             call()
-    assert pt.radiance_device_ptr() == 0
+    assert pt.radiance_device_ptr() == 0 and pt.radiance_f16_device_ptr() == 0
+    with pytest.raises(pbr.PtcError, match="no device|needs a gfx950"):
+        pt.read_radiance_f16()
+    with pytest.raises(pbr.PtcError, match="no device|needs a gfx950"):
+        pt.comm_init(bytes(128), 0, 1)
 
 
 def test_argument_errors_are_codes_and_text(pbr):
@@ -112,3 +116,25 @@ def test_plain_c99_client_links_and_fails_cleanly_without_a_device(pbr, tmp_path
     r = subprocess.run([_build_c_client(tmp_path), "-1"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "4 triangles" in r.stdout and "2 emitters" in r.stdout and "no CPU path" in r.stdout
+
+
+def test_cmake_build_of_the_host(pbr, tmp_path):
+    """north_star: "the host stays C++/CMake".  physically-based-renderer_amd/CMakeLists.txt configures with hipcc as the C++
+    compiler, builds libptc.so + the ptc_render CLI + the C99 client, the library exports the whole C-ABI and the client runs
+    against it (description-only device: no GPU here)."""
+    import shutil
+    import subprocess
+
+    if not shutil.which("cmake"):
+        pytest.skip("cmake not installed")
+    src, bld = os.path.join(ROOT, "physically-based-renderer_amd"), str(tmp_path / "b")
+    r = subprocess.run(["cmake", "-S", src, "-B", bld, "-DCMAKE_CXX_COMPILER=/opt/rocm/bin/hipcc", "-DCMAKE_BUILD_TYPE=Release"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run(["cmake", "--build", bld, "-j", "4"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    L = C.CDLL(os.path.join(bld, "libptc.so"))
+    for sym in pbr.ptc.ABI_SYMBOLS:
+        assert hasattr(L, sym), sym
+    r = subprocess.run([os.path.join(bld, "c_client"), "-1"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "4 triangles" in r.stdout and "no CPU path" in r.stdout, r.stdout + r.stderr
+    assert os.path.exists(os.path.join(bld, "ptc_render"))

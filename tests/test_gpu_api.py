@@ -1,0 +1,268 @@
+"""The C-ABI's frame / output / multi-GPU contract on a real MI355X (everything through include/ptc.h):
+progressive resolve, deferred batching and queue sizing, the bounded event pool, the RGBA16F hand-off of the
+reference's HdrImage format, the G-buffer-format raster pass, RCCL through the C-ABI, and BASELINE configs 2 and 5
+at their full sizes."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from conftest import ROOT, rel_l2  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+COUNTERS = ("paths", "segments", "shadow_rays", "hits", "node_visits_closest", "tri_tests_closest", "node_visits_any", "tri_tests_any", "algorithmic_bytes")
+
+
+@pytest.fixture(scope="module")
+def gpu(pbr):
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return pbr
+
+
+def _bits_equal(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+def test_progressive_resolve_shows_the_k_sample_frame(gpu, ora):
+    """INTEGRATION.md §2's viewer loop: frame_begin(budget); add_samples(1); resolve; read — after k of N samples the
+    buffer holds the k-sample image (divisor = samples so far, not the budget), and the budget is enforced."""
+    d = gpu.scenes.sphere_scene(32, 17)
+    pt, o = gpu.PathTracer(0).load_scene(d), ora.Oracle().load_scene(d)
+    w, h, budget = 96, 64, 6
+    pt.frame_begin(w, h, budget, 9, 4, 0)
+    for k in range(1, budget + 1):
+        pt.frame_add_samples(1)
+        pt.frame_resolve()
+        assert _bits_equal(pt.read_radiance(), o.render(w, h, k, seed=9, max_bounces=4)), k
+    with pytest.raises(gpu.PtcError, match="spp_total"):
+        pt.frame_add_samples(1)                                   # past the budget
+    pt.frame_resolve()                                            # the frame is still intact
+    assert _bits_equal(pt.read_radiance(), o.render(w, h, budget, seed=9, max_bounces=4))
+    # resolve before any sample: zeros, no division by zero
+    pt.frame_begin(w, h, 2, 9, 4, 0)
+    pt.frame_resolve()
+    assert (pt.read_radiance() == 0).all()
+
+
+def test_queues_follow_the_batches_and_events_stay_bounded(gpu):
+    """a still-camera loop that adds one sample per displayed frame at 1080p must not allocate queues for the
+    whole budget (it did: 47 GB) nor create HIP events without bound (it did: ~56 per call)."""
+    pt = gpu.PathTracer(0).load_scene(gpu.scenes.cornell_box())
+    w, h = 1920, 1080
+    pt.frame_begin(w, h, 4096, 1, 4, 0)
+    assert pt.internals()["queue_cap"] == 0 or pt.internals()["queue_cap"] <= w * h      # nothing sized by the budget
+    for _ in range(40):
+        pt.frame_add_samples(1)
+        pt.frame_resolve()
+        pt.sync()
+    it = pt.internals()
+    assert it["queue_cap"] == w * h and it["pending"] == 0
+    first = it["events_created"]
+    for _ in range(160):
+        pt.frame_add_samples(1)
+        pt.frame_resolve()
+    pt.sync()
+    it = pt.internals()
+    assert it["events_created"] <= max(first, 2 * 1024 + 64) and it["spans_waiting"] <= 1024 + 64
+    assert pt.stats()["paths"] == 200 * w * h and pt.internals()["spans_waiting"] == 0
+
+
+def test_small_calls_merge_into_full_batches(gpu, ora):
+    """Deferred batching: samples added in small calls are issued as full wavefront batches (launches as wide as one
+    big call's), a partial batch goes out at resolve; bits do not depend on how the samples were handed over."""
+    d = gpu.scenes.atrium(0.05)
+    pt = gpu.PathTracer(0).load_scene(d)
+    w, h, spp = 160, 90, 12
+    ref = pt.render(w, h, spp, seed=4)
+    n_big = pt.stats()["launches_trace_closest"]
+    pt.frame_begin(w, h, spp, 4, 8, 0)
+    per = pt.internals()["per_batch"]
+    assert per >= spp                                                  # a small frame: everything fits one batch
+    for _ in range(spp):
+        pt.frame_add_samples(1)
+    assert pt.internals()["pending"] == spp                            # nothing issued yet
+    pt.frame_resolve()
+    assert _bits_equal(pt.read_radiance(), ref)
+    assert pt.stats()["launches_trace_closest"] == n_big               # one batch, not twelve
+    os.environ["PTC_BATCH_PATHS"] = str(w * h * 5 * 2)                 # per_batch = 5 samples
+    try:
+        small = gpu.PathTracer(0).load_scene(d)
+        small.frame_begin(w, h, spp, 4, 8, 0)
+        assert small.internals()["per_batch"] == 5
+        for k in range(spp):
+            small.frame_add_samples(1)
+            assert small.internals()["pending"] == (k + 1) % 5
+        small.frame_resolve()
+        assert _bits_equal(small.read_radiance(), ref)
+        assert small.stats()["launches_trace_closest"] == 3 * (8 + 1)  # batches of 5, 5 and 2 samples
+    finally:
+        del os.environ["PTC_BATCH_PATHS"]
+
+
+def test_rgba16f_output_matches_numpy_float16(gpu):
+    """The reference's lighting target / HdrImage is RGBA16F (PbrRenderSystem.hpp:21, HdrImage.cpp:20): the half buffer is
+    the fp32 buffer rounded to nearest even — numpy's float16 conversion — including denormals, overflow and inf."""
+    pt = gpu.PathTracer(0).load_scene(gpu.scenes.cornell_box())
+    w, h = 64, 48
+    img = pt.render(w, h, 4, seed=2)
+    with np.errstate(over="ignore"):
+        assert np.array_equal(pt.read_radiance_f16().view(np.uint16), img.astype(np.float16).view(np.uint16))
+    rng = np.random.default_rng(3)
+    special = np.array([0.0, -0.0, 1.0, -1.0, 65504.0, 65519.9, 65520.0, 65536.0, 1e9, -1e9, np.inf, -np.inf, 6.1035156e-05, 6.0975552e-05, 5.9604645e-08,
+                        2.9802322e-08, 2.9802326e-08, 8.9406967e-08, 1e-10, 0.33325195, 0.33337402, 2049.0, 2051.0, 1.0009766, 1.0004883, 1.0014648], np.float32)
+    vals = np.concatenate([special, (rng.standard_normal(3000) * 10.0 ** rng.uniform(-9, 6, 3000)).astype(np.float32),
+                           rng.integers(0, 2 ** 32, w * h * 4, dtype=np.uint64).astype(np.uint32).view(np.float32)])[: w * h * 4]
+    vals = np.where(np.isnan(vals), np.float32(1.5), vals).astype(np.float32).reshape(h, w, 4)
+    pt.write_radiance(vals)
+    with np.errstate(over="ignore"):
+        want = vals.astype(np.float16).view(np.uint16)
+    got = pt.read_radiance_f16().view(np.uint16)
+    assert np.array_equal(got, want), np.argwhere(got != want)[:5]
+    nan = vals.copy()
+    nan[0, 0, 0] = np.nan
+    pt.write_radiance(nan)
+    assert np.isnan(pt.read_radiance_f16()[0, 0, 0])
+    # the device-pointer form hands the same bytes to a consumer on the GPU (the viewer shim's staged copy)
+    import torch
+
+    ptr = pt.radiance_f16_device_ptr()
+    assert ptr
+    t = torch.as_tensor(gpu.dist._DevArray(ptr, w * h * 2), device="cuda:0")   # 8 bytes per pixel, viewed as 2 floats: compare raw bytes
+    raw = np.frombuffer(t.cpu().numpy().tobytes(), np.uint16).reshape(h, w, 4)
+    assert np.array_equal(raw, pt.read_radiance_f16().view(np.uint16))
+
+
+@pytest.mark.parametrize("name,kw,w,h", [("two_tris_sphere", {}, 64, 64), ("sphere10k", {}, 101, 67), ("textured_objects", {}, 96, 96),
+                                         ("textured_atrium", {"scale": 0.05, "tex_size": 128, "env_size": (64, 32)}, 160, 90)])
+def test_raster_gbuffer16_matches_the_oracle(gpu, ora, name, kw, w, h):
+    """GBuffer.hpp:13-16: the reference lights from RGBA16F positions/normals and UNORM16 albedo and writes RGBA16F."""
+    d = gpu.scenes.by_name(name, **kw)
+    pt, o = gpu.PathTracer(0).load_scene(d), ora.Oracle().load_scene(d)
+    g = pt.render(w, h, 1, integrator=gpu.INTEGRATOR_RASTER_GBUFFER16)
+    c = o.render(w, h, 1, integrator=2)
+    assert _bits_equal(g, c)
+    plain = pt.render(w, h, 1, integrator=gpu.INTEGRATOR_RASTER_COMPAT)
+    assert not np.array_equal(g, plain) and rel_l2(g, plain) < 2e-2         # the quantisation is visible, and small
+    pt.render(w, h, 1, integrator=gpu.INTEGRATOR_RASTER_GBUFFER16)
+    with np.errstate(over="ignore"):
+        assert np.array_equal(pt.read_radiance_f16().view(np.uint16), c.astype(np.float16).view(np.uint16))   # the RGBA16F lighting target
+
+
+def test_rccl_through_the_c_abi_single_rank(gpu):
+    """The RCCL code path of the C-ABI executes on the one card: unique id, ncclCommInitRank(world 1), ncclReduce in place
+    on the radiance buffer (x + nothing = x), destroy; and the one-process group API (ncclCommInitAll over one device)."""
+    pt = gpu.PathTracer(0).load_scene(gpu.scenes.cornell_box())
+    ref = pt.render(96, 64, 4, seed=6)
+    uid = gpu.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    with pytest.raises(gpu.PtcError, match="no communicator"):
+        pt.comm_reduce_radiance(0)
+    pt.comm_init(uid, 0, 1)
+    with pytest.raises(gpu.PtcError):
+        pt.comm_init(uid, 0, 1)                                    # already has one
+    pt.frame_begin(96, 64, 4, 6, 8, 0)
+    pt.frame_add_samples(4)
+    pt.frame_resolve()
+    pt.comm_reduce_radiance(0)
+    with pytest.raises(gpu.PtcError):
+        pt.comm_reduce_radiance(3)                                 # bad root
+    pt.sync()
+    assert _bits_equal(pt.read_radiance(), ref)
+    pt.comm_destroy()
+    g = gpu.Group([0]).load_scene(gpu.scenes.cornell_box())
+    assert len(g) == 1 and _bits_equal(g.render(96, 64, 4, seed=6), ref)
+    g.close()
+    with pytest.raises(gpu.PtcError):
+        gpu.Group([99])
+
+
+def test_torch_nccl_backend_world_size_1(gpu):
+    """bench.py's N>1 plumbing with the real backend: torch.distributed 'nccl' (= RCCL) initialised with device_id, the
+    zero-copy radiance tensor reduced with dist.reduce, and the C-ABI communicator created beside torch's — in a child
+    process, so that this test process keeps no process group."""
+    code = r"""
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'physically-based-renderer_amd'))
+import numpy as np, torch, torch.distributed as dist
+import pbr_amd
+from pbr_amd import dist as pdist
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+pt = pbr_amd.PathTracer(0).load_scene(pbr_amd.scenes.cornell_box())
+ref = pt.render(64, 64, 2, seed=1)
+box = [pbr_amd.comm_unique_id()]
+dist.broadcast_object_list(box, src=0)
+pt.comm_init(box[0], 0, 1)
+pt.frame_begin(64, 64, 2, 1, 8, 0); pt.frame_add_samples(2); pt.frame_resolve()
+pt.comm_reduce_radiance(0); pt.sync()
+t = pdist.radiance_tensor(pt, 64, 64)
+dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+tt = torch.tensor([1.5], dtype=torch.float64, device='cuda'); dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+torch.cuda.synchronize()
+assert np.array_equal(pt.read_radiance(), ref) and float(tt.item()) == 1.5
+dist.barrier(); dist.destroy_process_group()
+print('NCCL_OK')
+""" % (ROOT, ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "NCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_config2_full_size(gpu, ora):
+    """BASELINE configs[1] at its stated size: ~10 k-triangle GGX sphere, 1024x1024x256 spp (268 M paths) — run-to-run
+    determinism, counter identities, tile-shard sum — and 1024x1024x2 against the oracle, bits and counters."""
+    d = gpu.scenes.sphere_scene()
+    pt, o = gpu.PathTracer(0).load_scene(d), ora.Oracle().load_scene(d)
+    w = h = 1024
+    g = pt.render(w, h, 2, seed=2, max_bounces=8)
+    c = o.render(w, h, 2, seed=2, max_bounces=8, n_threads=ora.hw_threads())
+    assert _bits_equal(g, c)
+    for k in COUNTERS:
+        assert pt.stats()[k] == o.stats()[k], k
+    a = pt.render(w, h, 256, seed=2, max_bounces=8)
+    sa = pt.stats()
+    assert np.isfinite(a).all() and (a[..., 3] == 1).all() and a[..., :3].min() >= 0
+    assert sa["paths"] == w * h * 256 and sa["hits"] <= sa["segments"] and sa["shadow_rays"] <= sa["hits"] and sa["segments"] >= sa["paths"]
+    b = pt.render(w, h, 256, seed=2, max_bounces=8)
+    assert _bits_equal(a, b) and all(pt.stats()[k] == sa[k] for k in COUNTERS)
+    acc = np.zeros_like(a)
+    for r in range(2):
+        pt.frame_begin(w, h, 256, 2, 8, 0, tile_rank=r, tile_count=2)
+        pt.frame_add_samples(256)
+        pt.frame_resolve()
+        acc += pt.read_radiance()
+    assert _bits_equal(acc, a)
+    assert rel_l2(a, c) < 0.25                                   # 256 spp and 2 spp estimate the same image
+
+
+def test_config5_full_size(gpu, ora):
+    """BASELINE configs[4] at full size: the 250 k-triangle textured atrium, 1024^2 albedo / normal / metal-rough textures,
+    2048x1024 environment light, 1920x1080: 2 spp against the oracle (bits + counters), properties at 64 spp."""
+    d = gpu.scenes.textured_atrium()
+    d.camera.aspect = 1920 / 1080
+    assert d.textures[0].shape[:2] == (1024, 1024) and d.env.shape[:2] == (1024, 2048) and abs(d.n_triangles - 250_000) < 5_000
+    pt, o = gpu.PathTracer(0).load_scene(d), ora.Oracle().load_scene(d)
+    w, h = 1920, 1080
+    g = pt.render(w, h, 2, seed=5, max_bounces=8)
+    c = o.render(w, h, 2, seed=5, max_bounces=8, n_threads=ora.hw_threads())
+    assert _bits_equal(g, c), int((g != c).any(-1).sum())
+    for k in COUNTERS:
+        assert pt.stats()[k] == o.stats()[k], k
+    assert np.array_equal(pt.tonemap(), ora.tonemap_rgba8(c))
+    a = pt.render(w, h, 64, seed=5, max_bounces=8)
+    sa = pt.stats()
+    assert np.isfinite(a).all() and a[..., :3].min() >= 0 and sa["paths"] == w * h * 64
+    assert _bits_equal(pt.render(w, h, 64, seed=5, max_bounces=8), a) and all(pt.stats()[k] == sa[k] for k in COUNTERS)
+    acc = np.zeros_like(a)
+    for r in range(4):
+        pt.frame_begin(w, h, 64, 5, 8, 0, tile_rank=r, tile_count=4)
+        pt.frame_add_samples(64)
+        pt.frame_resolve()
+        acc += pt.read_radiance()
+    assert _bits_equal(acc, a)

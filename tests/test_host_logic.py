@@ -10,7 +10,7 @@ EMPTY = -(2 ** 31)
 
 
 def _decode_product(nodes, tris):
-    """Product node = 12 words (48 B, layout in ptc_scene.cpp) → per node: org bits, exponents, and per child
+    """Product node = 20 words (80 B, layout in ptc_scene.cpp) → per node: org bits, exponents, and per slot
     (type, qlo[3], qhi[3], interior index or leaf triangle-record range)."""
     w = nodes.view(np.uint32)
     out = []
@@ -18,20 +18,21 @@ def _decode_product(nodes, tris):
         org = tuple(int(x) for x in w[i, 0:3])
         ew = int(w[i, 3])
         e = (ew & 255, (ew >> 8) & 255, (ew >> 16) & 255)
-        desc = (ew >> 24) | ((int(w[i, 10]) >> 24) << 8)
-        next_child, next_tri = int(w[i, 10]) & 0xFFFFFF, int(w[i, 11])
+        imask = ew >> 24
+        next_child, next_tri = int(w[i, 16]), int(w[i, 17])
+        lmask, two = int(w[i, 18]) & 255, (int(w[i, 18]) >> 8) & 255
+        assert imask & lmask == 0 and two & ~lmask == 0 and int(w[i, 18]) >> 16 == 0 and int(w[i, 19]) == 0
         kids = []
-        for c in range(4):
-            d = (desc >> (4 * c)) & 15
-            typ, cm1 = d >> 2, d & 3
-            q = [(int(w[i, 4 + k]) >> (8 * c)) & 255 for k in range(6)]          # qlo.xyz, qhi.xyz
-            if typ == 2:
+        for c in range(8):
+            q = [(int(w[i, 4 + 2 * k + c // 4]) >> (8 * (c % 4))) & 255 for k in range(6)]          # qlo.xyz, qhi.xyz
+            if (imask >> c) & 1:
                 kids.append((2, q, next_child, ()))
                 next_child += 1
-            elif typ == 1:
-                prims = tuple(int(x) for x in tris[next_tri:next_tri + cm1 + 1, 3].view(np.uint32))
+            elif (lmask >> c) & 1:
+                cnt = 1 + ((two >> c) & 1)
+                prims = tuple(int(x) for x in tris[next_tri:next_tri + cnt, 3].view(np.uint32))
                 kids.append((1, q, next_tri, prims))
-                next_tri += cm1 + 1
+                next_tri += cnt
             else:
                 kids.append((0, q, -1, ()))
         out.append((org, e, kids))
@@ -44,9 +45,9 @@ def _decode_oracle(nodes, tris):
     for i in range(w.shape[0]):
         org = tuple(int(x) for x in w[i, 0:3])
         e = tuple(int(x) for x in w[i, 3:6])
-        qlo, qhi, code = w[i, 6:18].reshape(3, 4), w[i, 18:30].reshape(3, 4), w[i, 30:34].view(np.int32)
+        qlo, qhi, code = w[i, 6:30].reshape(3, 8), w[i, 30:54].reshape(3, 8), w[i, 54:62].view(np.int32)
         kids = []
-        for c in range(4):
+        for c in range(8):
             q = [int(qlo[k, c]) for k in range(3)] + [int(qhi[k, c]) for k in range(3)]
             k = int(code[c])
             if k == EMPTY:
@@ -68,7 +69,7 @@ def _canon(decoded):
     for org, e, kids in decoded:
         r = list(org) + list(e)
         for typ, q, _, prims in kids:
-            r += [typ] + q + list(prims) + [-1] * (4 - len(prims))
+            r += [typ] + q + list(prims) + [-1] * (2 - len(prims))
         rows.append(r)
     a = np.asarray(rows, np.int64)
     return a[np.lexsort(a.T[::-1])]
@@ -125,7 +126,7 @@ def test_bvh_is_a_valid_partition(pbr):
         return exact[i]
 
     for i, (org, e, kids) in enumerate(dec):
-        assert kids[0][0] != 0 and kids[1][0] != 0              # at least two children, slots fill from the front
+        assert sum(1 for k in kids if k[0] != 0) >= 2           # at least two children
         nxt = None
         for typ, q, ref, prims in kids:
             if typ == 0:
@@ -134,7 +135,7 @@ def test_bvh_is_a_valid_partition(pbr):
             lo, hi = box(org, e, q)                             # quantised box: must contain the exact one
             if typ == 1:
                 cnt = len(prims)
-                assert 1 <= cnt <= 4
+                assert 1 <= cnt <= 2
                 seen[ref:ref + cnt] += 1
                 assert (lo_t[ref:ref + cnt] >= lo - 1e-4).all() and (hi_t[ref:ref + cnt] <= hi + 1e-4).all()   # e1/e2 are rounded differences
             else:
@@ -146,7 +147,7 @@ def test_bvh_is_a_valid_partition(pbr):
                 ext = np.maximum(chi - clo, 1e-6)
     assert (seen == 1).all()                                    # every triangle record in exactly one leaf
     assert interior_refs[0] == 0 and (interior_refs[1:] == 1).all()   # a tree rooted at node 0
-    assert n_children / len(dec) > 3.0                          # the greedy collapse fills the nodes
+    assert n_children / len(dec) > 4.0                          # the greedy collapse fills the nodes (only all-leaf nodes stay short)
     prim = tris[:, 3].view(np.uint32)
     assert np.array_equal(np.sort(prim), np.arange(n_rec))       # a permutation of the primitives
 

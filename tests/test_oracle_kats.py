@@ -155,3 +155,61 @@ def test_tile_owner_matches_python_walk(ora, pbr, w, h, n):
     for _ in range(200):
         x, y = int(rng.integers(0, w)), int(rng.integers(0, h))
         assert masks[ora.tile_owner(w, h, x, y, n)][y, x]
+
+
+def test_float16_rounding_equals_numpy(ora):
+    """fp32 -> fp16 of the RGBA16F contract (PbrRenderSystem.hpp:21, GBuffer.hpp:13-14): round to nearest even, like numpy's
+    float16 — every half round-trips, every midpoint between neighbouring halves ties to even, random floats and bit patterns."""
+    import numpy as np
+
+    for h in range(0, 65536, 1):
+        ref = np.array([h], np.uint16).view(np.float16).astype(np.float32)[0]
+        f = ora.f16_to_f32(h)
+        if np.isnan(ref):
+            assert np.isnan(f)
+            continue
+        assert np.float32(f).view(np.uint32) == ref.view(np.uint32) and ora.f32_to_f16(f) == h
+    with np.errstate(over="ignore"):
+        for h in range(0, 0x7C00, 7):
+            a, b = np.float64(ora.f16_to_f32(h)), np.float64(ora.f16_to_f32(h + 1))
+            mid = np.float32((a + b) / 2)
+            if np.float64(mid) == (a + b) / 2:
+                assert ora.f32_to_f16(mid) == int(mid.astype(np.float16).view(np.uint16)), h
+        rng = np.random.default_rng(1)
+        xs = (rng.standard_normal(20000) * 10.0 ** rng.uniform(-9, 6, 20000)).astype(np.float32)
+        bits = rng.integers(0, 2 ** 32, 20000, dtype=np.uint64).astype(np.uint32).view(np.float32)
+        for arr in (xs, bits):
+            want = arr.astype(np.float16).view(np.uint16)
+            for x, r in zip(arr, want):
+                g = ora.f32_to_f16(x)
+                if np.isnan(x):
+                    assert (g & 0x7C00) == 0x7C00 and (g & 0x3FF)
+                else:
+                    assert g == r, (x, hex(g), hex(int(r)))
+
+
+def test_raster_gbuffer16_is_the_quantised_lighting_pass(ora, pbr):
+    """Integrator 2 = lighting.glsl:19-29 fed from the reference's G-buffer formats (GBuffer.hpp:13-16): recomputed here in numpy
+    float64 from the fp32 raster-compat inputs of one flat-shaded pixel row: P and N rounded to fp16, albedo to UNORM16."""
+    import numpy as np
+
+    d = pbr.scenes.two_triangles_and_sphere()
+    o = ora.Oracle().load_scene(d)
+    a = o.render(64, 64, 1, integrator=1)
+    b = o.render(64, 64, 1, integrator=2)
+    hit = a[..., 3] > 0
+    assert (b[~hit] == 0).all() and hit.sum() > 500
+    assert not np.array_equal(a, b)
+    err = np.abs(a[hit] - b[hit]).max()
+    assert 0 < err < 2e-2                                       # quantisation of P (|P| < 8 -> ulp16 <= 2^-8), N and albedo: small but there
+    # a material whose albedo is exactly representable in UNORM16 and a head-on plane: only P and N rounding remain
+    sc = pbr.scene
+    v, i = pbr.scenes._quad((-4, -4, -2), (4, -4, -2), (4, 4, -2), (-4, 4, -2))
+    for base in ((1.0, 0.0, 1.0, 1.0), (0.2, 0.4, 0.6, 1.0)):
+        dd = sc.SceneDesc([sc.Material(base, 0.0, 1.0)], [sc.MeshDesc(v, i, 0)], [sc.InstanceDesc(0, (0, 0, 0), (1, 0, 0, 0), (1, 1, 1))],
+                          sc.CameraDesc((0, 0, 0), (0, 0, -1), 1.0, 1.0))
+        oo = ora.Oracle().load_scene(dd)
+        img = oo.render(9, 9, 1, integrator=2)
+        c = img[4, 4]                                           # centre pixel: P = (0,0,-2) exactly, N = (0,0,1): NdotV = 1, spec = 1
+        q = np.round(np.clip(np.asarray(base, np.float64), 0, 1) * 65535) / 65535
+        assert np.allclose(c, q * 1.0 + 1.0, rtol=0, atol=2e-7), (c, q)
