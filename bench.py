@@ -114,7 +114,7 @@ def main():
     reduce_impl = None
     if world > 1:
         reduce_impl = "torch.distributed.reduce"
-        if args.reduce == "cabi":
+        if args.reduce == "cabi" and args.backend == "nccl" and not args.share_device:     # RCCL needs one GPU per rank
             # rank 0 makes the RCCL unique id (C-ABI), torch.distributed ships it, every rank joins the communicator
             ok, uid = 1, None
             if rank == 0:

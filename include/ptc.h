@@ -252,11 +252,12 @@ int ptc_debug_get_texture(ptc_ctx*, int index, int* w, int* h, uint8_t* rgba);
  * loop-iteration diagnostics a -DPT_DIAG build fills).  Returns the number of counters the library keeps. */
 int ptc_debug_get_counters(ptc_ctx*, uint64_t* out, int n);
 
-/* The flattened 8-wide BVH as committed: nodes (n_nodes*20 32-bit words = 80 bytes each: org.xyz, packed exponents +
- * interior-slot mask, 8-bit quantised child planes of the 8 slots, child / triangle base indices, leaf-slot masks; layout
- * in csrc/ptc_scene.cpp) and triangle records in node order (n_tris*12 floats: v0,prim | e1,class | e2,0).
+/* The flattened 8-wide BVH as committed: ONE array of n_units 16-byte units (n_units*4 32-bit words) holding 64-byte nodes
+ * (origin on a 16-bit grid over the scene box, exponents, interior / leaf slot masks, the unit address of the children block,
+ * 8-bit quantised child planes of the 8 slots) and 48-byte triangle records (v0,prim | e1,class | e2,0) inside the children
+ * blocks; the root is the node at unit 0 (layout in csrc/ptc_scene.cpp).  grid: scene_lo.xyz, step.xyz of the origin grid.
  * Pass NULL to query sizes only. */
-int ptc_debug_get_bvh(ptc_ctx*, uint32_t* n_nodes, uint32_t* n_tris, float* nodes, float* tris);
+int ptc_debug_get_bvh(ptc_ctx*, uint32_t* n_nodes, uint32_t* n_tris, uint32_t* n_units, float* units, float grid[6]);
 
 /* Context internals for tests of the host logic: [0] HIP events created so far, [1] timing spans waiting to be
  * collected, [2] queue capacity (paths) of a lane, [3] samples of one full batch, [4] samples accepted but not yet

@@ -193,7 +193,7 @@ class Oracle:
 def _bvh(self):
     nn, nt = C.c_uint32(), C.c_uint32()
     self._ck(self._L.ora_get_bvh(self._h, C.byref(nn), C.byref(nt), None, None))
-    nodes = np.zeros((nn.value, 62), np.float32)
+    nodes = np.zeros((nn.value, 65), np.float32)
     tris = np.zeros((nt.value, 12), np.float32)
     self._ck(self._L.ora_get_bvh(self._h, None, None, nodes.ctypes.data_as(C.POINTER(C.c_float)), tris.ctypes.data_as(C.POINTER(C.c_float))))
     return nodes, tris

@@ -194,10 +194,13 @@ typedef struct {                 /* 64-byte interior node of the BINARY tree (si
 /* 8-wide node with quantised child boxes: the traversal structure (the binary node_t above is only the
  * build's intermediate).  A child plane on axis k is  org[k] + q * 2^(e[k]-127)  with q an 8-bit integer
  * (lower planes rounded down, upper planes rounded up, so the quantised box contains the exact one).
+ * The node's own origin is kept to 16 bits per axis on a grid over the scene box (org = grid_lo + oq * grid_step,
+ * rounded down), which lets the product store a node in 64 bytes.
  * A child sits in the slot whose octant it lies in (assign_slots below), so a ray can order the slots by
  * its direction signs alone.  code: >=0 node index; <0 leaf (as in node_t); ORA_EMPTY unused slot. */
 typedef struct {
-  float org[3];
+  float org[3];                              /* = fmaf(oq, grid_step, grid_lo): the node's origin on the scene's 16-bit grid */
+  uint32_t oq[3];                            /* 0..65535 */
   uint32_t e[3];
   uint32_t qlo[3][ORA_W], qhi[3][ORA_W];     /* [axis][slot], values 0..255 */
   int32_t code[ORA_W];
@@ -228,6 +231,7 @@ struct ora_ctx {
   int32_t* prim_light;                 /* original prim id → light index or -1 */
   light_t* lights; float* cdf; uint32_t n_lights;
   float scene_lo[3], scene_hi[3]; float ray_eps;
+  float grid_step[3];                  /* node origins: scene_lo + q * grid_step, q = 0..65535 */
   /* lat-long environment light: radiance texels, pmf, row-marginal and per-row conditional cdfs */
   float* env_px; int env_w, env_h; float* env_pmf; float* env_marg; float* env_cond; int env_ok;
   ora_stats stats;
@@ -668,8 +672,14 @@ static int32_t widen(ora_ctx* c, const dp_t* dp, int32_t bin_idx, uint32_t depth
   for (int k = 0; k < 3; ++k) {
     float clo[ORA_W], chi[ORA_W]; uint32_t qlo[ORA_W], qhi[ORA_W];
     for (int i = 0; i < n; ++i) { clo[i] = list[i].lo[k]; chi[i] = list[i].hi[k]; }
-    w.org[k] = nlo3[k];
-    quantize_axis(clo, chi, n, nlo3[k], nhi3[k], &w.e[k], qlo, qhi);
+    /* origin on the 16-bit scene grid, rounded down: the largest q with fmaf(q, step, lo) <= the node's lower bound */
+    float fq = floorf((nlo3[k] - c->scene_lo[k]) / c->grid_step[k]);
+    if (fq < 0.0f) fq = 0.0f;
+    if (fq > 65535.0f) fq = 65535.0f;
+    uint32_t oq = (uint32_t)fq;
+    while (oq > 0u && fmaf((float)oq, c->grid_step[k], c->scene_lo[k]) > nlo3[k]) --oq;
+    w.oq[k] = oq; w.org[k] = fmaf((float)oq, c->grid_step[k], c->scene_lo[k]);
+    quantize_axis(clo, chi, n, w.org[k], nhi3[k], &w.e[k], qlo, qhi);
     for (int sl = 0; sl < ORA_W; ++sl) { w.qlo[k][sl] = 255; w.qhi[k][sl] = 0; }
     for (int i = 0; i < n; ++i) { w.qlo[k][slot_of[i]] = qlo[i]; w.qhi[k][slot_of[i]] = qhi[i]; }
   }
@@ -739,6 +749,7 @@ int ora_scene_commit(ora_ctx* c) {
   }
   float diag = fmax2(fmax2(c->scene_hi[0] - c->scene_lo[0], c->scene_hi[1] - c->scene_lo[1]), c->scene_hi[2] - c->scene_lo[2]);
   c->ray_eps = 1e-4f * fmax2(diag, 1e-6f);
+  for (int k = 0; k < 3; ++k) { float st = (c->scene_hi[k] - c->scene_lo[k]) / 65535.0f; c->grid_step[k] = st > 0.0f ? st : 1.0f; }
   c->order = (uint32_t*)malloc(4u * n);
   for (uint32_t i = 0; i < n; ++i) c->order[i] = i;      /* initial order: original primitive order */
   c->nodes = (node_t*)calloc(n > 1 ? n : 1, sizeof(node_t));

@@ -57,7 +57,8 @@ int ora_trace_any(ora_ctx*, const float* origins, const float* dirs, const float
 int ora_get_flat_scene(ora_ctx*, uint32_t* n_verts, uint32_t* n_tris, void* verts48,
                        uint32_t* indices, int32_t* tri_material);
 
-/* BVH as built: 8-wide quantised nodes, n_nodes*62 32-bit words each: org[3] (float bits), e[3], qlo[3][8], qhi[3][8],
+/* BVH as built: 8-wide quantised nodes, n_nodes*65 32-bit words each: org[3] (float bits), oq[3] (the origin's 16-bit grid
+ * coordinates: org = fmaf(oq, (scene_hi - scene_lo) / 65535, scene_lo)), e[3], qlo[3][8], qhi[3][8],
  * code[8] (>= 0 node index, < 0 leaf ~(first | (count-1)<<28), 0x80000000 empty slot; the product stores the same
  * information packed into 80 bytes; tests decode both), sorted triangles n_tris*12 floats (v0,prim | e1,class | e2,0).
  * NULL pointers to query sizes. */

@@ -21,18 +21,22 @@
 #define TRACE_BLOCK 256
 #endif
 #ifndef TRACE_MIN_WAVES
-#define TRACE_MIN_WAVES 7         // waves per SIMD the register allocator must leave room for (launch bounds)
+#define TRACE_MIN_WAVES 8         // waves per SIMD the register allocator must leave room for (launch bounds): 64 VGPRs; 8 instead of 7 blocks per CU: +4 %
 #endif
 #define TRACE_WAVES (TRACE_BLOCK / 64)
 #ifndef TRACE_CHUNK
 #define TRACE_CHUNK 512u          // rays per work-fetch atomic
 #endif
 #ifndef TRACE_REFILL_IDLE
-#define TRACE_REFILL_IDLE 4       // refill as soon as this many lanes are idle (1..24 swept: flat optimum 4..8, +1 % over 16)
+#define TRACE_REFILL_IDLE 12      // refill as soon as this many lanes are idle (8-wide tree: 4: -3 %, 8: -1 %, 20: -1.5 %, 32: -14 %)
 #endif
 #ifndef TRACE_NODE_MIN
 #define TRACE_NODE_MIN 40         // leave the node loop when fewer lanes than this are still at interior nodes
-#endif                            // while others wait at a leaf (keeps both phases well populated)
+#endif                            // while others wait at a leaf (keeps both phases well populated; 24: -6 %, 32: -1.5 %, 48: -3 %, 56: -18 %)
+#ifndef TRACE_COOP
+#define TRACE_COOP 0              // 0: every lane gathers its own node with four 16-byte loads.  1: a wave fetches its nodes cooperatively (four
+#endif                            // lanes per 64-byte node, LDS-DMA into a 4-KiB stage): a quarter of the address lookups, but measured 13 % SLOWER —
+                                  // the stage costs 3 blocks per CU of occupancy and the kernels are not bound by the gather rate
 #ifndef SHADE_BLOCK
 #define SHADE_BLOCK 512
 #endif
@@ -106,8 +110,16 @@ __global__ __launch_bounds__(256) void k_raygen(DevCamera cam, DevFrame fr, DevQ
 // =================================================================================================
 // traversal machinery shared by the closest-hit and any-hit kernels
 //
-// 8-wide BVH, 80-byte nodes (layout: ptc_scene.cpp).  A ray keeps ONE group of pending interior children in
-// registers — (base_child, hits<<8 | imask): the slots of one node that were hit and not yet entered — and the
+// 8-wide BVH in one array of 16-byte units: 64-byte nodes, 48-byte triangle records (layout: ptc_scene.cpp); addresses are
+// unit indices.  What bounds these kernels is the address-processing rate of the vector-memory path: a wave instruction that
+// gathers 16 bytes per lane from 64 unrelated lines costs ~50 cycles of a CU's texture-address unit whatever the L2 hit
+// rate (tools/gather_bench.hip: 45 GB/s per CU), while four adjacent lanes reading one contiguous 64-byte node cost a
+// quarter of the lookups (64 GB/s per CU, the L2->CU limit).  So a wave fetches its 64 nodes COOPERATIVELY: in pass j lane l
+// loads piece l&3 of the node of lane 16j + l/4, straight into LDS (global_load_lds_dwordx4: destination = wave-uniform
+// base + lane x 16, which lays the 64 nodes out contiguously), and every lane then reads its own node from LDS.  The top of
+// the tree (breadth-first prefix of the unit array) is staged in LDS once per block and read from there.
+// A ray keeps ONE group of pending interior children in
+// registers — (block address, hits<<8 | imask): the slots of one node that were hit and not yet entered — and the
 // older groups on a per-lane stack of 8-byte entries.  The first `L` entries live in LDS (stride 64 lanes:
 // ds_read/write_b64 is conflict-free at every mix of depths), deeper entries — rare: at most one group per tree level
 // is ever pending — go to a global overflow slab laid out [wave][depth][lane].  No per-child entry distance is kept and
@@ -159,31 +171,52 @@ PT_DEV void build_order_table(uint8_t* tab) {
   }
 }
 
-// One node visit: the 8 slots of node `cur` against [tmin, tlimit].  Returns the hit mask (bit s = slot s, empty slots
-// masked off) and the node's child/triangle bases and slot masks (imask | lmask<<8 | two<<16).
+// Cooperative fetch of the wave's nodes into its 4-KiB LDS stage (64 x 64 B): the node of lane o lands at stage + 64 o.
+// Lanes with cur < n_lds_units (staged prefix) or cur < 0 (no node wanted) are skipped.  `stage_addr` is the wave-uniform LDS
+// byte address of the stage.  Ends with s_waitcnt vmcnt(0): the compiler does not count asm loads.
+PT_DEV void fetch_nodes(const DevScene& sc, uint32_t stage_addr, int cur, uint32_t lane) {
+  const uint32_t piece = lane & 3u, sub = lane >> 2;
+  int ocur[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) ocur[j] = __builtin_amdgcn_ds_bpermute((int)((16u * (uint32_t)j + sub) << 2), cur);   // 4 crossbar reads in flight
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (ocur[j] >= (int)sc.n_lds_units) {
+      const float4* src = sc.recs + ((size_t)(uint32_t)ocur[j] + piece);
+      const uint32_t dst = stage_addr + 1024u * (uint32_t)j;
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// One node visit: the 8 slots of the node at LDS byte address `node_addr` (the wave's stage or the staged top of the tree)
+// against [tmin, tlimit].  Returns the hit mask (bit s = slot s, empty slots masked off), the node's children-block address
+// and its slot masks (imask | lmask<<8 | two<<16).
 // Per-ray constants of the slab test: the sign of each direction component says which of a child's two planes on that
 // axis is entered first, so near/far need no min/max (identical values to min(t0,t1) / max(t0,t1): fma is monotonic in
-// the plane coordinate).  plane distance = fma(q, 2^(e-127)·inv, fma(org, inv, -ood)).
-template <bool NODELETS>
-PT_DEV uint32_t node_visit(const DevScene& sc, const float4* lds_nodes, int cur, const ray_t& r, uint32_t oct, float tmin, float tlimit,
-                           uint32_t& base_child, uint32_t& base_tri, uint32_t& masks) {
-  // two explicit address spaces: a pointer that may be LDS or global compiles to FLAT loads, which occupy both the LDS and the
-  // vector-memory pipe and wait on both counters
+// the plane coordinate).  plane distance = fma(q, 2^(e-127)·inv, fma(org, inv, -ood)), org = fma(oq, grid_step, grid_lo).
+PT_DEV uint32_t node_visit(const DevScene& sc, uint32_t node_addr, int cur, const ray_t& r, uint32_t oct, float tmin, float tlimit,
+                           uint32_t& block, uint32_t& masks) {
   typedef float fx4 __attribute__((ext_vector_type(4)));
   typedef __attribute__((address_space(3))) const fx4 lds_f4;
   typedef __attribute__((address_space(1))) const fx4 glb_f4;
-  fx4 f0, f1, f2, f3, f4;
-  if (NODELETS && (uint32_t)cur < sc.n_nodelets) {
-    lds_f4* p = (lds_f4*)lds_nodes + (uint32_t)cur * 5u;          // ds_read_b128 × 5
-    f0 = p[0]; f1 = p[1]; f2 = p[2]; f3 = p[3]; f4 = p[4];
+  fx4 f0, f1, f2, f3;
+  if (TRACE_COOP || (uint32_t)cur < sc.n_lds_units) {
+    lds_f4* p = (lds_f4*)(uintptr_t)node_addr;                    // ds_read_b128 × 4
+    f0 = p[0]; f1 = p[1]; f2 = p[2]; f3 = p[3];
   } else {
-    glb_f4* p = (glb_f4*)sc.nodes + (size_t)cur * 5;               // global_load_dwordx4 × 5
-    f0 = p[0]; f1 = p[1]; f2 = p[2]; f3 = p[3]; f4 = p[4];
+    glb_f4* p = (glb_f4*)sc.recs + (uint32_t)cur;                 // global_load_dwordx4 × 4
+    f0 = p[0]; f1 = p[1]; f2 = p[2]; f3 = p[3];
   }
-  const uint32_t ew = __float_as_uint(f0.w);
-  const float ax = __uint_as_float((ew & 255u) << 23) * r.inv.x, ay = __uint_as_float(((ew >> 8) & 255u) << 23) * r.inv.y,
-              az = __uint_as_float(((ew >> 16) & 255u) << 23) * r.inv.z;
-  const float bx = pt_fma(f0.x, r.inv.x, -r.ood.x), by = pt_fma(f0.y, r.inv.y, -r.ood.y), bz = pt_fma(f0.z, r.inv.z, -r.ood.z);
+  const uint32_t w0 = __float_as_uint(f0.x), w1 = __float_as_uint(f0.y), w2 = __float_as_uint(f0.z);
+  const float ox = pt_fma((float)(w0 & 0xffffu), sc.grid_step[0], sc.grid_lo[0]), oy = pt_fma((float)(w0 >> 16), sc.grid_step[1], sc.grid_lo[1]),
+              oz = pt_fma((float)(w1 & 0xffffu), sc.grid_step[2], sc.grid_lo[2]);
+  const float ax = __uint_as_float(((w1 >> 16) & 255u) << 23) * r.inv.x, ay = __uint_as_float((w1 >> 24) << 23) * r.inv.y,
+              az = __uint_as_float((w2 & 255u) << 23) * r.inv.z;
+  const float bx = pt_fma(ox, r.inv.x, -r.ood.x), by = pt_fma(oy, r.inv.y, -r.ood.y), bz = pt_fma(oz, r.inv.z, -r.ood.z);
   const bool px = (oct & 1u) != 0u, py = (oct & 2u) != 0u, pz = (oct & 4u) != 0u;
   // [0]: slots 0-3, [1]: slots 4-7
   const uint32_t lx[2] = {__float_as_uint(f1.x), __float_as_uint(f1.y)}, ly[2] = {__float_as_uint(f1.z), __float_as_uint(f1.w)},
@@ -199,17 +232,15 @@ PT_DEV uint32_t node_visit(const DevScene& sc, const float4* lds_nodes, int cur,
     for (int i = 3; i >= 0; --i) {      // slot 4h+i; descending, so that shifting the results in leaves slot s in bit s
       const float tn = hw_max(hw_max(hw_max(pt_fma(ubyte_f(nqx, i), ax, bx), pt_fma(ubyte_f(nqy, i), ay, by)), pt_fma(ubyte_f(nqz, i), az, bz)), tmin);
       const float tf = hw_min(hw_min(hw_min(pt_fma(ubyte_f(fqx, i), ax, bx), pt_fma(ubyte_f(fqy, i), ay, by)), pt_fma(ubyte_f(fqz, i), az, bz)), tlimit);
-      hits = hits + hits + (tn <= tf ? 1u : 0u);                   // v_cmp + v_addc
+      hits = hits + hits + (tn <= tf ? 1u : 0u);
     }
   }
-  const uint32_t w18 = __float_as_uint(f4.z);
-  const uint32_t imask = ew >> 24;
-  masks = imask | (w18 << 8);
-  base_child = __float_as_uint(f4.x); base_tri = __float_as_uint(f4.y);
-  return hits & (imask | (w18 & 255u));
+  masks = w2 >> 8;
+  block = __float_as_uint(f0.w);
+  return hits & ((masks | (masks >> 8)) & 255u);
 }
 
-// Pending-group bookkeeping.  G = (gbase, gmask = hits<<8 | imask) is the group in registers; `nh` are the interior hits of
+// Pending-group bookkeeping.  G = (gbase = children-block address, gmask = hits<<8 | imask) is the group in registers; `nh` are the interior hits of
 // the node just visited.  A non-empty new group goes on top (the old one is saved), then the next child is taken from the
 // top group: slot by the order table (closest hit) or the lowest set bit (any hit).  Returns the next node or CUR_FINISHED.
 template <bool ORDERED>
@@ -223,7 +254,7 @@ PT_DEV int advance(uint32_t& gbase, uint32_t& gmask, WStack& st, const uint8_t* 
   const uint32_t hits = gmask >> 8;
   const uint32_t sl = ORDERED ? (uint32_t)((lds_u8c*)order_tab)[(oct << 8) | hits] : (uint32_t)__builtin_ctz(hits);
   gmask &= ~(256u << sl);
-  return (int)(gbase + (uint32_t)__builtin_popcount(gmask & 255u & ((1u << sl) - 1u)));
+  return (int)(gbase + 4u * (uint32_t)__builtin_popcount(gmask & 255u & ((1u << sl) - 1u)));
 }
 PT_DEV void enter_group(uint32_t& gbase, uint32_t& gmask, WStack& st, uint32_t nbase, uint32_t nhits, uint32_t nimask) {
   if (nhits == 0u) return;
@@ -231,14 +262,14 @@ PT_DEV void enter_group(uint32_t& gbase, uint32_t& gmask, WStack& st, uint32_t n
   gbase = nbase; gmask = (nhits << 8) | nimask;
 }
 
-// Pending triangles of the last visited node: tmask = lhits | lmask<<8 | two<<16 | second<<24.  Returns the record index of
-// the next triangle to test and removes it from the set: the hit leaf slots in ascending order, a 2-triangle leaf's
-// second triangle right after its first.
+// Pending triangles of the last visited node: tbase = unit address of the node's first triangle record,
+// tmask = lhits | lmask<<8 | two<<16 | second<<24.  Returns the unit address of the next triangle to test and removes it
+// from the set: the hit leaf slots in ascending order, a 2-triangle leaf's second triangle right after its first.
 PT_DEV uint32_t next_triangle(uint32_t tbase, uint32_t& tmask) {
   const uint32_t sl = (uint32_t)__builtin_ctz(tmask & 255u);
   const uint32_t below = (1u << sl) - 1u;
   const uint32_t second = tmask >> 24;
-  const uint32_t k = tbase + (uint32_t)__builtin_popcount((tmask >> 8) & 255u & below) + (uint32_t)__builtin_popcount((tmask >> 16) & 255u & below) + second;
+  const uint32_t k = tbase + 3u * ((uint32_t)__builtin_popcount((tmask >> 8) & 255u & below) + (uint32_t)__builtin_popcount((tmask >> 16) & 255u & below) + second);
   const bool more = second == 0u && ((tmask >> (16u + sl)) & 1u) != 0u;
   tmask = more ? (tmask | (1u << 24)) : ((tmask & 0x00ffffffu) & ~(1u << sl));
   return k;
@@ -279,8 +310,29 @@ struct Reservoir {
 #define DIAG_ITER(var) do { } while (0)
 #endif
 
-// LDS of a trace block: [n_nodelets × 80 B nodes][waves × L × 64 stack entries of 8 B][2 KiB slot-order table (closest hit only)]
-PT_DEV uint2* trace_lds_stack(float4* lds_raw, const DevScene& sc, bool nodelets) { return reinterpret_cast<uint2*>(lds_raw + (nodelets ? (size_t)sc.n_nodelets * 5 : 0)); }
+// LDS of a trace block: [n_lds_units × 16 B: the top of the tree][waves × 4 KiB node stage][waves × L × 64 stack entries of 8 B]
+// [2 KiB slot-order table (closest hit only)]
+struct TraceLds { uint32_t top_addr, stage_addr; uint2* stack; uint8_t* order_tab; };
+PT_DEV TraceLds trace_lds(float4* lds_raw, const DevScene& sc, uint32_t wave, int stack_lds) {
+  TraceLds t;
+  float4* stage = lds_raw + sc.n_lds_units;
+  t.top_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_raw;
+  t.stage_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(stage + (size_t)wave * 256u));
+  t.stack = reinterpret_cast<uint2*>(stage + (TRACE_COOP ? (size_t)TRACE_WAVES * 256u : 0u));
+  t.order_tab = reinterpret_cast<uint8_t*>(t.stack + (size_t)TRACE_WAVES * (size_t)stack_lds * 64u);
+  return t;
+}
+// triangle record at unit address k: from the staged top of the tree or from global memory (two explicit address spaces: a
+// pointer that may be either compiles to FLAT loads, which occupy both the LDS and the vector-memory pipe)
+PT_DEV void load_triangle(const DevScene& sc, uint32_t top_addr, uint32_t k, float4& a, float4& b, float4& c) {
+  typedef float fx4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) const fx4 lds_f4;
+  typedef __attribute__((address_space(1))) const fx4 glb_f4;
+  fx4 x, y, z;
+  if (k + 3u <= sc.n_lds_units) { lds_f4* p = (lds_f4*)(uintptr_t)(top_addr + 16u * k); x = p[0]; y = p[1]; z = p[2]; }
+  else { glb_f4* p = (glb_f4*)sc.recs + k; x = p[0]; y = p[1]; z = p[2]; }
+  a = make_float4(x.x, x.y, x.z, x.w); b = make_float4(y.x, y.y, y.z, y.w); c = make_float4(z.x, z.y, z.z, z.w);
+}
 
 // =================================================================================================
 // P3 closest-hit traversal + triangle intersection: persistent waves, dynamic lane refill, 8-wide BVH.
@@ -289,16 +341,15 @@ PT_DEV uint2* trace_lds_stack(float4* lds_raw, const DevScene& sc, bool nodelets
 // Closest hit = lexicographic minimum of (t, original primitive id).
 // The hit record (t, prim | class<<28, u, v) is written IN PLACE at the ray's slot (miss: prim = -1).
 // CULL: R6 back-face culling + per-ray [tmin,tmax] from B.zw (raster-compat primary rays).
-template <bool CULL, bool NODELETS>
+template <bool CULL>
 __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_closest(DevScene sc, DevQueues q, int qi, int stack_lds) {
   extern __shared__ float4 lds_raw[];
-  float4* lds_nodes = lds_raw;                                                       // [n_nodelets × 80 B]
-  uint2* lds_stack = trace_lds_stack(lds_raw, sc, NODELETS);                         // [waves][L][64]
-  uint8_t* order_tab = reinterpret_cast<uint8_t*>(lds_stack + (size_t)TRACE_WAVES * (size_t)stack_lds * 64u);
+  __shared__ uint8_t s_pair[2][TRACE_WAVES][64];   // leaf phase: k-th owner with a second triangle <-> k-th free lane
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
-  if (NODELETS)
-    for (uint32_t i = threadIdx.x; i < sc.n_nodelets * 5u; i += TRACE_BLOCK) lds_nodes[i] = sc.nodes[i];
+  const TraceLds L = trace_lds(lds_raw, sc, wave, stack_lds);
+  uint8_t* order_tab = L.order_tab;
+  for (uint32_t i = threadIdx.x; i < sc.n_lds_units; i += TRACE_BLOCK) lds_raw[i] = sc.recs[i];
   build_order_table(order_tab);
   __syncthreads();
   const RayQ rq = q.ray[qi];
@@ -315,7 +366,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_closest(
 #endif
   Reservoir res; res.init(n);
   WStack st;
-  st.init(lds_stack + (size_t)wave * (size_t)stack_lds * 64u + lane,
+  st.init(L.stack + (size_t)wave * (size_t)stack_lds * 64u + lane,
           sc.stack_ovf + ((size_t)(blockIdx.x * TRACE_WAVES + wave) * sc.ovf_depth) * 64u + lane, stack_lds);
   int cur = CUR_DONE;
   uint32_t ri = 0, oct = 0, gbase = 0, gmask = 0, tbase = 0, tmask = 0;
@@ -350,32 +401,74 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_closest(
         if (!mn) break;
         if (__popcll(mn) < TRACE_NODE_MIN && __ballot(cur == CUR_LEAF)) break;   // few walkers, triangles waiting
         nv += (unsigned long long)__popcll(mn);
+        if (TRACE_COOP) fetch_nodes(sc, L.stage_addr, cur, lane);    // all lanes take part: every lane loads pieces of other lanes' nodes
         if (cur >= 0) {
           DIAG_ITER(d_node);
           uint32_t nb, masks;
-          const uint32_t hits = node_visit<NODELETS>(sc, lds_nodes, cur, r, oct, tmin, best_t, nb, tbase, masks);
+          const uint32_t node_addr = (uint32_t)cur < sc.n_lds_units ? L.top_addr + 16u * (uint32_t)cur : L.stage_addr + 64u * lane;
+          const uint32_t hits = node_visit(sc, node_addr, cur, r, oct, tmin, best_t, nb, masks);
           const uint32_t imask = masks & 255u, lhits = hits & (masks >> 8);
           enter_group(gbase, gmask, st, nb, hits & imask, imask);
+          tbase = nb + 4u * (uint32_t)__builtin_popcount(imask);
           tmask = lhits | (masks & 0x00ffff00u);
           cur = lhits ? CUR_LEAF : advance<true>(gbase, gmask, st, order_tab, oct);
         }
       }
       STAMP(t_node);
-      // ---- leaf phase: every lane with pending triangles tests one ----
-      if (__ballot(cur == CUR_LEAF)) {
-        DIAG_ITER(d_tri);
-        if (cur == CUR_LEAF) {
-          const uint32_t k = next_triangle(tbase, tmask);
-          const float4 a = sc.tris[(size_t)k * 3 + 0], b = sc.tris[(size_t)k * 3 + 1], c = sc.tris[(size_t)k * 3 + 2];
-          ++nt;
-          float t, u, v;
-          if (tri_test<CULL>(r, V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), t, u, v)) {
-            const int pid = __float_as_int(a.w);
-            if (t > tmin && (t < best_t || (t == best_t && pid < best_prim))) {
-              best_t = t; best_u = u; best_v = v; best_prim = pid; best_cls = __float_as_int(b.w); found = true;
+      // ---- leaf phase: every lane with pending triangles tests one; a lane that then still has triangles pending hands its next
+      // one to a lane that is not at a leaf (the k-th such owner to the k-th free lane, through two 64-byte LDS tables; the helper
+      // fetches the owner's ray through ds_bpermute and returns its result the same way).  Same tests, same results and counters
+      // as one triangle per pass — closest hit is an order-independent minimum — in fewer passes.
+      {
+        const bool leaf = cur == CUR_LEAF;
+        const uint64_t m_leaf = __ballot(leaf);
+        if (m_leaf) {
+          DIAG_ITER(d_tri);
+          uint32_t k1 = 0, k2 = 0;
+          bool more = false;
+          if (leaf) { k1 = next_triangle(tbase, tmask); more = (tmask & 255u) != 0u; }
+          const uint64_t m_more = __ballot(more), m_free = ~m_leaf;
+          const uint32_t n_more = (uint32_t)__popcll(m_more), n_free = (uint32_t)__popcll(m_free);
+          const uint32_t rank_more = mbcnt64(m_more), rank_free = mbcnt64(m_free);
+          const bool paired = more && rank_more < n_free, helper = !leaf && rank_free < n_more;
+          typedef __attribute__((address_space(3))) volatile uint8_t lds_u8;
+          lds_u8* tab_owner = (lds_u8*)s_pair[0][wave];
+          lds_u8* tab_helper = (lds_u8*)s_pair[1][wave];
+          if (paired) { k2 = next_triangle(tbase, tmask); tab_owner[rank_more] = (uint8_t)lane; }
+          if (helper) tab_helper[rank_free] = (uint8_t)lane;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const int src = helper ? (int)tab_owner[rank_free] : (int)lane;        // whose ray this lane tests with
+          ray_t rr;
+          rr.o = V3(__shfl(r.o.x, src), __shfl(r.o.y, src), __shfl(r.o.z, src));
+          rr.d = V3(__shfl(r.d.x, src), __shfl(r.d.y, src), __shfl(r.d.z, src));
+          const uint32_t k2_src = (uint32_t)__shfl((int)k2, src);                 // unconditional: a shuffle inside ?: would run with the owners masked off
+          const uint32_t k = helper ? k2_src : k1;
+          bool hit = false; float t = 0.0f, u = 0.0f, v = 0.0f; int pid = 0, cls = 0;
+          if (leaf || helper) {
+            float4 a, b, c;
+            load_triangle(sc, L.top_addr, k, a, b, c);
+            hit = tri_test<CULL>(rr, V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), t, u, v);
+            pid = __float_as_int(a.w); cls = __float_as_int(b.w);
+          }
+          if (leaf) {
+            ++nt;
+            if (hit && t > tmin && (t < best_t || (t == best_t && pid < best_prim))) {
+              best_t = t; best_u = u; best_v = v; best_prim = pid; best_cls = cls; found = true;
             }
           }
-          if ((tmask & 255u) == 0u) cur = advance<true>(gbase, gmask, st, order_tab, oct);
+          const int hsrc = paired ? (int)tab_helper[rank_more] : (int)lane;      // the lane that tested this owner's second triangle
+          const int h2 = __shfl(hit ? 1 : 0, hsrc);
+          const float t2 = __shfl(t, hsrc), u2 = __shfl(u, hsrc), v2 = __shfl(v, hsrc);
+          const int pid2 = __shfl(pid, hsrc), cls2 = __shfl(cls, hsrc);
+          if (paired) {
+            ++nt;
+            if (h2 && t2 > tmin && (t2 < best_t || (t2 == best_t && pid2 < best_prim))) {
+              best_t = t2; best_u = u2; best_v = v2; best_prim = pid2; best_cls = cls2; found = true;
+            }
+          }
+          if (leaf && (tmask & 255u) == 0u) cur = advance<true>(gbase, gmask, st, order_tab, oct);
         }
       }
       STAMP(t_leaf);
@@ -407,23 +500,21 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_closest(
 // P4 any-hit traversal for the NEE shadow rays: same nodes and machinery, the interval is fixed, hit slots are taken in
 // ascending slot order (occlusion needs no front-to-back order) and the first triangle hit inside (0, tmax) ends the ray.
 // An unoccluded ray adds its contribution to the path's radiance word (single owner: one shadow ray per path per bounce).
-template <bool NODELETS, bool DEBUG_OUT>
+template <bool DEBUG_OUT>
 __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_any(DevScene sc, DevQueues q, int stack_lds, uint8_t* debug_out) {
   extern __shared__ float4 lds_raw[];
-  float4* lds_nodes = lds_raw;
-  uint2* lds_stack = trace_lds_stack(lds_raw, sc, NODELETS);
+  __shared__ uint8_t s_pair[2][TRACE_WAVES][64];   // leaf phase: k-th owner with a second triangle <-> k-th free lane
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
-  if (NODELETS) {
-    for (uint32_t i = threadIdx.x; i < sc.n_nodelets * 5u; i += TRACE_BLOCK) lds_nodes[i] = sc.nodes[i];
-    __syncthreads();
-  }
+  const TraceLds L = trace_lds(lds_raw, sc, wave, stack_lds);
+  for (uint32_t i = threadIdx.x; i < sc.n_lds_units; i += TRACE_BLOCK) lds_raw[i] = sc.recs[i];
+  __syncthreads();
   const uint32_t n = q.cnt[CNT_SHADOW];
   unsigned long long nv = 0, nr = 0;
   uint32_t nt = 0;
   Reservoir res; res.init(n);
   WStack st;
-  st.init(lds_stack + (size_t)wave * (size_t)stack_lds * 64u + lane,
+  st.init(L.stack + (size_t)wave * (size_t)stack_lds * 64u + lane,
           sc.stack_ovf + ((size_t)(blockIdx.x * TRACE_WAVES + wave) * sc.ovf_depth) * 64u + lane, stack_lds);
   int cur = CUR_DONE;
   uint32_t ri = 0, path = 0, oct = 0, gbase = 0, gmask = 0, tbase = 0, tmask = 0;
@@ -453,23 +544,65 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_any(DevS
         if (!mn) break;
         if (__popcll(mn) < TRACE_NODE_MIN && __ballot(cur == CUR_LEAF)) break;
         nv += (unsigned long long)__popcll(mn);
+        if (TRACE_COOP) fetch_nodes(sc, L.stage_addr, cur, lane);
         if (cur >= 0) {
           uint32_t nb, masks;
-          const uint32_t hits = node_visit<NODELETS>(sc, lds_nodes, cur, r, oct, 0.0f, tmax, nb, tbase, masks);
+          const uint32_t node_addr = (uint32_t)cur < sc.n_lds_units ? L.top_addr + 16u * (uint32_t)cur : L.stage_addr + 64u * lane;
+          const uint32_t hits = node_visit(sc, node_addr, cur, r, oct, 0.0f, tmax, nb, masks);
           const uint32_t imask = masks & 255u, lhits = hits & (masks >> 8);
           enter_group(gbase, gmask, st, nb, hits & imask, imask);
+          tbase = nb + 4u * (uint32_t)__builtin_popcount(imask);
           tmask = lhits | (masks & 0x00ffff00u);
           cur = lhits ? CUR_LEAF : advance<false>(gbase, gmask, st, nullptr, 0u);
         }
       }
-      if (__ballot(cur == CUR_LEAF)) {
-        if (cur == CUR_LEAF) {
-          const uint32_t k = next_triangle(tbase, tmask);
-          const float4 a = sc.tris[(size_t)k * 3 + 0], b = sc.tris[(size_t)k * 3 + 1], c = sc.tris[(size_t)k * 3 + 2];
-          ++nt;
-          float t, u, v;
-          if (tri_test<false>(r, V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), t, u, v) && t > 0.0f && t < tmax) { occluded = true; cur = CUR_FINISHED; }
-          else if ((tmask & 255u) == 0u) cur = advance<false>(gbase, gmask, st, nullptr, 0u);
+      {
+        // ---- leaf phase: as in k_trace_closest, a lane's second pending triangle is tested in the same pass by a free lane.  The
+        // counter stays the sequential one: the second test is counted (and used) only when the first one missed.
+        const bool leaf = cur == CUR_LEAF;
+        const uint64_t m_leaf = __ballot(leaf);
+        if (m_leaf) {
+          uint32_t k1 = 0, k2 = 0;
+          bool more = false;
+          if (leaf) { k1 = next_triangle(tbase, tmask); more = (tmask & 255u) != 0u; }
+          const uint64_t m_more = __ballot(more), m_free = ~m_leaf;
+          const uint32_t n_more = (uint32_t)__popcll(m_more), n_free = (uint32_t)__popcll(m_free);
+          const uint32_t rank_more = mbcnt64(m_more), rank_free = mbcnt64(m_free);
+          const bool paired = more && rank_more < n_free, helper = !leaf && rank_free < n_more;
+          typedef __attribute__((address_space(3))) volatile uint8_t lds_u8;
+          lds_u8* tab_owner = (lds_u8*)s_pair[0][wave];
+          lds_u8* tab_helper = (lds_u8*)s_pair[1][wave];
+          uint32_t tmask_after = tmask;
+          if (paired) { k2 = next_triangle(tbase, tmask_after); tab_owner[rank_more] = (uint8_t)lane; }
+          if (helper) tab_helper[rank_free] = (uint8_t)lane;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const int src = helper ? (int)tab_owner[rank_free] : (int)lane;
+          ray_t rr;
+          rr.o = V3(__shfl(r.o.x, src), __shfl(r.o.y, src), __shfl(r.o.z, src));
+          rr.d = V3(__shfl(r.d.x, src), __shfl(r.d.y, src), __shfl(r.d.z, src));
+          const float tmax_src = __shfl(tmax, src);
+          const uint32_t k2_src = (uint32_t)__shfl((int)k2, src);
+          const uint32_t k = helper ? k2_src : k1;
+          bool hit = false;
+          if (leaf || helper) {
+            float4 a, b, c;
+            load_triangle(sc, L.top_addr, k, a, b, c);
+            float t, u, v;
+            hit = tri_test<false>(rr, V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), t, u, v) && t > 0.0f && t < tmax_src;
+          }
+          const int hsrc = paired ? (int)tab_helper[rank_more] : (int)lane;
+          const int h2 = __shfl(hit ? 1 : 0, hsrc);
+          if (leaf) {
+            ++nt;
+            if (hit) { occluded = true; cur = CUR_FINISHED; }
+            else if (paired) {
+              ++nt; tmask = tmask_after;
+              if (h2) { occluded = true; cur = CUR_FINISHED; }
+            }
+            if (cur == CUR_LEAF && (tmask & 255u) == 0u) cur = advance<false>(gbase, gmask, st, nullptr, 0u);
+          }
         }
       }
       if (cur == CUR_FINISHED) {
@@ -860,7 +993,10 @@ __global__ __launch_bounds__(256) void k_resolve(DevFrame fr, const float4* accu
 // GBUF16 (PTC_INTEGRATOR_RASTER_GBUFFER16): the lighting pass reads what the reference's G-buffer holds
 // (GBuffer.hpp:13-16): positions and normals as RGBA16F (fp32 → fp16, round to nearest even), albedo as RGBA16 UNORM
 // (clamp to [0,1], round(v·65535)/65535); the normal is NOT re-normalised after the rounding (lighting.glsl:21,28).
-PT_DEV float round_f16(float v) { return (float)(_Float16)v; }                       // v_cvt_f16_f32 (RTE, denormals kept) + v_cvt_f32_f16
+// v_cvt_f16_f32 (RTE, denormals kept) + v_cvt_f32_f16.  The empty asm hides the producer of `v`: without it the compiler fuses
+// an fma that feeds the conversion into v_fma_mixlo_f16, which rounds the exact product-sum ONCE to fp16, while the contract
+// (and the oracle) round it to fp32 first — 3 pixels of a 160x90 frame differed by one fp16 ulp.
+PT_DEV float round_f16(float v) { asm volatile("" : "+v"(v)); return (float)(_Float16)v; }
 PT_DEV float round_unorm16(float v) {
   const float c = fmin2(fmax2(v, 0.0f), 1.0f);                                       // NaN → 0 (fmax2(NaN, 0) = 0)
   return (float)(uint32_t)(c * 65535.0f + 0.5f) / 65535.0f;
@@ -947,7 +1083,7 @@ __global__ __launch_bounds__(256) void k_tonemap(const float4* radiance, uint32_
 // =================================================================================================
 // launchers
 static size_t trace_lds_bytes(const LaunchCfg& cfg, const DevScene& sc, bool closest) {
-  return (size_t)sc.n_nodelets * 80 + (size_t)TRACE_WAVES * cfg.stack_lds * 64 * 8 + (closest ? ORDER_TABLE_BYTES : 0);
+  return (size_t)sc.n_lds_units * 16 + (TRACE_COOP ? (size_t)TRACE_WAVES * 4096 : 0) + (size_t)TRACE_WAVES * cfg.stack_lds * 64 * 8 + (closest ? ORDER_TABLE_BYTES : 0);
 }
 
 int pt_trace_block_threads() { return TRACE_BLOCK; }
@@ -958,9 +1094,7 @@ size_t pt_trace_lds_bytes(const LaunchCfg& cfg, const DevScene& sc) { return tra
 // included: the runtime's own occupancy calculation), minimum over the closest-hit and any-hit kernels; <= 0 on error.
 // Dynamic LDS above the default 64 KiB limit is enabled on every variant first.
 int pt_trace_blocks_per_cu(size_t lds) {
-  const void* fns[] = {(const void*)k_trace_closest<false, true>, (const void*)k_trace_closest<false, false>, (const void*)k_trace_closest<true, true>,
-                       (const void*)k_trace_closest<true, false>, (const void*)k_trace_any<true, false>, (const void*)k_trace_any<false, false>,
-                       (const void*)k_trace_any<true, true>, (const void*)k_trace_any<false, true>};
+  const void* fns[] = {(const void*)k_trace_closest<false>, (const void*)k_trace_closest<true>, (const void*)k_trace_any<false>, (const void*)k_trace_any<true>};
   int best = 1 << 30;
   for (const void* f : fns) {
     if (lds > 64u * 1024u && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
@@ -982,23 +1116,17 @@ void pt_launch_raygen(hipStream_t s, const DevCamera& cam, const DevFrame& fr, c
 }
 
 void pt_launch_trace_closest(hipStream_t s, const LaunchCfg& cfg, const DevScene& sc, const DevQueues& q, int qi, bool cull) {
-  const bool nodelets = sc.n_nodelets > 0;
   const dim3 grid((unsigned)(cfg.n_cu * cfg.trace_blocks_per_cu));
   const size_t lds = trace_lds_bytes(cfg, sc, true);
-#define TC(C, N) hipLaunchKernelGGL((k_trace_closest<C, N>), grid, dim3(TRACE_BLOCK), lds, s, sc, q, qi, cfg.stack_lds)
-  if (cull) { if (nodelets) TC(true, true); else TC(true, false); }
-  else { if (nodelets) TC(false, true); else TC(false, false); }
-#undef TC
+  if (cull) hipLaunchKernelGGL(k_trace_closest<true>, grid, dim3(TRACE_BLOCK), lds, s, sc, q, qi, cfg.stack_lds);
+  else hipLaunchKernelGGL(k_trace_closest<false>, grid, dim3(TRACE_BLOCK), lds, s, sc, q, qi, cfg.stack_lds);
 }
 
 void pt_launch_trace_any(hipStream_t s, const LaunchCfg& cfg, const DevScene& sc, const DevQueues& q, uint8_t* debug_out) {
-  const bool nodelets = sc.n_nodelets > 0;
   const dim3 grid((unsigned)(cfg.n_cu * cfg.trace_blocks_per_cu));
   const size_t lds = trace_lds_bytes(cfg, sc, false);
-#define TA(N, D) hipLaunchKernelGGL((k_trace_any<N, D>), grid, dim3(TRACE_BLOCK), lds, s, sc, q, cfg.stack_lds, debug_out)
-  if (debug_out) { if (nodelets) TA(true, true); else TA(false, true); }
-  else { if (nodelets) TA(true, false); else TA(false, false); }
-#undef TA
+  if (debug_out) hipLaunchKernelGGL(k_trace_any<true>, grid, dim3(TRACE_BLOCK), lds, s, sc, q, cfg.stack_lds, debug_out);
+  else hipLaunchKernelGGL(k_trace_any<false>, grid, dim3(TRACE_BLOCK), lds, s, sc, q, cfg.stack_lds, debug_out);
 }
 
 void pt_launch_shade(hipStream_t s, const LaunchCfg& cfg, const DevScene& sc, const DevFrame& fr, const DevQueues& q, int qi, uint32_t bounce) {

@@ -79,7 +79,7 @@ struct ptc_ctx {
   int device = 0;
   std::string err;
   LaunchCfg cfg{};
-  uint32_t nodelet_budget = 73;   // wide nodes staged in LDS: the top three levels (1+8+64) of the tree, 80 B each = 5.7 KB
+  uint32_t nodelet_budget = 73;   // 64-byte records staged in LDS: the top three levels (1+8+64 nodes) of the tree = 4.6 KB
   size_t max_batch_paths = (size_t)1 << 28;   // paths in flight over all lanes: large batches amortise launch tails (sized for 288 GB of HBM:
                                               // 176 B per path -> 47 GB of queues at 1080p x 64 spp x 2 lanes; 2^27 is 2 % slower, 2^29 1 % faster)
   bool timing = true;
@@ -248,9 +248,10 @@ struct ScopedSpan {   // records a start/stop event pair around launches on one 
 int configure_launch(ptc_ctx* c) {
   // Traversal stack: at most one group of pending children per tree level, so a ray needs at most depth+1 entries.
   // `stack_lds` of them live in LDS (8 B each, 512 B per level and wave), the rest in a global overflow slab.
-  // LDS per block = nodelets·80 B + waves·stack_lds·512 B + the 2-KiB slot-order table.
+  // LDS per block = staged top of the tree (4.6 KB) + waves·stack_lds·512 B + the 2-KiB slot-order table
+  // (+ waves·4 KiB node stage in a -DTRACE_COOP=1 build).
   const int need = (int)c->built.max_depth + 2;
-  int l = 6;    // stack entries per lane kept in LDS: with 73 nodelets, 6 entries leave room for 7 blocks (28 waves) per CU
+  int l = 6;    // stack entries per lane kept in LDS: 18.6 KB per block, 8 blocks (32 waves, the register limit) share a CU
   if (const char* e = std::getenv("PTC_STACK_LDS")) { int v = std::atoi(e); if (v >= 1 && v <= 64) l = v; }
   if (l > need) l = need;
   c->cfg.stack_lds = l;
@@ -586,7 +587,7 @@ int ptc_scene_commit(ptc_ctx* c) {
   {
     const float* p = nullptr;
     auto up = [&](const std::vector<float>& v, const float4** out) { if (!rc) { rc = dev_upload(c, c->scene_allocs, &p, v); *out = (const float4*)p; } };
-    up(B.nodes, &d.nodes); up(B.tris, &d.tris); up(B.mats, &d.mats); up(B.lights, &d.lights);
+    up(B.recs, &d.recs); up(B.mats, &d.mats); up(B.lights, &d.lights);
     if (!rc) rc = dev_upload(c, c->scene_allocs, &d.cdf, B.cdf);
     up(B.shade, &d.shade); up(B.shade_tex, &d.shade_tex);
     if (!rc) rc = dev_upload(c, c->scene_allocs, &d.texels, B.texels);
@@ -598,7 +599,8 @@ int ptc_scene_commit(ptc_ctx* c) {
   if (rc) { free_all(c->scene_allocs); return rc; }
   d.env_w = B.env_w; d.env_h = B.env_h; d.env_ok = B.env_ok;
   d.tex_linear = c->tex_linear;
-  d.n_lights = B.n_lights; d.n_mats = (uint32_t)c->mats.size(); d.n_nodelets = B.n_nodelets; d.ray_eps = B.ray_eps;
+  d.n_lights = B.n_lights; d.n_mats = (uint32_t)c->mats.size(); d.n_lds_units = B.n_lds_units; d.ray_eps = B.ray_eps;
+  for (int k = 0; k < 3; ++k) { d.grid_lo[k] = B.grid_lo[k]; d.grid_step[k] = B.grid_step[k]; }
   c->dsc = d;
   { int rc2 = configure_launch(c); if (rc2) { free_all(c->scene_allocs); return rc2; } }
   c->committed = true;
@@ -965,14 +967,15 @@ int ptc_debug_get_counters(ptc_ctx* c, uint64_t* out, int n) {
   return ST_N;
 }
 
-int ptc_debug_get_bvh(ptc_ctx* c, uint32_t* n_nodes, uint32_t* n_tris, float* nodes, float* tris) {
+int ptc_debug_get_bvh(ptc_ctx* c, uint32_t* n_nodes, uint32_t* n_tris, uint32_t* n_units, float* units, float grid[6]) {
   if (!c) return PTC_E_ARG;
   if (!c->committed) return fail(c, PTC_E_STATE, "debug_get_bvh: scene not committed");
   const HostBuilt& B = c->built;
   if (n_nodes) *n_nodes = B.n_nodes;
   if (n_tris) *n_tris = B.n_tri_records;
-  if (nodes) std::memcpy(nodes, B.nodes.data(), B.nodes.size() * 4);
-  if (tris) std::memcpy(tris, B.tris.data(), B.tris.size() * 4);
+  if (n_units) *n_units = B.n_units;
+  if (units) std::memcpy(units, B.recs.data(), B.recs.size() * 4);
+  if (grid) for (int k = 0; k < 3; ++k) { grid[k] = B.grid_lo[k]; grid[3 + k] = B.grid_step[k]; }
   return PTC_OK;
 }
 

@@ -9,8 +9,10 @@
 
 // ---- HBM layout of the committed scene (DESIGN.md §"Data layout in HBM") -----------------------
 struct DevScene {
-  const float4* nodes;        // 5 × 16 B per 8-wide node (80 B): org+exponents+imask, 8-bit child planes of the 8 slots, child/triangle bases, leaf masks (ptc_scene.cpp)
-  const float4* tris;         // 3 × float4 per triangle record (48 B): (v0,prim) (e1,class) (e2,-), grouped by owning node
+  const float4* recs;         // the BVH: one array of 16-byte units; 64-byte 8-wide nodes (origin on a 16-bit scene grid, exponents, slot masks,
+                              // children-block address, 8-bit child planes) and 48-byte triangle records (v0,prim) (e1,class) (e2,-) in the
+                              // children blocks of their nodes; addresses are unit indices, the root is at 0 (layout: ptc_scene.cpp)
+  float grid_lo[3], grid_step[3];   // node origin = fma(oq, grid_step, grid_lo)
   const float4* shade;        // 5 × float4 per original primitive id (80 B): the three R1 vertex records de-indexed to what
                               // shading reads: (Pa,mat) (Pb,light) (Pc,Na.x) (Na.yz,Nb.xy) (Nb.z,Nc.xyz)
   const float4* mats;         // 3 × float4 per material: (base.rgb, metallic) (emissive.rgb, roughness) (base.a, tex_color, tex_normal, tex_mr)
@@ -26,7 +28,7 @@ struct DevScene {
   const float* cdf;           // emitter power cdf
   uint32_t n_lights;
   uint32_t n_mats;
-  uint32_t n_nodelets;        // leading nodes (BFS order) that the trace kernels stage in LDS
+  uint32_t n_lds_units;       // leading units (the top of the tree, breadth-first) that the trace kernels stage in LDS
   uint2* stack_ovf;           // per-lane traversal-stack overflow: [wave][ovf_depth][64] entries of (base_child, hits<<8 | imask)
   uint32_t ovf_depth;
   float ray_eps;
@@ -103,18 +105,18 @@ struct HostBuilt {
   std::vector<int32_t> tex_info; // 4 ints per texture
   std::vector<float> env, env_marg, env_cond;   // 4 floats per texel; cdfs
   int env_w = 0, env_h = 0, env_ok = 0;
-  std::vector<float> nodes;      // 20 words per 8-wide node
-  std::vector<float> tris;       // 12 floats per triangle record (node order)
+  std::vector<float> recs;       // the BVH as 16-byte units (4 floats each): nodes + triangle records (see DevScene::recs)
+  float grid_lo[3] = {0, 0, 0}, grid_step[3] = {1, 1, 1};
   std::vector<float> mats;       // 12 floats per material
   std::vector<float> lights;     // 20 floats per emitter
   std::vector<float> cdf;
-  uint32_t n_nodes = 0, n_tris = 0, n_tri_records = 0, n_lights = 0, max_depth = 0, n_nodelets = 0;
+  uint32_t n_nodes = 0, n_tris = 0, n_tri_records = 0, n_lights = 0, max_depth = 0, n_units = 0, n_lds_units = 0;
   float ray_eps = 0.0f;
 };
 
 // returns empty string on success, else the error text
 std::string ptc_build_scene(const std::vector<HostMaterial>&, const std::vector<HostMesh>&, const std::vector<HostInstance>&,
-                            const std::vector<HostTexture>&, const HostEnv&, uint32_t nodelet_budget, HostBuilt& out);
+                            const std::vector<HostTexture>&, const HostEnv&, uint32_t toplet_budget, HostBuilt& out);
 void ptc_trs_to_matrix(const float t[3], const float q_wxyz[4], const float s[3], float m16[16]);
 void ptc_make_camera(const float pos[3], const float target[3], float fov, float aspect, DevCamera& cam);
 // pixels owned by (rank,count) in tile-Morton order

@@ -19,7 +19,7 @@ namespace {
 
 constexpr int kLeafMax = 2;
 constexpr int kWide = 8;      // child slots per BVH node
-constexpr int kNodeWords = 20; // 80-byte node
+constexpr int kNodeWords = 16; // 64-byte node = 4 units of 16 bytes
 constexpr float kCostNode = 1.0f, kCostPrim = 1.0f;   // surface-area cost of one node visit / one triangle test (collapse)
 constexpr int kTile = 32;
 
@@ -238,7 +238,7 @@ void ptc_owned_pixels(int w, int h, int tile_rank, int tile_count, std::vector<u
 
 std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::vector<HostMesh>& meshes,
                             const std::vector<HostInstance>& insts, const std::vector<HostTexture>& texs, const HostEnv& env,
-                            uint32_t nodelet_budget, HostBuilt& B) {
+                            uint32_t toplet_budget, HostBuilt& B) {
   if (insts.empty()) return "scene_commit: no instances";
   uint64_t nv = 0, nt = 0;
   for (const auto& in : insts) { nv += meshes[(size_t)in.mesh].v.size(); nt += meshes[(size_t)in.mesh].idx.size() / 3; }
@@ -331,16 +331,21 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
   // then the lowest slot.  A ray then orders the slots by its direction signs alone (descending slot ^ octant), with
   // no per-child distance sort.
   //
-  // Storage: 80-byte nodes (5 × 16-byte loads per visit), child boxes quantised to 8 bits against the node's own box:
-  //   w0..2   org.xyz (float)            w3    ex | ey<<8 | ez<<16 | imask<<24     plane = org + q · 2^(e-127)
+  // Storage: ONE array of 16-byte units holding 64-byte nodes and 48-byte triangle records; the unit index is the address the
+  // kernels use.  A node's origin is kept to 16 bits per axis on a grid over the scene box (org = scene_lo + oq·step, rounded
+  // down), child boxes are quantised to 8 bits against that origin:
+  //   w0      oq.x | oq.y<<16            w1   oq.z | ex<<16 | ey<<24       w2   ez | imask<<8 | lmask<<16 | two<<24
+  //   w3      block: unit address of this node's children block            plane = org + q · 2^(e-127)
   //   w4,5    qlo.x slots 0-3 / 4-7      w6,7  qlo.y     w8,9   qlo.z
   //   w10,11  qhi.x                      w12,13 qhi.y    w14,15 qhi.z               (empty slot: qlo 255, qhi 0)
-  //   w16     base_child                 w17   base_tri  w18    lmask | two<<8      w19    0
-  // imask / lmask: slots holding an interior / a leaf child; two: leaf slots with 2 triangles.  A node's interior
-  // children are consecutive nodes from base_child and its leaf children's triangles are consecutive records from
-  // base_tri, both in slot order, so a child's index is base + popcount(mask below its slot).
-  // Layout: breadth-first until `nodelet_budget` nodes exist (the trace kernels stage those in LDS), then
-  // depth-first, always allocating a node's children as one block.
+  // imask / lmask: slots holding an interior / a leaf child; two: leaf slots with 2 triangles.  A children block starts on a
+  // 64-byte boundary and holds the interior children (nodes, 4 units each, slot order) followed by the triangles of the leaf
+  // children (3 units each, slot order): child node = block + 4·popcount(imask below its slot), triangle = block +
+  // 4·popcount(imask) + 3·(number of triangles in lower leaf slots).  The root is the node at unit 0.  64-byte alignment of the
+  // nodes is what lets four adjacent lanes fetch one node as one contiguous 64-byte piece (a quarter of the address-processing
+  // cost of four unrelated 16-byte gathers: tools/gather_bench.hip).
+  // Layout: blocks breadth-first until `toplet_budget` 64-byte records exist (the trace kernels stage that prefix in LDS),
+  // then depth-first.
   struct WChild { bool leaf; uint32_t lo, hi; int32_t radix; Box box; };
   std::vector<SplitNode> radix;
   std::vector<Box> radix_box;
@@ -442,11 +447,12 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
   std::vector<Slot> order;          // node index → radix node (or -1 for the single-triangle special case)
   std::vector<Wide> wide;           // node index → its children
   std::vector<uint32_t> child_base; // node index → index of its first interior child
+  std::vector<uint32_t> block_order; // node indices in the order their children blocks were allocated
   if (n == 1) {   // a single triangle: two identical leaf children (mirrors the binary special case)
     WChild kid[2];
     for (int k = 0; k < 2; ++k) { kid[k].leaf = true; kid[k].lo = kid[k].hi = 0; kid[k].radix = -1; kid[k].box = tbox[0]; }
     const Wide w = make_wide(kid, 2);
-    order.push_back({-1, 0}); wide.push_back(w); child_base.push_back(1);
+    order.push_back({-1, 0}); wide.push_back(w); child_base.push_back(1); block_order.push_back(0);
   } else {
     build_split_tree(tbox, ord, radix);
     // boxes of all radix nodes, bottom-up (iterative post-order)
@@ -495,13 +501,14 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
     // allocate the interior children of node `idx` as one consecutive block, in slot order
     auto alloc_children = [&](uint32_t idx) {
       child_base[idx] = (uint32_t)order.size();
+      block_order.push_back(idx);
       const Wide w = wide[idx];
       for (int sl = 0; sl < kWide; ++sl)
         if (w.used[sl] && !w.slot[sl].leaf) number(w.slot[sl].radix, order[idx].depth + 1);
     };
     number(0, 0);
     size_t head = 0;
-    for (; head < order.size() && order.size() < nodelet_budget; ++head) alloc_children((uint32_t)head);   // breadth-first top
+    for (; head < order.size() && order.size() < toplet_budget; ++head) alloc_children((uint32_t)head);   // breadth-first top
     {
       std::vector<uint32_t> stack;                                                   // depth-first remainder
       const size_t n_top = order.size();
@@ -518,17 +525,35 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
       }
     }
   }
-  // ---- emit nodes (index order) and triangles (each node's leaf children in slot order) ----------------
+  // ---- unit addresses: root at 0, then the children blocks in allocation order, each on a 64-byte boundary ---------------
   B.n_nodes = (uint32_t)order.size();
-  if (B.n_nodes >= (1u << 28)) return "scene_commit: too many BVH nodes";
-  B.nodes.assign((size_t)B.n_nodes * kNodeWords, 0.0f);
-  B.tris.clear();
+  std::vector<uint32_t> node_addr(B.n_nodes, 0u), block_addr(B.n_nodes, 0u);
+  uint64_t next_unit = 4;
+  uint32_t n_tri_records = 0;
+  for (const uint32_t idx : block_order) {
+    const Wide& w = wide[idx];
+    uint32_t ni = 0, nt = 0;
+    for (int sl = 0; sl < kWide; ++sl) {
+      if (!w.used[sl]) continue;
+      if (!w.slot[sl].leaf) ++ni; else nt += w.slot[sl].hi - w.slot[sl].lo + 1u;
+    }
+    block_addr[idx] = (uint32_t)next_unit;
+    for (uint32_t i = 0; i < ni; ++i) node_addr[child_base[idx] + i] = (uint32_t)next_unit + 4u * i;
+    next_unit += ((uint64_t)4 * ni + (uint64_t)3 * nt + 3u) & ~(uint64_t)3;
+    n_tri_records += nt;
+    if (next_unit >= (1ull << 31)) return "scene_commit: BVH too large";
+  }
+  // ---- emit nodes and triangles -----------------------------------------------------------------------------------------
+  B.recs.assign((size_t)next_unit * 4, 0.0f);
+  B.n_units = (uint32_t)next_unit;
+  float grid_step[3];
+  for (int k = 0; k < 3; ++k) { const float st = (sb.hi[k] - sb.lo[k]) / 65535.0f; grid_step[k] = st > 0.0f ? st : 1.0f; B.grid_lo[k] = sb.lo[k]; B.grid_step[k] = grid_step[k]; }
   uint32_t maxd = 0;
   for (uint32_t idx = 0; idx < B.n_nodes; ++idx) {
     if (order[idx].depth > maxd) maxd = order[idx].depth;
     const Wide& w = wide[idx];
     uint32_t word[kNodeWords] = {0};
-    uint32_t e[3], qlo[3][kWide], qhi[3][kWide];
+    uint32_t e[3], oq[3], qlo[3][kWide], qhi[3][kWide];
     int sl_of[kWide], nk = 0;                      // used slots in ascending order
     for (int sl = 0; sl < kWide; ++sl) if (w.used[sl]) sl_of[nk++] = sl;
     for (int k = 0; k < 3; ++k) {
@@ -538,33 +563,42 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
         clo[i] = w.slot[sl_of[i]].box.lo[k]; chi[i] = w.slot[sl_of[i]].box.hi[k];
         nlo = clo[i] < nlo ? clo[i] : nlo; nhi = chi[i] > nhi ? chi[i] : nhi;
       }
+      // origin on the 16-bit scene grid, rounded down: the largest q with fmaf(q, step, lo) <= the node's lower bound
+      float fq = std::floor((nlo - sb.lo[k]) / grid_step[k]);
+      if (fq < 0.0f) fq = 0.0f;
+      if (fq > 65535.0f) fq = 65535.0f;
+      uint32_t q16 = (uint32_t)fq;
+      while (q16 > 0u && fmaf((float)q16, grid_step[k], sb.lo[k]) > nlo) --q16;
+      oq[k] = q16;
+      const float org = fmaf((float)q16, grid_step[k], sb.lo[k]);
       for (int sl = 0; sl < kWide; ++sl) { qlo[k][sl] = 255; qhi[k][sl] = 0; }
-      quantize_axis(clo, chi, nk, nlo, nhi, e[k], ql, qh);
+      quantize_axis(clo, chi, nk, org, nhi, e[k], ql, qh);
       for (int i = 0; i < nk; ++i) { qlo[k][sl_of[i]] = ql[i]; qhi[k][sl_of[i]] = qh[i]; }
-      std::memcpy(&word[k], &nlo, 4);
     }
-    uint32_t imask = 0, lmask = 0, two = 0;
-    const uint32_t base_tri = (uint32_t)(B.tris.size() / 12);
+    uint32_t imask = 0, lmask = 0, two = 0, ni = 0;
+    for (int sl = 0; sl < kWide; ++sl) if (w.used[sl] && !w.slot[sl].leaf) { imask |= 1u << sl; ++ni; }
+    float* tri_out = &B.recs[((size_t)block_addr[idx] + 4u * ni) * 4];
     for (int sl = 0; sl < kWide; ++sl) {
-      if (!w.used[sl]) continue;
+      if (!w.used[sl] || !w.slot[sl].leaf) continue;
       const WChild& ch = w.slot[sl];
-      if (!ch.leaf) { imask |= 1u << sl; continue; }
       lmask |= 1u << sl;
       if (ch.hi - ch.lo + 1u == 2u) two |= 1u << sl;
-      for (uint32_t t = ch.lo; t <= ch.hi; ++t) { B.tris.resize(B.tris.size() + 12); tri_record(t, &B.tris[B.tris.size() - 12]); }
+      for (uint32_t t = ch.lo; t <= ch.hi; ++t) { tri_record(t, tri_out); tri_out += 12; }
     }
-    word[3] = e[0] | (e[1] << 8) | (e[2] << 16) | (imask << 24);
+    word[0] = oq[0] | (oq[1] << 16);
+    word[1] = oq[2] | (e[0] << 16) | (e[1] << 24);
+    word[2] = e[2] | (imask << 8) | (lmask << 16) | (two << 24);
+    word[3] = block_addr[idx];
     auto pack4 = [](const uint32_t* q) { return q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24); };
     for (int k = 0; k < 3; ++k) {
       word[4 + 2 * k] = pack4(&qlo[k][0]); word[5 + 2 * k] = pack4(&qlo[k][4]);
       word[10 + 2 * k] = pack4(&qhi[k][0]); word[11 + 2 * k] = pack4(&qhi[k][4]);
     }
-    word[16] = child_base[idx]; word[17] = base_tri; word[18] = lmask | (two << 8);
-    std::memcpy(&B.nodes[(size_t)idx * kNodeWords], word, sizeof word);
+    std::memcpy(&B.recs[(size_t)node_addr[idx] * 4], word, sizeof word);
   }
   B.max_depth = maxd;
-  B.n_tri_records = (uint32_t)(B.tris.size() / 12);
-  B.n_nodelets = B.n_nodes < nodelet_budget ? B.n_nodes : nodelet_budget;
+  B.n_tri_records = n_tri_records;
+  B.n_lds_units = B.n_units < toplet_budget * 4u ? B.n_units : toplet_budget * 4u;
   // ---- materials --------------------------------------------------------------------------------------
   B.mats.resize(mats.size() * 12);
   for (size_t i = 0; i < mats.size(); ++i) {

@@ -105,7 +105,7 @@ def load_library():
     L.ptc_debug_trace_closest.argtypes = [vp, fp, fp, C.c_uint32, fp, i32p, fp]
     L.ptc_debug_trace_any.argtypes = [vp, fp, fp, fp, C.c_uint32, u8p]
     L.ptc_debug_get_flat_scene.argtypes = [vp, u32p, u32p, vp, u32p, i32p]
-    L.ptc_debug_get_bvh.argtypes = [vp, u32p, u32p, fp, fp]
+    L.ptc_debug_get_bvh.argtypes = [vp, u32p, u32p, u32p, fp, fp]
     L.ptc_debug_get_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
     L.ptc_debug_get_description.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.ptc_debug_get_material.argtypes = [vp, C.c_int, fp, C.POINTER(C.c_int)]
@@ -318,12 +318,14 @@ class PathTracer:
         return mats, texs
 
     def bvh(self):
-        nn, nt = C.c_uint32(), C.c_uint32()
-        self._ck(self._L.ptc_debug_get_bvh(self._h, C.byref(nn), C.byref(nt), None, None))
-        nodes = np.zeros((nn.value, 20), np.float32)     # 80-byte nodes
-        tris = np.zeros((nt.value, 12), np.float32)
-        self._ck(self._L.ptc_debug_get_bvh(self._h, None, None, nodes.ctypes.data_as(C.POINTER(C.c_float)), tris.ctypes.data_as(C.POINTER(C.c_float))))
-        return nodes, tris
+        """(units, n_nodes, n_tris, grid): the BVH's unit array as (n_units, 4) float32 (see include/ptc.h), node / triangle-record
+        counts and the origin grid (scene_lo.xyz, step.xyz)."""
+        nn, nt, nu = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._ck(self._L.ptc_debug_get_bvh(self._h, C.byref(nn), C.byref(nt), C.byref(nu), None, None))
+        units = np.zeros((nu.value, 4), np.float32)
+        grid = np.zeros(6, np.float32)
+        self._ck(self._L.ptc_debug_get_bvh(self._h, None, None, None, units.ctypes.data_as(C.POINTER(C.c_float)), grid.ctypes.data_as(C.POINTER(C.c_float))))
+        return units, nn.value, nt.value, grid
 
     def internals(self):
         buf = (C.c_uint64 * 8)()

@@ -367,9 +367,13 @@ def test_bench_two_rank_rehearsal(gpu):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(line) == 1, r.stdout
     d = json.loads(line[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2
-    assert d["config"]["paths"] == 256 * 192 * 2 * 2 * 2 and d["value"] > 0          # weak: 2 spp x 2 ranks per step, 2 steps
-    assert d["per_path"]["segments"] > 1.0
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 2       # the default: the frame is fixed, ranks split its pixels
+    assert d["config"]["paths"] == 256 * 192 * 2 * 2 and d["value"] > 0              # 2 spp per step, 2 steps, whole frame
+    assert d["per_path"]["segments"] > 1.0 and "torch.distributed.reduce" in d["config"]["sharding"]
+    r = subprocess.run(cmd + ["--scaling", "weak"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["scaling"] == "weak" and d["config"]["paths"] == 256 * 192 * 2 * 2 * 2  # weak (opt-in): 2 spp x 2 ranks per step, 2 steps
 
 
 def test_plain_c_client_renders(gpu, tmp_path):

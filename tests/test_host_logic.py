@@ -9,33 +9,42 @@ import pytest
 EMPTY = -(2 ** 31)
 
 
-def _decode_product(nodes, tris):
-    """Product node = 20 words (80 B, layout in ptc_scene.cpp) → per node: org bits, exponents, and per slot
-    (type, qlo[3], qhi[3], interior index or leaf triangle-record range)."""
-    w = nodes.view(np.uint32)
-    out = []
-    for i in range(w.shape[0]):
-        org = tuple(int(x) for x in w[i, 0:3])
-        ew = int(w[i, 3])
-        e = (ew & 255, (ew >> 8) & 255, (ew >> 16) & 255)
-        imask = ew >> 24
-        next_child, next_tri = int(w[i, 16]), int(w[i, 17])
-        lmask, two = int(w[i, 18]) & 255, (int(w[i, 18]) >> 8) & 255
-        assert imask & lmask == 0 and two & ~lmask == 0 and int(w[i, 18]) >> 16 == 0 and int(w[i, 19]) == 0
+def _decode_product(units, n_nodes, n_tris, grid):
+    """Product BVH = one array of 16-byte units (layout in ptc_scene.cpp): walk it from the root at unit 0 → per node: the origin's
+    16-bit grid coordinates, exponents, and per slot (type, qlo[3] + qhi[3], unit address of the interior child or of the leaf's first
+    triangle record, primitive ids of the leaf).  Also checks the structural rules of the layout."""
+    w = units.view(np.uint32)
+    out, todo, seen_units = [], [0], np.zeros(len(units), np.int32)
+    while todo:
+        u = todo.pop()
+        assert u % 4 == 0                                            # nodes sit on 64-byte boundaries
+        seen_units[u:u + 4] += 1
+        n = w[u:u + 4].reshape(16)
+        oq = (int(n[0]) & 0xFFFF, int(n[0]) >> 16, int(n[1]) & 0xFFFF)
+        e = ((int(n[1]) >> 16) & 255, int(n[1]) >> 24, int(n[2]) & 255)
+        imask, lmask, two = (int(n[2]) >> 8) & 255, (int(n[2]) >> 16) & 255, int(n[2]) >> 24
+        assert imask & lmask == 0 and two & ~lmask == 0
+        block = int(n[3])
+        assert block % 4 == 0 and block > u                         # children blocks are 64-byte aligned and come after their node
+        next_child, next_tri = block, block + 4 * bin(imask).count("1")
         kids = []
         for c in range(8):
-            q = [(int(w[i, 4 + 2 * k + c // 4]) >> (8 * (c % 4))) & 255 for k in range(6)]          # qlo.xyz, qhi.xyz
+            q = [(int(n[4 + 2 * k + c // 4]) >> (8 * (c % 4))) & 255 for k in range(6)]          # qlo.xyz, qhi.xyz
             if (imask >> c) & 1:
                 kids.append((2, q, next_child, ()))
-                next_child += 1
+                todo.append(next_child)
+                next_child += 4
             elif (lmask >> c) & 1:
                 cnt = 1 + ((two >> c) & 1)
-                prims = tuple(int(x) for x in tris[next_tri:next_tri + cnt, 3].view(np.uint32))
+                prims = tuple(int(w[next_tri + 3 * j, 3]) for j in range(cnt))
+                seen_units[next_tri:next_tri + 3 * cnt] += 1
                 kids.append((1, q, next_tri, prims))
-                next_tri += cnt
+                next_tri += 3 * cnt
             else:
                 kids.append((0, q, -1, ()))
-        out.append((org, e, kids))
+        out.append((oq, e, kids, u))
+    assert len(out) == n_nodes and seen_units.max() == 1          # every unit belongs to at most one record
+    assert int(seen_units.sum()) == 4 * n_nodes + 3 * n_tris       # the rest is alignment padding
     return out
 
 
@@ -43,9 +52,9 @@ def _decode_oracle(nodes, tris):
     w = nodes.view(np.uint32)
     out = []
     for i in range(w.shape[0]):
-        org = tuple(int(x) for x in w[i, 0:3])
-        e = tuple(int(x) for x in w[i, 3:6])
-        qlo, qhi, code = w[i, 6:30].reshape(3, 8), w[i, 30:54].reshape(3, 8), w[i, 54:62].view(np.int32)
+        oq = tuple(int(x) for x in w[i, 3:6])
+        e = tuple(int(x) for x in w[i, 6:9])
+        qlo, qhi, code = w[i, 9:33].reshape(3, 8), w[i, 33:57].reshape(3, 8), w[i, 57:65].view(np.int32)
         kids = []
         for c in range(8):
             q = [int(qlo[k, c]) for k in range(3)] + [int(qhi[k, c]) for k in range(3)]
@@ -58,7 +67,7 @@ def _decode_oracle(nodes, tris):
                 kids.append((1, q, first, tuple(int(x) for x in tris[first:first + cnt, 3].view(np.uint32))))
             else:
                 kids.append((2, q, k, ()))
-        out.append((org, e, kids))
+        out.append((oq, e, kids, i))
     return out
 
 
@@ -66,7 +75,7 @@ def _canon(decoded):
     """Layout-independent rows: boxes, child types and the primitive ids of leaf children (node indices and
     triangle-record positions differ between the two builders by design)."""
     rows = []
-    for org, e, kids in decoded:
+    for org, e, kids, _ in decoded:
         r = list(org) + list(e)
         for typ, q, _, prims in kids:
             r += [typ] + q + list(prims) + [-1] * (2 - len(prims))
@@ -83,10 +92,27 @@ def test_flatten_and_lbvh_equal_oracle(ora, pbr, name, kw):
     v1, i1, m1 = pt.flat_scene()
     v2, i2, m2 = o.flat_scene()
     assert np.array_equal(v1.view(np.uint32), v2.view(np.uint32)) and np.array_equal(i1, i2) and np.array_equal(m1, m2)
-    n1, t1 = pt.bvh()
+    units, nn, nt, grid = pt.bvh()
     n2, t2 = o.bvh()
-    assert sorted(map(bytes, t1.view(np.uint8))) == sorted(map(bytes, t2.view(np.uint8))) or t1.shape[0] != t2.shape[0]   # same records, different order
-    assert n1.shape[0] == n2.shape[0] and np.array_equal(_canon(_decode_product(n1, t1)), _canon(_decode_oracle(n2, t2)))
+    dec = _decode_product(units, nn, nt, grid)
+    assert nn == n2.shape[0] and np.array_equal(_canon(dec), _canon(_decode_oracle(n2, t2)))
+    # the oracle's node origin is the grid point the product stores: org = fma(oq, step, scene_lo), here in exact arithmetic
+    # (the float32 fma rounds the exact value once)
+    from fractions import Fraction as F
+    import struct
+    for row in n2[:: max(1, len(n2) // 200)]:
+        for k in range(3):
+            exact = F(float(grid[k])) + F(int(row.view(np.uint32)[3 + k])) * F(float(grid[3 + k]))
+            got = F(float(row[k]))
+            ulp = F(float(np.spacing(np.float32(abs(float(row[k])) or 1e-30))))
+            assert abs(got - exact) <= ulp / 2, (row[k], float(exact))
+    # triangle records: the same (v0,prim | e1,class | e2) rows as the oracle's, in a different order
+    recs = []
+    for _, _, kids, _ in dec:
+        for typ, _, ref, prims in kids:
+            if typ == 1:
+                recs += [units[ref + 3 * j: ref + 3 * j + 3].reshape(12) for j in range(len(prims))]
+    assert sorted(map(bytes, np.asarray(recs, np.float32).view(np.uint8))) == sorted(map(bytes, t2.view(np.uint8)))
     s1, s2 = pt.stats(), o.stats()
     for k in ("n_triangles", "n_bvh_nodes", "n_emitters", "bvh_max_depth"):
         assert s1[k] == s2[k]
@@ -96,20 +122,22 @@ def test_flatten_and_lbvh_equal_oracle(ora, pbr, name, kw):
 def test_bvh_is_a_valid_partition(pbr):
     d = pbr.scenes.sphere_scene()
     pt = pbr.PathTracer(pbr.DEVICE_NONE).load_scene(d)
-    nodes, tris = pt.bvh()
-    dec = _decode_product(nodes, tris)
-    n_rec = tris.shape[0]
-    seen = np.zeros(n_rec, int)
-    interior_refs = np.zeros(len(dec), int)
-    P0, E1, E2 = tris[:, 0:3].astype(np.float64), tris[:, 4:7].astype(np.float64), tris[:, 8:11].astype(np.float64)
-    lo_t = np.minimum(np.minimum(P0, P0 + E1), P0 + E2)
-    hi_t = np.maximum(np.maximum(P0, P0 + E1), P0 + E2)
-    n_children = 0
+    units, nn, nt, grid = pt.bvh()
+    dec = _decode_product(units, nn, nt, grid)
+    by_addr = {u: i for i, (_, _, _, u) in enumerate(dec)}
+    tri = lambda ref: units[ref:ref + 3].reshape(12)
+    n_children, prims_seen, interior_refs = 0, [], np.zeros(len(dec), int)
 
-    def box(org, e, q):
-        o = np.asarray(org, np.uint32).view(np.float32).astype(np.float64)
-        s = np.array([2.0 ** (x - 127) for x in e])
-        return o + np.asarray(q[:3]) * s, o + np.asarray(q[3:]) * s
+    def tri_box(ref):
+        t = tri(ref).astype(np.float64)
+        P0, E1, E2 = t[0:3], t[4:7], t[8:11]
+        pts = np.stack([P0, P0 + E1, P0 + E2])
+        return pts.min(0), pts.max(0)
+
+    def box(oq, e, q):
+        o = np.asarray(grid[:3], np.float64) + np.asarray(oq, np.float64) * np.asarray(grid[3:], np.float64)
+        sc = np.array([2.0 ** (x - 127) for x in e])
+        return o + np.asarray(q[:3]) * sc, o + np.asarray(q[3:]) * sc
 
     exact = {}
 
@@ -118,38 +146,38 @@ def test_bvh_is_a_valid_partition(pbr):
             lo, hi = np.full(3, np.inf), np.full(3, -np.inf)
             for typ, q, ref, prims in dec[i][2]:
                 if typ == 1:
-                    lo, hi = np.minimum(lo, lo_t[ref:ref + len(prims)].min(0)), np.maximum(hi, hi_t[ref:ref + len(prims)].max(0))
+                    for j in range(len(prims)):
+                        tl, th = tri_box(ref + 3 * j)
+                        lo, hi = np.minimum(lo, tl), np.maximum(hi, th)
                 elif typ == 2:
-                    clo, chi = subtree_box(ref)
+                    clo, chi = subtree_box(by_addr[ref])
                     lo, hi = np.minimum(lo, clo), np.maximum(hi, chi)
             exact[i] = (lo, hi)
         return exact[i]
 
-    for i, (org, e, kids) in enumerate(dec):
+    for i, (oq, e, kids, _) in enumerate(dec):
         assert sum(1 for k in kids if k[0] != 0) >= 2           # at least two children
         nxt = None
         for typ, q, ref, prims in kids:
             if typ == 0:
                 continue
             n_children += 1
-            lo, hi = box(org, e, q)                             # quantised box: must contain the exact one
+            lo, hi = box(oq, e, q)                              # quantised box: must contain the exact one
             if typ == 1:
-                cnt = len(prims)
-                assert 1 <= cnt <= 2
-                seen[ref:ref + cnt] += 1
-                assert (lo_t[ref:ref + cnt] >= lo - 1e-4).all() and (hi_t[ref:ref + cnt] <= hi + 1e-4).all()   # e1/e2 are rounded differences
+                assert 1 <= len(prims) <= 2
+                prims_seen += list(prims)
+                for j in range(len(prims)):
+                    tl, th = tri_box(ref + 3 * j)
+                    assert (tl >= lo - 1e-4).all() and (th <= hi + 1e-4).all()   # e1/e2 are rounded differences
             else:
-                interior_refs[ref] += 1
-                assert nxt is None or ref == nxt                # interior children are consecutive nodes
-                nxt = ref + 1
-                clo, chi = subtree_box(ref)
+                interior_refs[by_addr[ref]] += 1
+                assert nxt is None or ref == nxt                # interior children are consecutive 64-byte records
+                nxt = ref + 4
+                clo, chi = subtree_box(by_addr[ref])
                 assert (clo >= lo - 1e-4).all() and (chi <= hi + 1e-4).all()
-                ext = np.maximum(chi - clo, 1e-6)
-    assert (seen == 1).all()                                    # every triangle record in exactly one leaf
-    assert interior_refs[0] == 0 and (interior_refs[1:] == 1).all()   # a tree rooted at node 0
-    assert n_children / len(dec) > 4.0                          # the greedy collapse fills the nodes (only all-leaf nodes stay short)
-    prim = tris[:, 3].view(np.uint32)
-    assert np.array_equal(np.sort(prim), np.arange(n_rec))       # a permutation of the primitives
+    assert interior_refs[by_addr[0]] == 0 and (np.delete(interior_refs, by_addr[0]) == 1).all()   # a tree rooted at unit 0
+    assert n_children / len(dec) > 4.0                          # the cost-optimal collapse fills the nodes
+    assert sorted(prims_seen) == list(range(d.n_triangles))     # every primitive in exactly one leaf
 
 
 def test_single_triangle_and_tiny_scenes(ora, pbr):

@@ -8,7 +8,7 @@ pt = pbr_amd.PathTracer(0).load_scene(scenes.atrium())
 pt.frame_begin(1920, 1080, 4, seed=3, max_bounces=8)
 pt.frame_add_samples(4); pt.sync()
 st = pt.stats(); c = pt.raw_counters()
-names = ["segments", "shadow", "hits", "nodes_c", "tris_c", "nodes_a", "tris_a", "node_iters", "tri_iters", "leaf_visits", "rounds", "refilled"]
+names = ["segments", "shadow", "hits", "nodes_c", "tris_c", "nodes_a", "tris_a", "node_iters", "tri_iters", "leaf_visits", "rounds", "refilled"]   # node_iters / tri_iters / rounds: wave-level iterations of the closest-hit kernel
 d = dict(zip(names, c)); print(d)
 print("node-phase lane utilisation  %.3f" % (d["nodes_c"] / (64.0 * max(1, d["node_iters"]))))
 print("tri-phase lane utilisation   %.3f" % (d["tris_c"] / (64.0 * max(1, d["tri_iters"]))))
