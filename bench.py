@@ -27,7 +27,10 @@ Extra objects on the JSON line:
                `traffic` = HBM-side bytes per launch from the same PMC profile; `algorithmic_*` = the
                SURVEY §8(d) byte model (counted units × record sizes), labelled as such: those bytes are mostly
                served by LDS / L2 / Infinity Cache and are NOT an HBM roofline.
+               `frac` uses the live HIP-event time of a launch, which includes the time it shares the chip with the other
+               lane's kernels; `frac_exclusive` uses the kernel's exclusive duration from the profile's serialised run.
   kernels      the same two rooflines (valu_issue, hbm) for k_trace_closest, k_trace_any and k_shade.
+  whole_frame  VALU issue and HBM rates of the three kernels together over the timed wall time.
   cpu_baseline the oracle (scalar C restatement, kind "port") timed on this box's host cores on a
                bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -196,14 +199,32 @@ def main():
                 gbs = n_units * m["hbm_bytes_per_unit"] / sec / 1e9
                 e["hbm"] = {"achieved": gbs, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
                             "bytes_per_launch": n_units * m["hbm_bytes_per_unit"] / nl}
+            # The live event time of a launch includes the time it shares the chip with the other lane's kernels; the profile's
+            # serialised run gives the kernel's exclusive duration for the same units per launch.
+            if m.get("serialised_ms_per_launch") and m.get("serialised_units_per_launch"):
+                excl_ms = m["serialised_ms_per_launch"] * (n_units / nl) / m["serialised_units_per_launch"]
+                e["exclusive_launch_ms_from_profile"] = excl_ms
+                if "valu_issue" in e:
+                    e["valu_issue"]["frac_exclusive"] = n_units / nl * m["valu_winstr_per_unit"] / (excl_ms * 1e-3) / 1e9 / e["valu_issue"]["peak"]
+                if "hbm" in e:
+                    e["hbm"]["frac_exclusive"] = n_units / nl * m["hbm_bytes_per_unit"] / (excl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             kernels[kname] = e
+        whole = None
+        if all("valu_issue" in kernels[k] and "hbm" in kernels[k] for k in kernels):
+            winstr = sum(float(d[units[k][0]]) * model[k]["valu_winstr_per_unit"] for k in kernels)
+            hbm_b = sum(float(d[units[k][0]]) * model[k]["hbm_bytes_per_unit"] for k in kernels)
+            pk = valu_peak_measured or VALU_PEAK_PAPER_GIPS
+            whole = {"note": "the three kernels together over the timed wall time (two lanes share the chip, so per-kernel event times overlap)",
+                     "valu_issue_G_winstr_s": winstr / dt / 1e9, "valu_issue_frac": winstr / dt / 1e9 / pk,
+                     "hbm_GBs": hbm_b / dt / 1e9, "hbm_frac": hbm_b / dt / 1e9 / HBM_PEAK_GBS}
         n_launch = max(1, d["launches_trace_closest"])
-        tc_bytes = d["segments"] * (56 + 16) + d["node_visits_closest"] * 80 + d["tri_tests_closest"] * 48
+        tc_bytes = d["segments"] * (56 + 16) + d["node_visits_closest"] * 64 + d["tri_tests_closest"] * 48
         tc_sec = d["seconds_trace_closest"]
         tc = kernels["k_trace_closest"]
         if "valu_issue" in tc:
             roof = {"bound": "valu_issue", "kernel": "k_trace_closest", "achieved": tc["valu_issue"]["achieved"], "peak": tc["valu_issue"]["peak"],
                     "unit": "G wave-instr/s", "frac": tc["valu_issue"]["frac"], "frac_of_paper_peak": tc["valu_issue"]["frac_of_paper_peak"],
+                    "frac_exclusive": tc["valu_issue"].get("frac_exclusive"), "exclusive_launch_ms_from_profile": tc.get("exclusive_launch_ms_from_profile"),
                     "peak_kind": tc["valu_issue"]["peak_kind"], "traffic": tc.get("hbm", {}).get("bytes_per_launch"),
                     "hbm_achieved_GBs": tc.get("hbm", {}).get("achieved"), "hbm_frac": tc.get("hbm", {}).get("frac")}
         else:   # no committed profile to calibrate from: report the physical side as unknown rather than a byte model as a bound
@@ -235,6 +256,7 @@ def main():
             },
             "roofline": roof,
             "kernels": kernels,
+            "whole_frame": whole,
             "whole_path_algorithmic_GBs": tot["algorithmic_bytes"] / dt / 1e9,
             "scene_commit_seconds": s1.get("seconds_commit"),    # flatten + SAH BVH + upload, once per scene, outside the timed region
             "seconds": {"wall": dt, "trace_closest": d["seconds_trace_closest"], "trace_any": d["seconds_trace_any"], "shade": d["seconds_shade"]},

@@ -55,7 +55,7 @@
 #define S_RAY 56u
 #define S_HIT 16u
 #define S_SHADOW 44u
-#define S_NODE 80u
+#define S_NODE 64u
 #define S_TRI 48u
 #define S_SURF 176u
 #define S_FB 16u

@@ -216,7 +216,9 @@ PT_DEV uint32_t node_visit(const DevScene& sc, uint32_t node_addr, int cur, cons
               oz = pt_fma((float)(w1 & 0xffffu), sc.grid_step[2], sc.grid_lo[2]);
   const float ax = __uint_as_float(((w1 >> 16) & 255u) << 23) * r.inv.x, ay = __uint_as_float((w1 >> 24) << 23) * r.inv.y,
               az = __uint_as_float((w2 & 255u) << 23) * r.inv.z;
-  const float bx = pt_fma(ox, r.inv.x, -r.ood.x), by = pt_fma(oy, r.inv.y, -r.ood.y), bz = pt_fma(oz, r.inv.z, -r.ood.z);
+  // o·inv is recomputed here (the same product make_ray forms) instead of living in three registers for the ray's lifetime:
+  // that is what keeps the kernel within the 64 VGPRs of 8 waves per SIMD without spilling
+  const float bx = pt_fma(ox, r.inv.x, -(r.o.x * r.inv.x)), by = pt_fma(oy, r.inv.y, -(r.o.y * r.inv.y)), bz = pt_fma(oz, r.inv.z, -(r.o.z * r.inv.z));
   const bool px = (oct & 1u) != 0u, py = (oct & 2u) != 0u, pz = (oct & 4u) != 0u;
   // [0]: slots 0-3, [1]: slots 4-7
   const uint32_t lx[2] = {__float_as_uint(f1.x), __float_as_uint(f1.y)}, ly[2] = {__float_as_uint(f1.z), __float_as_uint(f1.w)},
@@ -232,7 +234,11 @@ PT_DEV uint32_t node_visit(const DevScene& sc, uint32_t node_addr, int cur, cons
     for (int i = 3; i >= 0; --i) {      // slot 4h+i; descending, so that shifting the results in leaves slot s in bit s
       const float tn = hw_max(hw_max(hw_max(pt_fma(ubyte_f(nqx, i), ax, bx), pt_fma(ubyte_f(nqy, i), ay, by)), pt_fma(ubyte_f(nqz, i), az, bz)), tmin);
       const float tf = hw_min(hw_min(hw_min(pt_fma(ubyte_f(fqx, i), ax, bx), pt_fma(ubyte_f(fqy, i), ay, by)), pt_fma(ubyte_f(fqz, i), az, bz)), tlimit);
+#ifndef PT_NO_ADDC
+      asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hits) : "v"(tn), "v"(tf) : "vcc");   // hits = 2·hits + (tn <= tf)
+#else
       hits = hits + hits + (tn <= tf ? 1u : 0u);
+#endif
     }
   }
   masks = w2 >> 8;

@@ -763,8 +763,8 @@ int ptc_get_stats(ptc_ctx* c, ptc_stats* out) {
   s.node_visits_closest = st[ST_NODES_C]; s.tri_tests_closest = st[ST_TRIS_C];
   s.node_visits_any = st[ST_NODES_A]; s.tri_tests_any = st[ST_TRIS_A];
   // SURVEY §8d byte model with this build's record sizes (DESIGN.md §"Algorithmic bytes")
-  s.algorithmic_bytes = s.segments * (2u * 56u + 2u * 16u) + s.node_visits_closest * 80u + s.tri_tests_closest * 48u + s.hits * 176u +
-                        s.shadow_rays * (2u * 44u) + s.node_visits_any * 80u + s.tri_tests_any * 48u + s.paths * (2u * 16u);
+  s.algorithmic_bytes = s.segments * (2u * 56u + 2u * 16u) + s.node_visits_closest * 64u + s.tri_tests_closest * 48u + s.hits * 176u +
+                        s.shadow_rays * (2u * 44u) + s.node_visits_any * 64u + s.tri_tests_any * 48u + s.paths * (2u * 16u);
   collect_times(c, true);
   *out = c->stats;
   return PTC_OK;

@@ -12,6 +12,7 @@
 
 #include <array>
 #include <cstdint>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -67,7 +68,11 @@ public:
   explicit PathTraceRenderSystem(int device) : _ctx(ptc_create(device)) {
     if (!_ctx) throw std::runtime_error(ptc_last_error(nullptr));
   }
-  ~PathTraceRenderSystem() { ptc_destroy(_ctx); }
+  // a view of a context owned elsewhere (one device of a DeviceGroup)
+  explicit PathTraceRenderSystem(ptc_ctx* borrowed) : _ctx(borrowed), _owned(false) {
+    if (!_ctx) throw std::runtime_error("PathTraceRenderSystem: null context");
+  }
+  ~PathTraceRenderSystem() { if (_owned) ptc_destroy(_ctx); }
   PathTraceRenderSystem(PathTraceRenderSystem const&) = delete;
   auto operator=(PathTraceRenderSystem const&) -> PathTraceRenderSystem& = delete;
 
@@ -104,13 +109,51 @@ public:
     ck(ptc_tonemap_rgba8(_ctx, out.data()));
     return out;
   }
+  // the same image in the reference's HdrImage format, RGBA16F (PbrRenderSystem.hpp:21, HdrImage.cpp:20): what a viewer shim
+  // copies into the image the tonemapper samples
+  auto radianceHalf() -> std::vector<std::uint16_t> {
+    std::vector<std::uint16_t> out((std::size_t)_w * _h * 4);
+    ck(ptc_read_radiance_rgba16f(_ctx, out.data()));
+    return out;
+  }
+  auto readRadiance(int w, int h) -> std::vector<float> {
+    std::vector<float> out((std::size_t)w * h * 4);
+    ck(ptc_read_radiance_rgba32f(_ctx, out.data()));
+    _w = w; _h = h;
+    return out;
+  }
   auto stats() -> ptc_stats { ptc_stats s; ck(ptc_get_stats(_ctx, &s)); return s; }
   auto handle() -> ptc_ctx* { return _ctx; }
 
 private:
   auto ck(int rc) -> int { if (rc < 0) throw std::runtime_error(ptc_last_error(_ctx)); return rc; }
   ptc_ctx* _ctx;
+  bool _owned = true;
   int _w = 0, _h = 0;
+};
+
+// Several GPUs driven by one process (ptc_group: one context per device + an RCCL communicator): the same scene is committed on
+// every device, render() traces device i's 32x32-pixel tiles on device i and reduces the framebuffer onto device 0 (ncclReduce).
+// The reference has a single vk::Device (core/GpuHandle.cpp:94-101); this is the build's multi-GPU addition.
+class DeviceGroup {
+public:
+  explicit DeviceGroup(std::vector<int> const& devices) : _g(ptc_group_create(devices.data(), (int)devices.size())) {
+    if (!_g) throw std::runtime_error(ptc_group_last_error(nullptr));
+    for (int i = 0; i < ptc_group_size(_g); ++i) _views.emplace_back(new PathTraceRenderSystem(ptc_group_ctx(_g, i)));
+  }
+  ~DeviceGroup() { _views.clear(); ptc_group_destroy(_g); }
+  DeviceGroup(DeviceGroup const&) = delete;
+  auto operator=(DeviceGroup const&) -> DeviceGroup& = delete;
+  [[nodiscard]] auto size() const -> int { return (int)_views.size(); }
+  auto device(int i) -> PathTraceRenderSystem& { return *_views[(std::size_t)i]; }
+  auto render(int w, int h, int spp, std::uint64_t seed, int maxBounces, int integrator = PTC_INTEGRATOR_PATH) -> std::vector<float> {
+    if (ptc_group_render(_g, w, h, spp, seed, maxBounces, integrator) < 0) throw std::runtime_error(ptc_group_last_error(_g));
+    return _views[0]->readRadiance(w, h);
+  }
+
+private:
+  ptc_group* _g;
+  std::vector<std::unique_ptr<PathTraceRenderSystem>> _views;
 };
 
 }  // namespace pbr

@@ -1,6 +1,9 @@
 // ptc_render — dependency-free C++17 offline renderer over the C-ABI (include/ptc.h).
 //   ptc_render (--scene cornell|sphere | --gltf file.glb [--cam-pos x y z --cam-target x y z --fov deg]) --width W --height H
-//              --spp N --seed S --bounces B [--raster] [--env latlong.pfm | --sky] [--filter nearest|linear] --out image.pfm [--png image.png] [--ppm image.ppm]
+//              --spp N --seed S --bounces B [--raster | --raster16] [--env latlong.pfm | --sky] [--filter nearest|linear] [--device D] [--gpus N]
+//              --out image.pfm [--png image.png] [--ppm image.ppm] [--half image.f16]
+// --gpus N: devices D..D+N-1 share the frame by 32x32-pixel tiles, one RCCL reduce brings it to device D (ptc_group_*).
+// --raster16: the reference's Blinn-Phong pass lit from its G-buffer formats; --half writes the RGBA16F buffer (raw little-endian halves).
 // --env: ordinary lat-long RGB environment map (PFM, top row = up).  The reference's world is y-down (up = -y, CameraData.hpp:28) and
 // ptc_set_env_latlong_rgb32f takes row 0 = +y, so the rows are flipped on the way in.  --sky: a built-in gradient sky with a sun, for
 // assets that carry no emitters.
@@ -106,7 +109,8 @@ int main(int argc, char** argv) {
   int filter = PTC_FILTER_NEAREST;          // what the reference's default-constructed samplers do
   float camPos[3] = {0, 0, 0}, camTarget[3] = {0, 0, -1}, fovDeg = 60.0f;
   bool haveCam = false;
-  int w = 256, h = 256, spp = 64, bounces = 8, device = 0, integrator = PTC_INTEGRATOR_PATH;
+  int w = 256, h = 256, spp = 64, bounces = 8, device = 0, gpus = 0 /* 0: one plain context; N >= 1: a device group of N */, integrator = PTC_INTEGRATOR_PATH;
+  std::string halfPath;
   std::uint64_t seed = 1;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
@@ -114,6 +118,7 @@ int main(int argc, char** argv) {
     if (a == "--scene") scene = next(); else if (a == "--width") w = std::atoi(next()); else if (a == "--height") h = std::atoi(next());
     else if (a == "--spp") spp = std::atoi(next()); else if (a == "--seed") seed = std::strtoull(next(), nullptr, 10);
     else if (a == "--bounces") bounces = std::atoi(next()); else if (a == "--device") device = std::atoi(next());
+    else if (a == "--gpus") gpus = std::atoi(next()); else if (a == "--half") halfPath = next(); else if (a == "--raster16") integrator = PTC_INTEGRATOR_RASTER_GBUFFER16;
     else if (a == "--gltf") gltf = next();
     else if (a == "--env") envPath = next(); else if (a == "--sky") sky = true;
     else if (a == "--filter") { const std::string f = next(); if (f == "linear") filter = PTC_FILTER_LINEAR; else if (f == "nearest") filter = PTC_FILTER_NEAREST; else { std::cerr << "--filter nearest|linear\n"; return 2; } }
@@ -124,7 +129,8 @@ int main(int argc, char** argv) {
     else { std::cerr << "unknown argument " << a << "\n"; return 2; }
   }
   try {
-    pbr::PathTraceRenderSystem rs(device);
+    if (gpus < 0) throw std::runtime_error("--gpus must be >= 1");
+    auto buildScene = [&](pbr::PathTraceRenderSystem& rs) {
     if (!gltf.empty()) {
       const pbr::gltf::FlatScene fs = pbr::gltf::load(gltf);
       rs.beginScene();
@@ -136,6 +142,7 @@ int main(int argc, char** argv) {
                                          (fs.bbox_hi[2] - fs.bbox_lo[2]) * (fs.bbox_hi[2] - fs.bbox_lo[2]));
         camTarget[0] = cx; camTarget[1] = cy; camTarget[2] = cz;
         camPos[0] = cx; camPos[1] = cy; camPos[2] = cz + r / std::tan(0.5f * fovDeg * 3.14159265f / 180.0f) + r;
+        haveCam = true;
       }
       rs.setCamera({camPos[0], camPos[1], camPos[2]}, {camTarget[0], camTarget[1], camTarget[2]}, fovDeg * 3.14159265f / 180.0f, (float)w / h);
       if (!envPath.empty()) {
@@ -160,10 +167,31 @@ int main(int argc, char** argv) {
         if (ptc_set_env_latlong_rgb32f(rs.handle(), env.data(), ew, eh) < 0) throw std::runtime_error(ptc_last_error(rs.handle()));
       }
       rs.commitScene();
-      scene = gltf;
     } else if (scene == "cornell") buildCornell(rs); else if (scene == "sphere") buildSphere(rs, (float)w / h); else throw std::runtime_error("unknown scene " + scene);
-    const std::vector<float> img = rs.render(w, h, spp, seed, bounces, integrator);
-    const ptc_stats st = rs.stats();
+    };
+    std::unique_ptr<pbr::PathTraceRenderSystem> single;
+    std::unique_ptr<pbr::DeviceGroup> group;
+    std::vector<float> img;
+    if (gpus == 0) {
+      single.reset(new pbr::PathTraceRenderSystem(device));
+      buildScene(*single);
+      img = single->render(w, h, spp, seed, bounces, integrator);
+    } else {
+      std::vector<int> ids;
+      for (int i = 0; i < gpus; ++i) ids.push_back(device + i);
+      group.reset(new pbr::DeviceGroup(ids));
+      for (int i = 0; i < gpus; ++i) buildScene(group->device(i));
+      img = group->render(w, h, spp, seed, bounces, integrator);
+    }
+    pbr::PathTraceRenderSystem& rs = single ? *single : group->device(0);
+    if (!gltf.empty()) scene = gltf;
+    ptc_stats st = rs.stats();
+    for (int i = 1; i < gpus; ++i) { const ptc_stats o = group->device(i).stats(); st.paths += o.paths; st.node_visits_closest += o.node_visits_closest; st.node_visits_any += o.node_visits_any; }
+    if (!halfPath.empty()) {
+      const std::vector<std::uint16_t> hb = rs.radianceHalf();
+      std::ofstream g(halfPath, std::ios::binary);
+      g.write(reinterpret_cast<const char*>(hb.data()), (std::streamsize)(hb.size() * 2));
+    }
     pbr::image::write_pfm(out, img.data(), w, h);
     if (!png.empty()) { const std::vector<std::uint8_t> ldr = rs.tonemap(); pbr::image::write_png(png, ldr.data(), w, h); }
     if (!ppm.empty()) {
@@ -172,7 +200,7 @@ int main(int argc, char** argv) {
       g << "P6\n" << w << " " << h << "\n255\n";
       for (std::size_t p = 0; p < (std::size_t)w * h; ++p) g.write(reinterpret_cast<const char*>(&ldr[p * 4]), 3);
     }
-    std::printf("{\"scene\": \"%s\", \"paths\": %llu, \"seconds_render\": %.6f, \"mpaths_per_s\": %.2f, \"node_visits\": %llu}\n", scene.c_str(),
+    std::printf("{\"scene\": \"%s\", \"gpus\": %d, \"paths\": %llu, \"seconds_render\": %.6f, \"mpaths_per_s\": %.2f, \"node_visits\": %llu}\n", scene.c_str(), gpus ? gpus : 1,
                 (unsigned long long)st.paths, st.seconds_render, st.seconds_render > 0 ? st.paths / st.seconds_render / 1e6 : 0.0,
                 (unsigned long long)(st.node_visits_closest + st.node_visits_any));
   } catch (std::exception const& e) {

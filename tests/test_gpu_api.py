@@ -180,6 +180,25 @@ def test_rccl_through_the_c_abi_single_rank(gpu):
     g.close()
     with pytest.raises(gpu.PtcError):
         gpu.Group([99])
+    # the C++ host: `ptc_render --gpus 1` goes through pbr::DeviceGroup (ptc_group_*), and writes the RGBA16F buffer as well
+    import json
+    import tempfile
+
+    exe = os.path.join(os.path.dirname(gpu.ptc.LIB_PATH), "ptc_render")
+    with tempfile.TemporaryDirectory() as td:
+        out, half = os.path.join(td, "c.pfm"), os.path.join(td, "c.f16")
+        r = subprocess.run([exe, "--scene", "cornell", "--width", "96", "--height", "64", "--spp", "4", "--seed", "6", "--gpus", "1", "--out", out, "--half", half],
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        info = json.loads(r.stdout.strip().splitlines()[-1])
+        assert info["gpus"] == 1 and info["paths"] == 96 * 64 * 4
+        img = np.frombuffer(open(out, "rb").read().split(b"-1.0\n", 1)[1], "<f4").reshape(64, 96, 3)[::-1]
+        d = gpu.scenes.cornell_box()
+        d.camera.aspect = 1.0
+        ref2 = gpu.PathTracer(0).load_scene(d).render(96, 64, 4, seed=6)
+        assert _bits_equal(np.ascontiguousarray(img), np.ascontiguousarray(ref2[..., :3]))
+        with np.errstate(over="ignore"):
+            assert np.array_equal(np.fromfile(half, np.uint16).reshape(64, 96, 4), ref2.astype(np.float16).view(np.uint16))
 
 
 def test_torch_nccl_backend_world_size_1(gpu):

@@ -11,7 +11,7 @@ st = pt.stats(); c = pt.raw_counters()
 names = ["segments", "shadow", "hits", "nodes_c", "tris_c", "nodes_a", "tris_a", "node_iters", "tri_iters", "leaf_visits", "rounds", "refilled"]   # node_iters / tri_iters / rounds: wave-level iterations of the closest-hit kernel
 d = dict(zip(names, c)); print(d)
 print("node-phase lane utilisation  %.3f" % (d["nodes_c"] / (64.0 * max(1, d["node_iters"]))))
-print("tri-phase lane utilisation   %.3f" % (d["tris_c"] / (64.0 * max(1, d["tri_iters"]))))
+print("leaf-phase lane utilisation  %.3f  (triangle tests, helpers included, per 64 lanes and pass)" % (d["tris_c"] / (64.0 * max(1, d["tri_iters"]))))
 print("rays per refill round        %.2f" % (d["segments"] / max(1, d["rounds"])))
 print("node visits/ray %.1f tri tests/ray %.1f  node wave-iters/ray %.2f tri wave-iters/ray %.2f" % (d["nodes_c"]/d["segments"], d["tris_c"]/d["segments"], d["node_iters"]*64/d["segments"], d["tri_iters"]*64/d["segments"]))
 print({k: st[k] for k in ("seconds_trace_closest", "seconds_trace_any", "seconds_shade", "seconds_render")})
