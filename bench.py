@@ -129,8 +129,16 @@ def main():
             box = [uid if ok else None]
             dist.broadcast_object_list(box, src=0)
             if box[0] is not None:
-                pt.comm_init(box[0], rank, world)
-                reduce_impl = "ncclReduce via C-ABI (ptc_comm_reduce_radiance)"
+                try:
+                    pt.comm_init(box[0], rank, world)
+                    joined = 1
+                except pbr_amd.PtcError as e:
+                    print(f"bench: rank {rank}: ptc_comm_init failed ({e})", file=sys.stderr)
+                    joined = 0
+                flag = torch.tensor([joined], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # every rank uses the same reduce
+                if int(flag.item()) == 1:
+                    reduce_impl = "ncclReduce via C-ABI (ptc_comm_reduce_radiance)"
 
     def barrier():
         if world > 1:

@@ -79,7 +79,7 @@ struct ptc_ctx {
   int device = 0;
   std::string err;
   LaunchCfg cfg{};
-  uint32_t nodelet_budget = 73;   // 64-byte records staged in LDS: the top three levels (1+8+64 nodes) of the tree = 4.6 KB
+  uint32_t toplet_budget = 73;   // 64-byte records staged in LDS: the top three levels (1+8+64 nodes) of the tree = 4.6 KB
   size_t max_batch_paths = (size_t)1 << 28;   // paths in flight over all lanes: large batches amortise launch tails (sized for 288 GB of HBM:
                                               // 176 B per path -> 47 GB of queues at 1080p x 64 spp x 2 lanes; 2^27 is 2 % slower, 2^29 1 % faster)
   bool timing = true;
@@ -256,7 +256,7 @@ int configure_launch(ptc_ctx* c) {
   if (l > need) l = need;
   c->cfg.stack_lds = l;
   const size_t lds = pt_trace_lds_bytes(c->cfg, c->dsc);
-  if (lds > 160u * 1024u) return fail(c, PTC_E_ARG, "configure_launch: nodelets + stack exceed the 160 KiB of LDS");
+  if (lds > 160u * 1024u) return fail(c, PTC_E_ARG, "configure_launch: staged tree top + stack exceed the 160 KiB of LDS");
   int per_cu = pt_trace_blocks_per_cu(lds);     // registers, static LDS and launch bounds included
   if (per_cu < 1) return fail(c, PTC_E_DEVICE, "configure_launch: the trace kernels do not fit a CU with this LDS size");
   if (const char* e = std::getenv("PTC_TRACE_BLOCKS_PER_CU")) { int v = std::atoi(e); if (v >= 1 && v <= per_cu) per_cu = v; }
@@ -409,7 +409,7 @@ ptc_ctx* ptc_create(int device_id) {
   if (device_id == PTC_DEVICE_NONE) {   // description-only context: host flatten + BVH build, no rendering
     ptc_ctx* c = new ptc_ctx();
     c->device = PTC_DEVICE_NONE;
-    if (const char* s = std::getenv("PTC_NODELETS")) c->nodelet_budget = (uint32_t)std::strtoul(s, nullptr, 10);
+    if (const char* s = std::getenv("PTC_NODELETS")) c->toplet_budget = (uint32_t)std::strtoul(s, nullptr, 10);
     return c;
   }
   int n = 0;
@@ -425,7 +425,7 @@ ptc_ctx* ptc_create(int device_id) {
   c->cfg.n_cu = prop.multiProcessorCount;
   c->cfg.trace_blocks_per_cu = 4;
   c->cfg.stack_lds = 6;
-  if (const char* s = std::getenv("PTC_NODELETS")) c->nodelet_budget = (uint32_t)std::strtoul(s, nullptr, 10);
+  if (const char* s = std::getenv("PTC_NODELETS")) c->toplet_budget = (uint32_t)std::strtoul(s, nullptr, 10);
   if (const char* s = std::getenv("PTC_BATCH_PATHS")) { size_t v = std::strtoull(s, nullptr, 10); if (v >= 1024) c->max_batch_paths = v; }
   if (const char* s = std::getenv("PTC_TIMING")) c->timing = std::atoi(s) != 0;
   if (const char* s = std::getenv("PTC_LANES")) { int v = std::atoi(s); if (v >= 1 && v <= 8) c->n_lanes = v; }
@@ -566,7 +566,7 @@ int ptc_scene_commit(ptc_ctx* c) {
     { int rs = sync_all_lanes(c); if (rs) return rs; }
   }
   const auto t0 = std::chrono::steady_clock::now();
-  const std::string e = ptc_build_scene(c->mats, c->meshes, c->insts, c->texs, c->env, c->nodelet_budget, c->built);
+  const std::string e = ptc_build_scene(c->mats, c->meshes, c->insts, c->texs, c->env, c->toplet_budget, c->built);
   if (!e.empty()) return fail(c, PTC_E_STATE, e);
   ptc_make_camera(c->cam_pos, c->cam_target, c->cam_fov, c->cam_aspect, c->cam);
   c->in_frame = false; c->pending = 0;

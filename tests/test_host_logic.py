@@ -85,7 +85,7 @@ def _canon(decoded):
 
 
 @pytest.mark.parametrize("name,kw", [("cornell", {}), ("sphere10k", {}), ("two_tris_sphere", {}), ("atrium", {"scale": 0.05}), ("atrium", {})])
-def test_flatten_and_lbvh_equal_oracle(ora, pbr, name, kw):
+def test_flatten_and_bvh_equal_oracle(ora, pbr, name, kw):
     d = pbr.scenes.by_name(name, **kw)
     pt = pbr.PathTracer(pbr.DEVICE_NONE).load_scene(d)
     o = ora.Oracle().load_scene(d)
