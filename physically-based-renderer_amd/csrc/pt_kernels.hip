@@ -44,8 +44,8 @@
 #define SHADE_MIN_WAVES 1
 #endif
 #ifndef SHADE_GRID
-#define SHADE_GRID 3          // blocks per CU; occupancy (4..8 waves/SIMD) and block size (256/512) measured: no effect, the kernel is HBM-bound
-#endif
+#define SHADE_GRID 2          // blocks per CU = what is resident at 114 VGPRs (4 waves/SIMD): windows are dealt statically, so a third, non-resident
+#endif                        // block per CU only adds a tail (3: +5 % kernel time in the one-lane run); 256-thread blocks: +58 % kernel time
 #define SHADE_WAVES (SHADE_BLOCK / 64)
 #define SHADE_LDS_LIGHTS 64       // emitter table and material table are staged in LDS when they fit
 #define SHADE_LDS_MATS 64
