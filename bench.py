@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--workload", choices=["atrium", "textured"], default="atrium",
                     help="atrium = BASELINE configs[2]/[3] (the metric's configuration); textured = configs[4]: the same atrium with 1024^2 "
                          "albedo/normal/metal-rough textures and a 2048x1024 environment light")
+    ap.add_argument("--direct-scene", action="store_true", help="hand the generated arrays to the C-ABI directly instead of through a GLB file + the glTF loader")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the bounded CPU-baseline render")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --share-device rehearses N ranks on a one-GPU box")
@@ -110,7 +111,24 @@ def main():
 
     desc = scenes.atrium(args.scene_scale) if args.workload == "atrium" else scenes.textured_atrium(args.scene_scale)
     desc.camera.aspect = args.width / args.height
-    pt = pbr_amd.PathTracer(local_rank).load_scene(desc)
+    # The metric is quoted on a glTF scene: the generated scene is written as a binary glTF and comes in through the library's own
+    # loader (ptc_gltf_load: JSON, accessors, node hierarchy, PNG textures) — bit-identical to handing the arrays over directly
+    # (tests/test_gltf.py, test_gpu_parity.py::test_gltf_loaded_scene_renders_identically).
+    pt = pbr_amd.PathTracer(local_rank)
+    scene_source = "generated arrays handed to the C-ABI"
+    if args.direct_scene:
+        pt.load_scene(desc)
+    else:
+        import tempfile
+
+        from pbr_amd import gltf
+
+        with tempfile.TemporaryDirectory() as td:
+            glb = os.path.join(td, f"bench_rank{rank}.glb")
+            gltf.write_glb(desc, glb)
+            n_tri, _, _ = gltf.load_into(pt, glb, camera=desc.camera, env=getattr(desc, "env", None))
+            assert n_tri == desc.n_triangles, (n_tri, desc.n_triangles)
+            scene_source = f"binary glTF ({os.path.getsize(glb) / 1e6:.1f} MB) written from the generator, loaded by ptc_gltf_load"
     K, W, S = args.steps, args.warmup, args.spp_per_step * (world if args.scaling == "weak" else 1)
     spp_total = (K + W) * S
     pt.frame_begin(args.width, args.height, spp_total, args.seed, args.max_bounces, pbr_amd.INTEGRATOR_PATH, tile_rank=rank, tile_count=world)
@@ -259,6 +277,7 @@ def main():
                              f"textured atrium {desc.n_triangles} tris + 1024^2 albedo/normal/metal-rough textures + 2048x1024 env light (BASELINE configs[4])")
                             + f", {args.width}x{args.height}, {S * K} spp = {K} steps x {S} spp, max_bounces {args.max_bounces}, seed {args.seed}",
                 "paths": paths,
+                "scene_source": scene_source,
                 "sharding": (f"32x32 tiles over {world} ranks (each rank: 1/{world} of the pixels x {S} spp per step), {reduce_impl} to rank 0"
                              if world > 1 else "single GPU"),
             },

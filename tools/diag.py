@@ -5,8 +5,9 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "physically-base
 import pbr_amd
 from pbr_amd import scenes
 pt = pbr_amd.PathTracer(0).load_scene(scenes.atrium())
-pt.frame_begin(1920, 1080, 4, seed=3, max_bounces=8)
-pt.frame_add_samples(4); pt.sync()
+spp = int(sys.argv[1]) if len(sys.argv) > 1 else 4          # 64 = the bench's batch size: small batches overstate start-up and drain
+pt.frame_begin(1920, 1080, spp, seed=3, max_bounces=8)
+pt.frame_add_samples(spp); pt.sync()
 st = pt.stats(); c = pt.raw_counters()
 names = ["segments", "shadow", "hits", "nodes_c", "tris_c", "nodes_a", "tris_a", "node_iters", "tri_iters", "leaf_visits", "rounds", "refilled"]   # node_iters / tri_iters / rounds: wave-level iterations of the closest-hit kernel
 d = dict(zip(names, c)); print(d)

@@ -5,8 +5,9 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "physically-base
 import pbr_amd
 from pbr_amd import scenes
 pt = pbr_amd.PathTracer(0).load_scene(scenes.atrium())
-pt.frame_begin(1920, 1080, 16, seed=3, max_bounces=8)
-pt.frame_add_samples(16); pt.sync()
+spp = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+pt.frame_begin(1920, 1080, spp, seed=3, max_bounces=8)
+pt.frame_add_samples(spp); pt.sync()
 st = pt.stats(); c = pt.raw_counters()
 node, leaf, fin, refill = c[7], c[8], c[9], c[10]
 tot = node + leaf + fin + refill
