@@ -9,8 +9,8 @@
 //    waves pull 512-ray chunks (one atomic per chunk) and refill idle lanes from their private chunk;
 //    the shade kernel sorts and compacts per 512-thread block through LDS and does ONE atomic per
 //    block and output queue;
-//  * traversal is latency-bound with poor lane utilisation when a wave waits for its slowest ray, so
-//    finished lanes are refilled in place (persistent while-while with dynamic fetch);
+//  * traversal has poor lane utilisation when a wave waits for its slowest ray, so finished lanes are
+//    refilled in place (persistent while-while with dynamic fetch);
 //  * every queue access is a 16-byte lane (dwordx4); no float atomics anywhere — each per-path /
 //    per-pixel word has one owner, so results do not depend on scheduling.  MFMA is unused: there is
 //    no dense contraction on this path.
@@ -111,13 +111,14 @@ __global__ __launch_bounds__(256) void k_raygen(DevCamera cam, DevFrame fr, DevQ
 // traversal machinery shared by the closest-hit and any-hit kernels
 //
 // 8-wide BVH in one array of 16-byte units: 64-byte nodes, 48-byte triangle records (layout: ptc_scene.cpp); addresses are
-// unit indices.  What bounds these kernels is the address-processing rate of the vector-memory path: a wave instruction that
-// gathers 16 bytes per lane from 64 unrelated lines costs ~50 cycles of a CU's texture-address unit whatever the L2 hit
-// rate (tools/gather_bench.hip: 45 GB/s per CU), while four adjacent lanes reading one contiguous 64-byte node cost a
-// quarter of the lookups (64 GB/s per CU, the L2->CU limit).  So a wave fetches its 64 nodes COOPERATIVELY: in pass j lane l
-// loads piece l&3 of the node of lane 16j + l/4, straight into LDS (global_load_lds_dwordx4: destination = wave-uniform
-// base + lane x 16, which lays the 64 nodes out contiguously), and every lane then reads its own node from LDS.  The top of
-// the tree (breadth-first prefix of the unit array) is staged in LDS once per block and read from there.
+// unit indices.  Both kernels are bound by vector-instruction issue (0.81 / 0.73 of the measured ceiling; 42 % of the
+// wave-cycles wait for an issue slot), so the design minimises instructions per ray: fat nodes (12 visits per ray instead of 16),
+// no sort, one stack entry per node instead of one per child, and everything that raises lane utilisation (lane refill, phase
+// thresholds, helper lanes in the leaf phase).  Every lane gathers its own node with four 16-byte loads; the top of the tree
+// (breadth-first prefix of the unit array) is staged in LDS once per block.  The alternative fetch — a wave loads its 64 nodes
+// cooperatively, four adjacent lanes per node, straight into LDS (global_load_lds_dwordx4) — needs a quarter of the address lookups
+// (tools/gather_bench.hip: 64 instead of 45 GB/s per CU) and is kept behind -DTRACE_COOP=1, but it is 13 % slower here: the gather
+// rate is not what binds.
 // A ray keeps ONE group of pending interior children in
 // registers — (block address, hits<<8 | imask): the slots of one node that were hit and not yet entered — and the
 // older groups on a per-lane stack of 8-byte entries.  The first `L` entries live in LDS (stride 64 lanes:
