@@ -204,7 +204,7 @@ def main():
         assert abs(tot["paths"] - paths) < 0.5, (tot["paths"], paths)
         # Rooflines of the three kernels that carry the frame, on this rank.  Units are counted by the kernels; the
         # per-unit instruction and HBM-byte figures come from the committed PMC profile of the same workload.
-        model = _load_json(os.path.join(ROOT, "profiles", "r02_kernel_model.json")) or {}
+        model = _load_json(os.path.join(ROOT, "profiles", "r02_kernel_model.json" if args.workload == "atrium" else "r02_textured_kernel_model.json")) or {}
         valu = _load_json(os.path.join(ROOT, "profiles", "r02_valu_issue.json")) or {}
         ns_per_instr = valu.get("ns_per_instr_per_simd_at_7_waves")
         valu_peak_measured = N_SIMD / ns_per_instr if ns_per_instr else None          # G wave-instr/s
