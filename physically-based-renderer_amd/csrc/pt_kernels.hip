@@ -33,10 +33,6 @@
 #ifndef TRACE_NODE_MIN
 #define TRACE_NODE_MIN 40         // leave the node loop when fewer lanes than this are still at interior nodes
 #endif                            // while others wait at a leaf (keeps both phases well populated; 24: -6 %, 32: -1.5 %, 48: -3 %, 56: -18 %)
-#ifndef TRACE_COOP
-#define TRACE_COOP 0              // 0: every lane gathers its own node with four 16-byte loads.  1: a wave fetches its nodes cooperatively (four
-#endif                            // lanes per 64-byte node, LDS-DMA into a 4-KiB stage): a quarter of the address lookups, but measured 13 % SLOWER —
-                                  // the stage costs 3 blocks per CU of occupancy and the kernels are not bound by the gather rate
 #ifndef SHADE_BLOCK
 #define SHADE_BLOCK 512
 #endif
@@ -117,8 +113,8 @@ __global__ __launch_bounds__(256) void k_raygen(DevCamera cam, DevFrame fr, DevQ
 // thresholds, helper lanes in the leaf phase).  Every lane gathers its own node with four 16-byte loads; the top of the tree
 // (breadth-first prefix of the unit array) is staged in LDS once per block.  The alternative fetch — a wave loads its 64 nodes
 // cooperatively, four adjacent lanes per node, straight into LDS (global_load_lds_dwordx4) — needs a quarter of the address lookups
-// (tools/gather_bench.hip: 64 instead of 45 GB/s per CU) and is kept behind -DTRACE_COOP=1, but it is 13 % slower here: the gather
-// rate is not what binds.
+// (tools/gather_bench.hip: 64 instead of 45 GB/s per CU) but was 13 % slower here (commit 8dfd8eb has it): its 4-KiB stage per wave
+// costs occupancy, and the gather rate is not what binds.
 // A ray keeps ONE group of pending interior children in
 // registers — (block address, hits<<8 | imask): the slots of one node that were hit and not yet entered — and the
 // older groups on a per-lane stack of 8-byte entries.  The first `L` entries live in LDS (stride 64 lanes:
@@ -172,29 +168,8 @@ PT_DEV void build_order_table(uint8_t* tab) {
   }
 }
 
-// Cooperative fetch of the wave's nodes into its 4-KiB LDS stage (64 x 64 B): the node of lane o lands at stage + 64 o.
-// Lanes with cur < n_lds_units (staged prefix) or cur < 0 (no node wanted) are skipped.  `stage_addr` is the wave-uniform LDS
-// byte address of the stage.  Ends with s_waitcnt vmcnt(0): the compiler does not count asm loads.
-PT_DEV void fetch_nodes(const DevScene& sc, uint32_t stage_addr, int cur, uint32_t lane) {
-  const uint32_t piece = lane & 3u, sub = lane >> 2;
-  int ocur[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) ocur[j] = __builtin_amdgcn_ds_bpermute((int)((16u * (uint32_t)j + sub) << 2), cur);   // 4 crossbar reads in flight
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    if (ocur[j] >= (int)sc.n_lds_units) {
-      const float4* src = sc.recs + ((size_t)(uint32_t)ocur[j] + piece);
-      const uint32_t dst = stage_addr + 1024u * (uint32_t)j;
-      unsigned keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// One node visit: the 8 slots of the node at LDS byte address `node_addr` (the wave's stage or the staged top of the tree)
-// against [tmin, tlimit].  Returns the hit mask (bit s = slot s, empty slots masked off), the node's children-block address
+// One node visit: the 8 slots of node `cur` (read from the staged top of the tree at LDS byte address `node_addr` when it lies there,
+// else gathered from global memory) against [tmin, tlimit].  Returns the hit mask (bit s = slot s, empty slots masked off), the node's children-block address
 // and its slot masks (imask | lmask<<8 | two<<16).
 // Per-ray constants of the slab test: the sign of each direction component says which of a child's two planes on that
 // axis is entered first, so near/far need no min/max (identical values to min(t0,t1) / max(t0,t1): fma is monotonic in
@@ -205,7 +180,7 @@ PT_DEV uint32_t node_visit(const DevScene& sc, uint32_t node_addr, int cur, cons
   typedef __attribute__((address_space(3))) const fx4 lds_f4;
   typedef __attribute__((address_space(1))) const fx4 glb_f4;
   fx4 f0, f1, f2, f3;
-  if (TRACE_COOP || (uint32_t)cur < sc.n_lds_units) {
+  if ((uint32_t)cur < sc.n_lds_units) {
     lds_f4* p = (lds_f4*)(uintptr_t)node_addr;                    // ds_read_b128 × 4
     f0 = p[0]; f1 = p[1]; f2 = p[2]; f3 = p[3];
   } else {
@@ -317,15 +292,12 @@ struct Reservoir {
 #define DIAG_ITER(var) do { } while (0)
 #endif
 
-// LDS of a trace block: [n_lds_units × 16 B: the top of the tree][waves × 4 KiB node stage][waves × L × 64 stack entries of 8 B]
-// [2 KiB slot-order table (closest hit only)]
-struct TraceLds { uint32_t top_addr, stage_addr; uint2* stack; uint8_t* order_tab; };
-PT_DEV TraceLds trace_lds(float4* lds_raw, const DevScene& sc, uint32_t wave, int stack_lds) {
+// LDS of a trace block: [n_lds_units × 16 B: the top of the tree][waves × L × 64 stack entries of 8 B][2 KiB slot-order table (closest hit only)]
+struct TraceLds { uint32_t top_addr; uint2* stack; uint8_t* order_tab; };
+PT_DEV TraceLds trace_lds(float4* lds_raw, const DevScene& sc, int stack_lds) {
   TraceLds t;
-  float4* stage = lds_raw + sc.n_lds_units;
   t.top_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_raw;
-  t.stage_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(stage + (size_t)wave * 256u));
-  t.stack = reinterpret_cast<uint2*>(stage + (TRACE_COOP ? (size_t)TRACE_WAVES * 256u : 0u));
+  t.stack = reinterpret_cast<uint2*>(lds_raw + sc.n_lds_units);
   t.order_tab = reinterpret_cast<uint8_t*>(t.stack + (size_t)TRACE_WAVES * (size_t)stack_lds * 64u);
   return t;
 }
@@ -354,7 +326,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_closest(
   __shared__ uint8_t s_pair[2][TRACE_WAVES][64];   // leaf phase: k-th owner with a second triangle <-> k-th free lane
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
-  const TraceLds L = trace_lds(lds_raw, sc, wave, stack_lds);
+  const TraceLds L = trace_lds(lds_raw, sc, stack_lds);
   uint8_t* order_tab = L.order_tab;
   for (uint32_t i = threadIdx.x; i < sc.n_lds_units; i += TRACE_BLOCK) lds_raw[i] = sc.recs[i];
   build_order_table(order_tab);
@@ -408,11 +380,10 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_closest(
         if (!mn) break;
         if (__popcll(mn) < TRACE_NODE_MIN && __ballot(cur == CUR_LEAF)) break;   // few walkers, triangles waiting
         nv += (unsigned long long)__popcll(mn);
-        if (TRACE_COOP) fetch_nodes(sc, L.stage_addr, cur, lane);    // all lanes take part: every lane loads pieces of other lanes' nodes
         if (cur >= 0) {
           DIAG_ITER(d_node);
           uint32_t nb, masks;
-          const uint32_t node_addr = (uint32_t)cur < sc.n_lds_units ? L.top_addr + 16u * (uint32_t)cur : L.stage_addr + 64u * lane;
+          const uint32_t node_addr = L.top_addr + 16u * (uint32_t)cur;
           const uint32_t hits = node_visit(sc, node_addr, cur, r, oct, tmin, best_t, nb, masks);
           const uint32_t imask = masks & 255u, lhits = hits & (masks >> 8);
           enter_group(gbase, gmask, st, nb, hits & imask, imask);
@@ -513,7 +484,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_any(DevS
   __shared__ uint8_t s_pair[2][TRACE_WAVES][64];   // leaf phase: k-th owner with a second triangle <-> k-th free lane
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
-  const TraceLds L = trace_lds(lds_raw, sc, wave, stack_lds);
+  const TraceLds L = trace_lds(lds_raw, sc, stack_lds);
   for (uint32_t i = threadIdx.x; i < sc.n_lds_units; i += TRACE_BLOCK) lds_raw[i] = sc.recs[i];
   __syncthreads();
   const uint32_t n = q.cnt[CNT_SHADOW];
@@ -551,10 +522,9 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_any(DevS
         if (!mn) break;
         if (__popcll(mn) < TRACE_NODE_MIN && __ballot(cur == CUR_LEAF)) break;
         nv += (unsigned long long)__popcll(mn);
-        if (TRACE_COOP) fetch_nodes(sc, L.stage_addr, cur, lane);
         if (cur >= 0) {
           uint32_t nb, masks;
-          const uint32_t node_addr = (uint32_t)cur < sc.n_lds_units ? L.top_addr + 16u * (uint32_t)cur : L.stage_addr + 64u * lane;
+          const uint32_t node_addr = L.top_addr + 16u * (uint32_t)cur;
           const uint32_t hits = node_visit(sc, node_addr, cur, r, oct, 0.0f, tmax, nb, masks);
           const uint32_t imask = masks & 255u, lhits = hits & (masks >> 8);
           enter_group(gbase, gmask, st, nb, hits & imask, imask);
@@ -730,7 +700,8 @@ PT_DEV v3 env_sample(const DevScene& sc, float r1, float r2) {
 // Middle (P5–P8): surface reconstruction, emission with MIS, next-event estimation, BSDF sampling,
 // Russian roulette.
 // Back end (P9): continuation and shadow rays are compacted into the output queues with the same
-// ballot/prefix scheme and ONE atomic per block and queue.
+// ballot/prefix scheme and ONE atomic per block and queue (same-word atomics cost ≈5.6 ns each, serialised: one per wave
+// made the kernel 6× slower); the stores happen inside the next window's front end, when the atomics have returned.
 __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, DevFrame fr, DevQueues q, int qi, uint32_t b) {
   __shared__ uint32_t s_cnt[4][SHADE_WAVES];     // per-wave counts: class0, class1, shadow, next
   __shared__ uint32_t s_base[2];                 // block's base slots in the shadow / next queues
@@ -758,6 +729,28 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene
   const RayQ rin = q.ray[qi], rout = q.ray[qi ^ 1];
   const uint32_t n = q.cnt[CNT_RAYS];
   const uint32_t n_windows = (n + SHADE_BLOCK - 1u) / SHADE_BLOCK;
+#ifdef PT_STAMP_SHADE   // wave-cycles per phase of a window (tools/stamp_shade.py)
+  unsigned long long t_front = 0, t_load = 0, t_math = 0, t_back = 0, t_store = 0, t_mark = __builtin_amdgcn_s_memtime();
+#define SSTAMP(acc) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - t_mark; t_mark = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SSTAMP_LOADS(acc) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SSTAMP(acc); } while (0)
+#else
+#define SSTAMP(acc) do { } while (0)
+#define SSTAMP_LOADS(acc) do { } while (0)
+#endif
+  // The back end of a window is finished inside the front end of the next one: the block's atomics on the two output counters
+  // are issued and left in flight, their result (the block's base slots) is published at the next window's first barrier, where the
+  // class words of that window — requested right behind the atomics — are awaited anyway, and the rays are stored after it.
+  bool alive = false, has_shadow = false;            // outputs of the window before
+  float4 oA, oB, oC;                                 // continuation ray
+  float4 sA, sB, sC;                                 // shadow ray
+  oA = oB = oC = sA = sB = sC = make_float4(0, 0, 0, 0);
+  uint32_t out_s = 0, out_a = 0;                     // their slots behind the block's bases
+  uint32_t base_s = 0, base_a = 0;                   // thread 0: the bases (atomic results, in flight)
+  auto publish_bases = [&]() { if (threadIdx.x == 0) { s_base[0] = base_s; s_base[1] = base_a; } };
+  auto store_outputs = [&]() {
+    if (has_shadow) { const uint32_t s = s_base[0] + out_s; q.shadow.A[s] = sA; q.shadow.B[s] = sB; q.shadow.C[s] = sC; }
+    if (alive) { const uint32_t s = s_base[1] + out_a; rout.A[s] = oA; rout.B[s] = oB; rout.C[s] = oC; }
+  };
   for (uint32_t win = blockIdx.x; win < n_windows; win += gridDim.x) {
     const uint32_t wbase = win * SHADE_BLOCK;
     // ---- front end: class sort of the window ----
@@ -773,6 +766,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene
     const uint64_t m0 = __ballot(cls == 0), m1 = __ballot(cls >= 1);   // misses queue up behind the GGX group
     if (lane == 0) { s_cnt[0][wave] = (uint32_t)__popcll(m0); s_cnt[1][wave] = (uint32_t)__popcll(m1); }
     s_idx[threadIdx.x] = 0xffffu;
+    publish_bases();
     __syncthreads();
     uint32_t off0 = 0, off1 = 0, tot0 = 0;
 #pragma unroll
@@ -790,15 +784,14 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene
       if (p >= SHADE_BLOCK) p = tot0 + (p - SHADE_BLOCK);
       s_idx[p] = (uint16_t)threadIdx.x;
     }
+    store_outputs();                                 // of the window before (nothing on the first)
     __syncthreads();
     const uint32_t item = s_idx[threadIdx.x];
     const bool valid = item != 0xffffu;
     const uint32_t slot = wbase + (valid ? item : 0u);
+    SSTAMP(t_front);
 
-    bool alive = false, has_shadow = false;
-    float4 oA, oB, oC;                               // continuation ray
-    float4 sA, sB, sC;                               // shadow ray
-    oA = oB = oC = sA = sB = sC = make_float4(0, 0, 0, 0);
+    alive = false; has_shadow = false;
     if (valid) {
       const float4 A = rin.A[slot], Bq = rin.B[slot], Cq = rin.C[slot], H = q.hit[slot];
       const v3 d = V3(A.w, Bq.x, Bq.y);
@@ -818,6 +811,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene
       // ---- P5 surface reconstruction from the primitive's shading record (five 16-byte loads) ----
       const float4* rec = sc.shade + (size_t)prim * 5;
       const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4];
+      SSTAMP_LOADS(t_load);
       const v3 Pa = V3(r0.x, r0.y, r0.z), Pb = V3(r1.x, r1.y, r1.z), Pc = V3(r2.x, r2.y, r2.z);
       const v3 Na = V3(r2.w, r3.x, r3.y), Nb = V3(r3.z, r3.w, r4.x), Nc = V3(r4.y, r4.z, r4.w);
       const float hw = 1.0f - hu - hv;
@@ -947,6 +941,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene
       }
       }   // hit
     }
+    SSTAMP(t_math);
     // ---- back end: compaction, ballot + mbcnt prefix per wave, LDS prefix per block, one atomic per queue ----
     const uint64_t ms = __ballot(has_shadow), ma = __ballot(alive);
     if (lane == 0) { s_cnt[2][wave] = (uint32_t)__popcll(ms); s_cnt[3][wave] = (uint32_t)__popcll(ma); }
@@ -958,15 +953,21 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene
       if (w < wave) { offs += a; offa += b; }
       tots += a; tota += b;
     }
+    out_s = offs + mbcnt64(ms); out_a = offa + mbcnt64(ma);
     if (threadIdx.x == 0) {
-      s_base[0] = tots ? atomicAdd(&q.cnt[CNT_SHADOW], tots) : 0u;
-      s_base[1] = tota ? atomicAdd(&q.cnt[CNT_NEXT], tota) : 0u;
+      base_s = tots ? atomicAdd(&q.cnt[CNT_SHADOW], tots) : 0u;
+      base_a = tota ? atomicAdd(&q.cnt[CNT_NEXT], tota) : 0u;
     }
-    __syncthreads();
-    if (has_shadow) { const uint32_t s = s_base[0] + offs + mbcnt64(ms); q.shadow.A[s] = sA; q.shadow.B[s] = sB; q.shadow.C[s] = sC; }
-    if (alive) { const uint32_t s = s_base[1] + offa + mbcnt64(ma); rout.A[s] = oA; rout.B[s] = oB; rout.C[s] = oC; }
-    __syncthreads();   // s_cnt / s_idx are rewritten by the next window
+    SSTAMP(t_back);
   }
+  publish_bases();
+  __syncthreads();
+  store_outputs();
+  SSTAMP(t_store);
+#ifdef PT_STAMP_SHADE
+  if (lane == 0) { atomicAdd(&q.stats[ST_DIAG_NODE_ITERS], t_front); atomicAdd(&q.stats[ST_DIAG_TRI_ITERS], t_load); atomicAdd(&q.stats[ST_DIAG_LEAF_VISITS], t_math);
+                   atomicAdd(&q.stats[ST_DIAG_ROUNDS], t_back); atomicAdd(&q.stats[ST_DIAG_REFILLED], t_store); }
+#endif
 }
 
 // =================================================================================================
@@ -1090,7 +1091,7 @@ __global__ __launch_bounds__(256) void k_tonemap(const float4* radiance, uint32_
 // =================================================================================================
 // launchers
 static size_t trace_lds_bytes(const LaunchCfg& cfg, const DevScene& sc, bool closest) {
-  return (size_t)sc.n_lds_units * 16 + (TRACE_COOP ? (size_t)TRACE_WAVES * 4096 : 0) + (size_t)TRACE_WAVES * cfg.stack_lds * 64 * 8 + (closest ? ORDER_TABLE_BYTES : 0);
+  return (size_t)sc.n_lds_units * 16 + (size_t)TRACE_WAVES * cfg.stack_lds * 64 * 8 + (closest ? ORDER_TABLE_BYTES : 0);
 }
 
 int pt_trace_block_threads() { return TRACE_BLOCK; }

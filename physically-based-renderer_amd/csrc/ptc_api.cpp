@@ -248,8 +248,7 @@ struct ScopedSpan {   // records a start/stop event pair around launches on one 
 int configure_launch(ptc_ctx* c) {
   // Traversal stack: at most one group of pending children per tree level, so a ray needs at most depth+1 entries.
   // `stack_lds` of them live in LDS (8 B each, 512 B per level and wave), the rest in a global overflow slab.
-  // LDS per block = staged top of the tree (4.6 KB) + waves·stack_lds·512 B + the 2-KiB slot-order table
-  // (+ waves·4 KiB node stage in a -DTRACE_COOP=1 build).
+  // LDS per block = staged top of the tree (4.6 KB) + waves·stack_lds·512 B + the 2-KiB slot-order table.
   const int need = (int)c->built.max_depth + 2;
   int l = 6;    // stack entries per lane kept in LDS: 18.6 KB per block, 8 blocks (32 waves, the register limit) share a CU
   if (const char* e = std::getenv("PTC_STACK_LDS")) { int v = std::atoi(e); if (v >= 1 && v <= 64) l = v; }
