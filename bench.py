@@ -136,17 +136,20 @@ def main():
     if world > 1:
         reduce_impl = "torch.distributed.reduce"
         if args.reduce == "cabi" and args.backend == "nccl" and not args.share_device:     # RCCL needs one GPU per rank
-            # rank 0 makes the RCCL unique id (C-ABI), torch.distributed ships it, every rank joins the communicator
+            # Every rank first proves, locally, that the library can load librccl (ptc_comm_unique_id is not a collective), and the
+            # ranks agree on that BEFORE anyone enters the collective ncclCommInitRank — a rank that cannot join must not leave the
+            # others waiting in it.  Then rank 0's id is shipped over torch.distributed and every rank joins the communicator.
             ok, uid = 1, None
-            if rank == 0:
-                try:
-                    uid = pbr_amd.comm_unique_id()
-                except pbr_amd.PtcError as e:
-                    print(f"bench: ptc_comm_unique_id failed ({e}); falling back to torch.distributed.reduce", file=sys.stderr)
-                    ok = 0
-            box = [uid if ok else None]
-            dist.broadcast_object_list(box, src=0)
-            if box[0] is not None:
+            try:
+                uid = pbr_amd.comm_unique_id()
+            except pbr_amd.PtcError as e:
+                print(f"bench: rank {rank}: ptc_comm_unique_id failed ({e}); falling back to torch.distributed.reduce", file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                box = [uid if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
                 try:
                     pt.comm_init(box[0], rank, world)
                     joined = 1
@@ -162,8 +165,21 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def reduce_to_root():
+        if world > 1 and reduce_impl.startswith("ncclReduce"):
+            pt.comm_reduce_radiance(0)           # queued on the context's stream behind the resolve
+            pt.sync()
+        else:
+            pt.sync()
+            if world > 1:
+                fb = pdist.radiance_tensor(pt, args.width, args.height)
+                pdist.reduce_framebuffer(fb, 0)
+
     for _ in range(W):
         pt.frame_add_samples(S)
+    if world > 1 and W > 0:                      # the warm-up includes one resolve + reduce: the first collective sets up the links
+        pt.frame_resolve()
+        reduce_to_root()
     pt.sync()
     s0 = pt.stats()
     barrier()
@@ -172,14 +188,7 @@ def main():
     for _ in range(K):
         pt.frame_add_samples(S)
     pt.frame_resolve()
-    if world > 1 and reduce_impl.startswith("ncclReduce"):
-        pt.comm_reduce_radiance(0)           # queued on the context's stream behind the resolve
-        pt.sync()
-    else:
-        pt.sync()
-        if world > 1:
-            fb = pdist.radiance_tensor(pt, args.width, args.height)
-            pdist.reduce_framebuffer(fb, 0)
+    reduce_to_root()
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
@@ -286,7 +295,8 @@ def main():
             "whole_frame": whole,
             "whole_path_algorithmic_GBs": tot["algorithmic_bytes"] / dt / 1e9,
             "scene_commit_seconds": s1.get("seconds_commit"),    # flatten + SAH BVH + upload, once per scene, outside the timed region
-            "seconds": {"wall": dt, "trace_closest": d["seconds_trace_closest"], "trace_any": d["seconds_trace_any"], "shade": d["seconds_shade"]},
+            "seconds": {"wall": dt, "trace_closest": d["seconds_trace_closest"], "trace_any": d["seconds_trace_any"], "shade": d["seconds_shade"],
+                        "batches": d.get("seconds_render", 0.0)},
             "per_path": {"segments": tot["segments"] / paths, "shadow_rays": tot["shadow_rays"] / paths,
                          "node_visits": (tot["node_visits_closest"] + tot["node_visits_any"]) / paths,
                          "algorithmic_bytes": tot["algorithmic_bytes"] / paths},

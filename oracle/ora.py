@@ -54,6 +54,7 @@ def lib():
         L.ora_add_texture_rgba8.argtypes = [vp, u8p, C.c_int, C.c_int]
         L.ora_set_env_latlong_rgb32f.argtypes = [vp, fp, C.c_int, C.c_int]
         L.ora_set_texture_filter.argtypes = [vp, C.c_int]
+        L.ora_set_bvh_builder.argtypes = [vp, C.c_int]
         L.ora_atan2f.argtypes = [C.c_float, C.c_float]
         L.ora_atan2f.restype = C.c_float
         L.ora_add_instance.argtypes = [vp, C.c_int, fp, fp, fp]
@@ -125,6 +126,7 @@ class Oracle:
             t = np.ascontiguousarray(t, np.uint8)
             self._ck(L.ora_add_texture_rgba8(h, t.ctypes.data_as(C.POINTER(C.c_uint8)), t.shape[1], t.shape[0]))
         self._ck(L.ora_set_texture_filter(h, 1 if getattr(desc, "texture_filter", "nearest") == "linear" else 0))
+        self._ck(L.ora_set_bvh_builder(h, 1 if getattr(desc, "bvh_builder", None) == "lbvh" else 0))
         env = getattr(desc, "env", None)
         if env is not None:
             e = np.ascontiguousarray(env, np.float32)

@@ -224,6 +224,7 @@ struct ora_ctx {
   int32_t* tri_mat;
   /* BVH (triangles in sorted order) */
   int tex_linear;                      /* 0 = NEAREST (the reference's sampler), 1 = bilinear */
+  int bvh_builder;                     /* 0 = binned SAH (default), 1 = Morton-order LBVH; see morton_split */
   uint32_t* order;                     /* sorted position → original prim id */
   v3 *tv0, *te1, *te2;                 /* per sorted position */
   node_t* nodes; uint32_t n_nodes; uint32_t max_depth;   /* binary radix tree (intermediate) */
@@ -263,7 +264,7 @@ static void free_description(ora_ctx* c) {
 }
 void ora_destroy(ora_ctx* c) { if (!c) return; free_committed(c); free_description(c); free(c); }
 
-int ora_scene_begin(ora_ctx* c) { free_committed(c); free_description(c); c->have_cam = 0; c->tex_linear = 0; return 0; }
+int ora_scene_begin(ora_ctx* c) { free_committed(c); free_description(c); c->have_cam = 0; c->tex_linear = 0; c->bvh_builder = 0; return 0; }
 
 int ora_add_material(ora_ctx* c, const float base[4], float metallic, float roughness,
                      const float emissive[3], int tc, int tn, int tmr) {
@@ -321,6 +322,11 @@ int ora_set_camera(ora_ctx* c, const float pos[3], const float target[3], float 
 int ora_set_texture_filter(ora_ctx* c, int mode) {
   if (mode != 0 && mode != 1) return fail(c, "set_texture_filter: mode must be 0 (nearest) or 1 (linear)");
   c->tex_linear = mode;
+  return 0;
+}
+int ora_set_bvh_builder(ora_ctx* c, int mode) {
+  if (mode != 0 && mode != 1) return fail(c, "set_bvh_builder: mode must be 0 (SAH) or 1 (LBVH)");
+  c->bvh_builder = mode;
   return 0;
 }
 
@@ -442,7 +448,7 @@ void ora_make_camera(const float pos[3], const float target[3], float fov, float
 /* <= ORA_LEAF_MAX triangles), the octant slot assignment and the 8-bit quantisation.             */
 static inline int32_t leaf_code(uint32_t first, uint32_t count) { return (int32_t)~(first | ((count - 1u) << 28)); }
 
-typedef struct { ora_ctx* c; const float* tlo; const float* thi; uint32_t next; uint32_t depth_max; } build_t;
+typedef struct { ora_ctx* c; const float* tlo; const float* thi; uint32_t next; uint32_t depth_max; const uint64_t* codes; } build_t;
 
 static void range_box(build_t* b, uint32_t lo, uint32_t hi, float blo[3], float bhi[3]) {
   for (int k = 0; k < 3; ++k) { blo[k] = INFINITY; bhi[k] = -INFINITY; }
@@ -512,12 +518,63 @@ static uint32_t sah_split(build_t* b, uint32_t lo, uint32_t hi) {
     return lo + nl - 1;
   }
 }
+/* LBVH (BASELINE north_star: "flattened LBVH"; Lauterbach et al. 2009, Karras 2012): the binary tree is the radix tree of the
+ * triangles' Morton codes.  Code of a triangle: its box centre, per axis q = (uint32)((ctr - cl) * (2097152 / (ch - cl))) clamped to
+ * 2^21 - 1 (cl, ch = bounds of all centres; 0 on a degenerate axis), bits interleaved x -> bit 0, y -> bit 1, z -> bit 2 (63 bits).
+ * The initial order is ascending (code, primitive id).  A range splits where the highest bit in which its first and last code
+ * differ flips from 0 to 1; a range of equal codes is cut at its middle index. */
+static inline uint64_t expand21(uint32_t v) {
+  uint64_t x = v & 0x1fffffu;
+  x = (x | x << 32) & 0x1f00000000ffffull;
+  x = (x | x << 16) & 0x1f0000ff0000ffull;
+  x = (x | x << 8) & 0x100f00f00f00f00full;
+  x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+  x = (x | x << 2) & 0x1249249249249249ull;
+  return x;
+}
+typedef struct { uint64_t code; uint32_t prim; } mkey_t;
+static int mkey_cmp(const void* a, const void* b) {
+  const mkey_t* x = (const mkey_t*)a; const mkey_t* y = (const mkey_t*)b;
+  if (x->code != y->code) return x->code < y->code ? -1 : 1;
+  return x->prim < y->prim ? -1 : (x->prim > y->prim ? 1 : 0);
+}
+/* fills order[] (sorted) and returns the codes in sorted order (caller frees) */
+static uint64_t* morton_order(ora_ctx* c, const float* tlo, const float* thi, uint32_t n) {
+  float cl[3] = {INFINITY, INFINITY, INFINITY}, ch[3] = {-INFINITY, -INFINITY, -INFINITY}, scale[3];
+  for (uint32_t p = 0; p < n; ++p)
+    for (int k = 0; k < 3; ++k) { float ctr = 0.5f * (tlo[p * 3 + k] + thi[p * 3 + k]); cl[k] = fmin2(cl[k], ctr); ch[k] = fmax2(ch[k], ctr); }
+  for (int k = 0; k < 3; ++k) scale[k] = ch[k] > cl[k] ? 2097152.0f / (ch[k] - cl[k]) : 0.0f;
+  mkey_t* keys = (mkey_t*)malloc(sizeof(mkey_t) * n);
+  for (uint32_t p = 0; p < n; ++p) {
+    uint32_t q[3];
+    for (int k = 0; k < 3; ++k) {
+      float ctr = 0.5f * (tlo[p * 3 + k] + thi[p * 3 + k]);
+      float f = (ctr - cl[k]) * scale[k];
+      q[k] = f >= 2097151.0f ? 2097151u : (uint32_t)f;
+    }
+    keys[p].code = expand21(q[0]) | expand21(q[1]) << 1 | expand21(q[2]) << 2;
+    keys[p].prim = p;
+  }
+  qsort(keys, n, sizeof(mkey_t), mkey_cmp);
+  uint64_t* codes = (uint64_t*)malloc(8u * n);
+  for (uint32_t i = 0; i < n; ++i) { c->order[i] = keys[i].prim; codes[i] = keys[i].code; }
+  free(keys);
+  return codes;
+}
+static uint32_t morton_split(const build_t* b, uint32_t lo, uint32_t hi) {
+  const uint64_t c0 = b->codes[lo], c1 = b->codes[hi];
+  if (c0 == c1) return lo + (hi - lo) / 2;
+  const uint64_t bit = 1ull << (63 - __builtin_clzll(c0 ^ c1));
+  uint32_t a = lo, z = hi;                 /* codes[a] has the bit clear, codes[z] has it set */
+  while (z - a > 1) { uint32_t m = a + (z - a) / 2; if (b->codes[m] & bit) z = m; else a = m; }
+  return a;
+}
 /* Emit the interior node covering [lo,hi] (count >= 2: the binary tree goes down to single triangles; which
  * subtrees become leaves of the wide tree is decided by the collapse below); returns its index. */
 static int32_t build_node(build_t* b, uint32_t lo, uint32_t hi, uint32_t depth) {
   uint32_t me = b->next++;
   if (depth > b->depth_max) b->depth_max = depth;
-  uint32_t split = sah_split(b, lo, hi);
+  uint32_t split = b->codes ? morton_split(b, lo, hi) : sah_split(b, lo, hi);
   node_t tmp; memset(&tmp, 0, sizeof tmp);
   range_box(b, lo, split, tmp.lo0, tmp.hi0);
   range_box(b, split + 1, hi, tmp.lo1, tmp.hi1);
@@ -752,8 +809,9 @@ int ora_scene_commit(ora_ctx* c) {
   for (int k = 0; k < 3; ++k) { float st = (c->scene_hi[k] - c->scene_lo[k]) / 65535.0f; c->grid_step[k] = st > 0.0f ? st : 1.0f; }
   c->order = (uint32_t*)malloc(4u * n);
   for (uint32_t i = 0; i < n; ++i) c->order[i] = i;      /* initial order: original primitive order */
+  uint64_t* codes = c->bvh_builder == 1 ? morton_order(c, tlo, thi, n) : NULL;
   c->nodes = (node_t*)calloc(n > 1 ? n : 1, sizeof(node_t));
-  build_t b = {c, tlo, thi, 0, 0};
+  build_t b = {c, tlo, thi, 0, 0, codes};
   if (n == 1) {                 /* a single triangle: both children are that leaf */
     node_t r; memset(&r, 0, sizeof r);
     range_box(&b, 0, 0, r.lo0, r.hi0); range_box(&b, 0, 0, r.lo1, r.hi1);
@@ -780,7 +838,7 @@ int ora_scene_commit(ora_ctx* c) {
     uint32_t next = 0, maxd = 0; widen(c, dp, 0, 0, &next, &maxd); c->n_wnodes = next; c->wdepth = maxd;
     free(dp);
   }
-  free(tlo); free(thi);
+  free(tlo); free(thi); free(codes);
   /* P7: emitter table in original primitive order, power pmf/cdf */
   c->prim_light = (int32_t*)malloc(4u * n);
   uint32_t nl = 0;

@@ -41,6 +41,7 @@ int ora_add_instance_matrix(ora_ctx*, int mesh, const float model16[16]);
 int ora_set_camera(ora_ctx*, const float pos[3], const float target[3], float fov_y, float aspect);
 int ora_set_env_latlong_rgb32f(ora_ctx*, const float* rgb, int w, int h);   /* NULL clears */
 int ora_set_texture_filter(ora_ctx*, int mode);                              /* 0 nearest (default, the reference's), 1 bilinear */
+int ora_set_bvh_builder(ora_ctx*, int mode);                                 /* 0 binned SAH (default), 1 Morton-order LBVH; reset by scene_begin */
 int ora_scene_commit(ora_ctx*);
 
 /* Renders into out_rgba (w*h*4 floats, y-down).  Pixels not owned by (tile_rank, tile_count)

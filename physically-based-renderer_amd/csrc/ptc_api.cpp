@@ -92,6 +92,8 @@ struct ptc_ctx {
   float cam_pos[3]{}, cam_target[3]{}, cam_fov = 0, cam_aspect = 1;
   bool have_cam = false;
   int tex_linear = 0;                    // PTC_FILTER_*: texture filter of the scene being described
+  int bvh_default = PTC_BVH_SAH;         // PTC_BVH_*: builder a new scene description starts with (PTC_BVH=lbvh in the environment changes it)
+  int bvh_builder = PTC_BVH_SAH;         // builder of the scene being described
   // committed scene
   bool committed = false;
   HostBuilt built;
@@ -409,6 +411,7 @@ ptc_ctx* ptc_create(int device_id) {
     ptc_ctx* c = new ptc_ctx();
     c->device = PTC_DEVICE_NONE;
     if (const char* s = std::getenv("PTC_NODELETS")) c->toplet_budget = (uint32_t)std::strtoul(s, nullptr, 10);
+    if (const char* s = std::getenv("PTC_BVH")) { if (std::strcmp(s, "lbvh") == 0) c->bvh_default = c->bvh_builder = PTC_BVH_LBVH; }
     return c;
   }
   int n = 0;
@@ -427,6 +430,7 @@ ptc_ctx* ptc_create(int device_id) {
   if (const char* s = std::getenv("PTC_NODELETS")) c->toplet_budget = (uint32_t)std::strtoul(s, nullptr, 10);
   if (const char* s = std::getenv("PTC_BATCH_PATHS")) { size_t v = std::strtoull(s, nullptr, 10); if (v >= 1024) c->max_batch_paths = v; }
   if (const char* s = std::getenv("PTC_TIMING")) c->timing = std::atoi(s) != 0;
+  if (const char* s = std::getenv("PTC_BVH")) { if (std::strcmp(s, "lbvh") == 0) c->bvh_default = c->bvh_builder = PTC_BVH_LBVH; }
   if (const char* s = std::getenv("PTC_LANES")) { int v = std::atoi(s); if (v >= 1 && v <= 8) c->n_lanes = v; }
   c->lanes.resize((size_t)c->n_lanes);
   bool ok = true;
@@ -468,6 +472,7 @@ int ptc_scene_begin(ptc_ctx* c) {
     { int rs = sync_all_lanes(c); if (rs) return rs; }
   }
   c->mats.clear(); c->meshes.clear(); c->insts.clear(); c->texs.clear(); c->env = HostEnv{}; c->tex_linear = 0;
+  c->bvh_builder = c->bvh_default;
   c->have_cam = false; c->committed = false; c->in_frame = false; c->pending = 0;
   free_all(c->scene_allocs);
   for (auto& ln : c->lanes) ln.stack_ovf = nullptr;
@@ -549,6 +554,13 @@ int ptc_set_texture_filter(ptc_ctx* c, int filter) {
   return PTC_OK;
 }
 
+int ptc_set_bvh_builder(ptc_ctx* c, int builder) {
+  if (!c) return PTC_E_ARG;
+  if (builder != PTC_BVH_SAH && builder != PTC_BVH_LBVH) return fail(c, PTC_E_ARG, "set_bvh_builder: unknown builder");
+  c->bvh_builder = builder;
+  return PTC_OK;
+}
+
 int ptc_set_env_latlong_rgb32f(ptc_ctx* c, const float* rgb, int w, int h) {
   if (!c) return PTC_E_ARG;
   if (!rgb) { c->env = HostEnv{}; return PTC_OK; }
@@ -565,7 +577,7 @@ int ptc_scene_commit(ptc_ctx* c) {
     { int rs = sync_all_lanes(c); if (rs) return rs; }
   }
   const auto t0 = std::chrono::steady_clock::now();
-  const std::string e = ptc_build_scene(c->mats, c->meshes, c->insts, c->texs, c->env, c->toplet_budget, c->built);
+  const std::string e = ptc_build_scene(c->mats, c->meshes, c->insts, c->texs, c->env, c->toplet_budget, c->bvh_builder, c->built);
   if (!e.empty()) return fail(c, PTC_E_STATE, e);
   ptc_make_camera(c->cam_pos, c->cam_target, c->cam_fov, c->cam_aspect, c->cam);
   c->in_frame = false; c->pending = 0;

@@ -116,7 +116,8 @@ struct HostBuilt {
 
 // returns empty string on success, else the error text
 std::string ptc_build_scene(const std::vector<HostMaterial>&, const std::vector<HostMesh>&, const std::vector<HostInstance>&,
-                            const std::vector<HostTexture>&, const HostEnv&, uint32_t toplet_budget, HostBuilt& out);
+                            const std::vector<HostTexture>&, const HostEnv&, uint32_t toplet_budget, int bvh_builder /* PTC_BVH_* */,
+                            HostBuilt& out);
 void ptc_trs_to_matrix(const float t[3], const float q_wxyz[4], const float s[3], float m16[16]);
 void ptc_make_camera(const float pos[3], const float target[3], float fov, float aspect, DevCamera& cam);
 // pixels owned by (rank,count) in tile-Morton order

@@ -91,11 +91,53 @@ inline float box_half_area(const Box& b) {
   return ex * ey + ey * ez + ez * ex;
 }
 
-void build_split_tree(const std::vector<Box>& tbox, std::vector<uint32_t>& ord, std::vector<SplitNode>& out) {
+// ---- LBVH option (BASELINE north_star's "flattened LBVH"): the binary tree is the radix tree of 63-bit Morton codes ------------
+// Per axis q = (uint32)((centre - cl) * (2^21 / (ch - cl))) clamped to 2^21 - 1 over the bounds cl..ch of all box centres (0 on a
+// degenerate axis); x in bit 0, y in bit 1, z in bit 2 of each triple.  Positions are ordered by (code, primitive id); a range splits
+// where the highest bit in which its end codes differ turns 1, a range of one code at its middle index.
+inline uint64_t spread_bits_3(uint32_t v) {
+  uint64_t r = 0;
+  for (int b = 0; b < 21; ++b) r |= (uint64_t)((v >> b) & 1u) << (3 * b);
+  return r;
+}
+std::vector<uint64_t> sort_by_morton_code(const std::vector<float>& ctr, std::vector<uint32_t>& ord) {
+  const uint32_t n = (uint32_t)ord.size();
+  float cl[3], ch[3], scale[3];
+  for (int k = 0; k < 3; ++k) { cl[k] = std::numeric_limits<float>::infinity(); ch[k] = -cl[k]; }
+  for (uint32_t p = 0; p < n; ++p)
+    for (int k = 0; k < 3; ++k) { const float c = ctr[(size_t)p * 3 + k]; cl[k] = cl[k] < c ? cl[k] : c; ch[k] = ch[k] > c ? ch[k] : c; }
+  for (int k = 0; k < 3; ++k) scale[k] = ch[k] > cl[k] ? 2097152.0f / (ch[k] - cl[k]) : 0.0f;
+  std::vector<std::pair<uint64_t, uint32_t>> keyed(n);
+  for (uint32_t p = 0; p < n; ++p) {
+    uint64_t code = 0;
+    for (int k = 0; k < 3; ++k) {
+      const float f = (ctr[(size_t)p * 3 + k] - cl[k]) * scale[k];
+      const uint32_t q = f >= 2097151.0f ? 2097151u : (uint32_t)f;
+      code |= spread_bits_3(q) << k;
+    }
+    keyed[p] = {code, p};
+  }
+  std::sort(keyed.begin(), keyed.end());
+  std::vector<uint64_t> codes(n);
+  for (uint32_t i = 0; i < n; ++i) { codes[i] = keyed[i].first; ord[i] = keyed[i].second; }
+  return codes;
+}
+inline uint32_t morton_last_left(const std::vector<uint64_t>& codes, uint32_t lo, uint32_t hi) {
+  const uint64_t diff = codes[lo] ^ codes[hi];
+  if (!diff) return lo + (hi - lo) / 2;
+  const uint64_t top = (uint64_t)1 << (63 - __builtin_clzll(diff));
+  // the bit is clear at lo and set at hi, and the codes are sorted: find the last position where it is clear
+  const auto first_set = std::partition_point(codes.begin() + lo, codes.begin() + hi + 1, [top](uint64_t c) { return (c & top) == 0; });
+  return (uint32_t)(first_set - codes.begin()) - 1u;
+}
+
+void build_split_tree(const std::vector<Box>& tbox, std::vector<uint32_t>& ord, std::vector<SplitNode>& out, bool lbvh) {
   const uint32_t n = (uint32_t)ord.size();
   std::vector<float> ctr((size_t)n * 3);
   for (uint32_t p = 0; p < n; ++p)
     for (int k = 0; k < 3; ++k) ctr[(size_t)p * 3 + k] = 0.5f * (tbox[p].lo[k] + tbox[p].hi[k]);
+  std::vector<uint64_t> codes;
+  if (lbvh) codes = sort_by_morton_code(ctr, ord);
   std::vector<uint32_t> right_part(n);
   out.clear();
   out.reserve(n);
@@ -108,7 +150,9 @@ void build_split_tree(const std::vector<Box>& tbox, std::vector<uint32_t>& ord, 
     const Work w = todo.back();
     todo.pop_back();
     uint32_t last_left;   // last position of the left part
-    {
+    if (lbvh) {
+      last_left = morton_last_left(codes, w.lo, w.hi);
+    } else {
       float cl[3], ch[3];
       for (int k = 0; k < 3; ++k) { cl[k] = std::numeric_limits<float>::infinity(); ch[k] = -cl[k]; }
       for (uint32_t i = w.lo; i <= w.hi; ++i) {
@@ -238,7 +282,7 @@ void ptc_owned_pixels(int w, int h, int tile_rank, int tile_count, std::vector<u
 
 std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::vector<HostMesh>& meshes,
                             const std::vector<HostInstance>& insts, const std::vector<HostTexture>& texs, const HostEnv& env,
-                            uint32_t toplet_budget, HostBuilt& B) {
+                            uint32_t toplet_budget, int bvh_builder, HostBuilt& B) {
   if (insts.empty()) return "scene_commit: no instances";
   uint64_t nv = 0, nt = 0;
   for (const auto& in : insts) { nv += meshes[(size_t)in.mesh].v.size(); nt += meshes[(size_t)in.mesh].idx.size() / 3; }
@@ -454,7 +498,7 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
     const Wide w = make_wide(kid, 2);
     order.push_back({-1, 0}); wide.push_back(w); child_base.push_back(1); block_order.push_back(0);
   } else {
-    build_split_tree(tbox, ord, radix);
+    build_split_tree(tbox, ord, radix, bvh_builder == 1);
     // boxes of all radix nodes, bottom-up (iterative post-order)
     radix_box.assign(radix.size(), empty_box());
     {

@@ -93,6 +93,8 @@ public:
   auto setCamera(std::array<float, 3> position, std::array<float, 3> target, float fov, float aspect) -> void {
     ck(ptc_set_camera(_ctx, position.data(), target.data(), fov, aspect));
   }
+  // PTC_BVH_SAH (default) or PTC_BVH_LBVH, for the scene being described
+  auto setBvhBuilder(int builder) -> void { ck(ptc_set_bvh_builder(_ctx, builder)); }
   auto commitScene() -> void { ck(ptc_scene_commit(_ctx)); }
 
   // replaces PbrRenderSystem::render: fills an fp32 RGBA radiance buffer (w*h*4, y-down)

@@ -30,7 +30,7 @@ ABI_VERSION = 2
 # every symbol include/ptc.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "ptc_create", "ptc_destroy", "ptc_last_error", "ptc_abi_version", "ptc_scene_begin", "ptc_add_material",
-    "ptc_add_texture_rgba8", "ptc_add_mesh", "ptc_add_instance", "ptc_add_instance_matrix", "ptc_set_camera", "ptc_set_env_latlong_rgb32f", "ptc_set_texture_filter", "ptc_scene_commit", "ptc_render",
+    "ptc_add_texture_rgba8", "ptc_add_mesh", "ptc_add_instance", "ptc_add_instance_matrix", "ptc_set_camera", "ptc_set_env_latlong_rgb32f", "ptc_set_texture_filter", "ptc_set_bvh_builder", "ptc_scene_commit", "ptc_render",
     "ptc_frame_begin", "ptc_frame_add_samples", "ptc_frame_resolve", "ptc_sync", "ptc_read_radiance_rgba32f",
     "ptc_radiance_device_ptr", "ptc_write_radiance_rgba32f", "ptc_tonemap_rgba8", "ptc_get_stats",
     "ptc_debug_trace_closest", "ptc_debug_trace_any", "ptc_debug_get_flat_scene", "ptc_debug_get_bvh", "ptc_debug_get_counters",
@@ -90,6 +90,7 @@ def load_library():
     L.ptc_set_camera.argtypes = [vp, fp, fp, C.c_float, C.c_float]
     L.ptc_set_env_latlong_rgb32f.argtypes = [vp, fp, C.c_int, C.c_int]
     L.ptc_set_texture_filter.argtypes = [vp, C.c_int]
+    L.ptc_set_bvh_builder.argtypes = [vp, C.c_int]
     L.ptc_scene_commit.argtypes = [vp]
     L.ptc_render.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int]
     L.ptc_frame_begin.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -182,6 +183,8 @@ class PathTracer:
             assert t.ndim == 3 and t.shape[2] == 4, "textures are (h, w, 4) uint8"
             self._ck(L.ptc_add_texture_rgba8(h, t.ctypes.data_as(C.POINTER(C.c_uint8)), t.shape[1], t.shape[0]))
         self._ck(L.ptc_set_texture_filter(h, 1 if getattr(desc, "texture_filter", "nearest") == "linear" else 0))
+        if getattr(desc, "bvh_builder", None) is not None:      # None: the context's default (SAH, or what PTC_BVH says)
+            self._ck(L.ptc_set_bvh_builder(h, {"sah": 0, "lbvh": 1}[desc.bvh_builder]))
         env = getattr(desc, "env", None)
         if env is not None:
             e = np.ascontiguousarray(env, np.float32)

@@ -204,6 +204,7 @@ class SceneDesc:
     textures: List[np.ndarray] = dataclasses.field(default_factory=list)  # RGBA8 images, (h, w, 4) uint8; Material.tex_* index this list
     env: Optional[np.ndarray] = None  # lat-long RGB32F environment map, (h, w, 3) float32, row 0 = +y
     texture_filter: str = "nearest"  # "nearest" (the reference's default-constructed sampler) or "linear" (bilinear, REPEAT)
+    bvh_builder: "str | None" = None  # "sah" (binned surface-area splits), "lbvh" (Morton-code radix tree) or None = the context's default
 
     @property
     def n_triangles(self) -> int:

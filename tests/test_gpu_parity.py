@@ -79,6 +79,26 @@ def test_path_tracer_image_and_counters(gpu, ora, name, kw, w, h, spp, seed, mb)
     assert sg["seconds_trace_closest"] > 0 and sg["launches_trace_closest"] == mb + 1
 
 
+@pytest.mark.parametrize("name,kw,w,h,spp,seed,mb", [("sphere10k", {}, 96, 96, 4, 2, 6), ("atrium", {}, 160, 90, 2, 3, 8)])
+def test_lbvh_builder(gpu, ora, name, kw, w, h, spp, seed, mb):
+    """PTC_BVH_LBVH (BASELINE north_star's literal "flattened LBVH"): image and all counters bit-exact against the oracle's LBVH;
+    the image is also the SAH tree's image, bit for bit (closest hit and occlusion do not depend on the tree), with more node visits."""
+    d = gpu.scenes.by_name(name, **kw)
+    d.bvh_builder = "lbvh"
+    pt, o = _pair(gpu, ora, d)
+    g = pt.render(w, h, spp, seed=seed, max_bounces=mb)
+    c = o.render(w, h, spp, seed=seed, max_bounces=mb)
+    assert _bits_equal(g, c)
+    sg, so = pt.stats(), o.stats()
+    for k in COUNTERS:
+        assert sg[k] == so[k], k
+    d.bvh_builder = "sah"
+    g2 = pt.load_scene(d).render(w, h, spp, seed=seed, max_bounces=mb)
+    s2 = pt.stats()
+    assert _bits_equal(g, g2)
+    assert s2["node_visits_closest"] < sg["node_visits_closest"] and s2["segments"] == sg["segments"]
+
+
 @pytest.mark.parametrize("name,kw,w,h", [("two_tris_sphere", {}, 64, 64), ("atrium", {"scale": 0.05}, 160, 90), ("sphere10k", {}, 101, 67),
                                          ("textured_objects", {}, 96, 96), ("textured_atrium", {"scale": 0.05, "tex_size": 128, "env_size": (64, 32)}, 160, 90)])
 def test_raster_compat(gpu, ora, name, kw, w, h):

@@ -84,9 +84,11 @@ def _canon(decoded):
     return a[np.lexsort(a.T[::-1])]
 
 
+@pytest.mark.parametrize("builder", ["sah", "lbvh"])
 @pytest.mark.parametrize("name,kw", [("cornell", {}), ("sphere10k", {}), ("two_tris_sphere", {}), ("atrium", {"scale": 0.05}), ("atrium", {})])
-def test_flatten_and_bvh_equal_oracle(ora, pbr, name, kw):
+def test_flatten_and_bvh_equal_oracle(ora, pbr, name, kw, builder):
     d = pbr.scenes.by_name(name, **kw)
+    d.bvh_builder = builder
     pt = pbr.PathTracer(pbr.DEVICE_NONE).load_scene(d)
     o = ora.Oracle().load_scene(d)
     v1, i1, m1 = pt.flat_scene()
@@ -222,3 +224,38 @@ def test_atrium_matches_baseline_config(pbr):
     assert abs(d.n_triangles - 250_000) <= 2_500                # 250 000 ± 1 %
     assert max(m.vertices.size for m in d.meshes) < 65_536      # every primitive u16-expressible (reference indices)
     assert len(d.materials) == 6
+
+
+def test_lbvh_is_the_morton_radix_tree(ora, pbr):
+    """PTC_BVH_LBVH (BASELINE north_star's "flattened LBVH"): same triangles, a different tree; the SAH tree needs fewer node visits
+    for the same hits; the builder is reset by scene_begin and PTC_BVH=lbvh makes it the default of a new context."""
+    import os, subprocess, sys
+    d = pbr.scenes.by_name("atrium", scale=0.05)
+    rng = np.random.default_rng(5)
+    n = 4000
+    org = np.tile(np.asarray(d.camera.position, np.float32), (n, 1))
+    dirs = rng.normal(size=(n, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    res = {}
+    for b in ("sah", "lbvh"):
+        d.bvh_builder = b
+        o = ora.Oracle().load_scene(d)
+        t, prim, uv = o.trace_closest(org, dirs)
+        res[b] = (t, prim, uv, o.stats())
+    assert np.array_equal(res["sah"][0], res["lbvh"][0]) and np.array_equal(res["sah"][1], res["lbvh"][1])   # closest hit does not depend on the tree
+    v_sah, v_lbvh = res["sah"][3]["node_visits_closest"], res["lbvh"][3]["node_visits_closest"]
+    assert v_sah < v_lbvh, (v_sah, v_lbvh)
+    # the product: explicit choice, reset by scene_begin, environment default
+    pt = pbr.PathTracer(pbr.DEVICE_NONE)
+    d.bvh_builder = "lbvh"
+    u_l = pt.load_scene(d).bvh()[0].view(np.uint32).copy()
+    d.bvh_builder = None
+    u_d = pt.load_scene(d).bvh()[0].view(np.uint32).copy()          # scene_begin went back to the default
+    d.bvh_builder = "sah"
+    u_s = pt.load_scene(d).bvh()[0].view(np.uint32).copy()
+    assert np.array_equal(u_d, u_s) and (u_l.shape != u_s.shape or not np.array_equal(u_l, u_s))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import pbr_amd; d = pbr_amd.scenes.by_name('atrium', scale=0.05); "
+            "pt = pbr_amd.PathTracer(pbr_amd.DEVICE_NONE).load_scene(d); print(pt.bvh()[0].tobytes().hex()[:64], pt.bvh()[0].shape[0])"
+            % os.path.dirname(os.path.dirname(pbr.__file__)))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PTC_BVH="lbvh"), capture_output=True, text=True, check=True).stdout.split()
+    assert out[0] == u_l.tobytes().hex()[:64] and int(out[1]) == u_l.shape[0]
