@@ -1,6 +1,6 @@
 // ptc_render — dependency-free C++17 offline renderer over the C-ABI (include/ptc.h).
 //   ptc_render (--scene cornell|sphere | --gltf file.glb [--cam-pos x y z --cam-target x y z --fov deg]) --width W --height H
-//              --spp N --seed S --bounces B [--raster | --raster16] [--env latlong.pfm | --sky] [--filter nearest|linear] [--device D] [--gpus N]
+//              --spp N --seed S --bounces B [--raster | --raster16] [--env latlong.pfm | --sky] [--filter nearest|linear] [--bvh sah|lbvh] [--device D] [--gpus N]
 //              --out image.pfm [--png image.png] [--ppm image.ppm] [--half image.f16]
 // --gpus N: devices D..D+N-1 share the frame by 32x32-pixel tiles, one RCCL reduce brings it to device D (ptc_group_*).
 // --raster16: the reference's Blinn-Phong pass lit from its G-buffer formats; --half writes the RGBA16F buffer (raw little-endian halves).
@@ -107,6 +107,7 @@ int main(int argc, char** argv) {
   std::string scene = "cornell", out = "out.pfm", ppm, png, gltf, envPath;
   bool sky = false;
   int filter = PTC_FILTER_NEAREST;          // what the reference's default-constructed samplers do
+  int bvh = -1;                             // -1: the context's default (SAH, or PTC_BVH in the environment)
   float camPos[3] = {0, 0, 0}, camTarget[3] = {0, 0, -1}, fovDeg = 60.0f;
   bool haveCam = false;
   int w = 256, h = 256, spp = 64, bounces = 8, device = 0, gpus = 0 /* 0: one plain context; N >= 1: a device group of N */, integrator = PTC_INTEGRATOR_PATH;
@@ -125,6 +126,7 @@ int main(int argc, char** argv) {
     else if (a == "--cam-pos") { for (float& v : camPos) v = (float)std::atof(next()); haveCam = true; }
     else if (a == "--cam-target") { for (float& v : camTarget) v = (float)std::atof(next()); }
     else if (a == "--fov") fovDeg = (float)std::atof(next());
+    else if (a == "--bvh") { const std::string f = next(); if (f == "lbvh") bvh = PTC_BVH_LBVH; else if (f == "sah") bvh = PTC_BVH_SAH; else { std::cerr << "--bvh sah|lbvh\n"; return 2; } }
     else if (a == "--out") out = next(); else if (a == "--png") png = next(); else if (a == "--ppm") ppm = next(); else if (a == "--raster") integrator = PTC_INTEGRATOR_RASTER_COMPAT;
     else { std::cerr << "unknown argument " << a << "\n"; return 2; }
   }
@@ -136,6 +138,7 @@ int main(int argc, char** argv) {
       rs.beginScene();
       if (pbr::gltf::upload(rs.handle(), fs) < 0) throw std::runtime_error(ptc_last_error(rs.handle()));
       if (ptc_set_texture_filter(rs.handle(), filter) < 0) throw std::runtime_error(ptc_last_error(rs.handle()));
+      if (bvh >= 0) rs.setBvhBuilder(bvh);
       if (!haveCam) {   // frame the bounding box from +z
         const float cx = 0.5f * (fs.bbox_lo[0] + fs.bbox_hi[0]), cy = 0.5f * (fs.bbox_lo[1] + fs.bbox_hi[1]), cz = 0.5f * (fs.bbox_lo[2] + fs.bbox_hi[2]);
         const float r = 0.5f * std::sqrt((fs.bbox_hi[0] - fs.bbox_lo[0]) * (fs.bbox_hi[0] - fs.bbox_lo[0]) + (fs.bbox_hi[1] - fs.bbox_lo[1]) * (fs.bbox_hi[1] - fs.bbox_lo[1]) +
