@@ -132,6 +132,7 @@ def main():
     K, W, S = args.steps, args.warmup, args.spp_per_step * (world if args.scaling == "weak" else 1)
     spp_total = (K + W) * S
     pt.frame_begin(args.width, args.height, spp_total, args.seed, args.max_bounces, pbr_amd.INTEGRATOR_PATH, tile_rank=rank, tile_count=world)
+    pt.frame_reserve()          # queues for full batches now: no allocation (and no drain of the device for one) inside the timed region
     reduce_impl = None
     if world > 1:
         reduce_impl = "torch.distributed.reduce"

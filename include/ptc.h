@@ -182,6 +182,11 @@ int ptc_frame_begin(ptc_ctx*, int w, int h, int spp_total, uint64_t seed, int ma
  * ptc_frame_resolve / ptc_sync / ptc_get_stats queue whatever is still held back.  Queues are sized by the batches
  * actually issued: adding one sample per call needs queues for one sample per pixel. */
 int ptc_frame_add_samples(ptc_ctx*, int n_samples);
+/* Optional: allocate the current frame's wavefront queues for FULL batches now (min(batch, spp_total) samples per owned pixel and
+ * lane).  Without it the queues grow with the batches issued — right for a viewer that adds a sample per displayed frame, but a
+ * growth step drains the device and reallocates; an offline render that will spend its budget calls this once after
+ * ptc_frame_begin so that nothing is allocated while it renders.  PTC_E_NOMEM if the queues do not fit. */
+int ptc_frame_reserve(ptc_ctx*);
 /* sum / (samples accumulated so far) → full-frame RGBA32F (zeros in pixels this context does not own): after k of
  * N samples the buffer holds the k-sample image, correctly exposed (progressive display). */
 int ptc_frame_resolve(ptc_ctx*);

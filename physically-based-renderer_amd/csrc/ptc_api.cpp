@@ -667,6 +667,14 @@ int ptc_frame_begin(ptc_ctx* c, int w, int h, int spp_total, uint64_t seed, int 
   return PTC_OK;
 }
 
+int ptc_frame_reserve(ptc_ctx* c) {
+  { int rd = need_device(c); if (rd) return rd; }
+  if (!c->in_frame) return fail(c, PTC_E_STATE, "frame_reserve: no frame");
+  if (c->fr.n_owned == 0) return PTC_OK;
+  const uint32_t k = is_raster(c->integrator) ? 1u : (c->per_batch < (uint32_t)c->spp_total ? c->per_batch : (uint32_t)c->spp_total);
+  return ensure_lane_queues(c, c->fr.n_owned * k);     // n_owned * per_batch fits 32 bits by construction (frame_begin)
+}
+
 int ptc_frame_add_samples(ptc_ctx* c, int n_samples) {
   { int rd = need_device(c); if (rd) return rd; }
   if (!c->in_frame) return fail(c, PTC_E_STATE, "frame_add_samples: no frame");

@@ -31,7 +31,7 @@ ABI_VERSION = 2
 ABI_SYMBOLS = [
     "ptc_create", "ptc_destroy", "ptc_last_error", "ptc_abi_version", "ptc_scene_begin", "ptc_add_material",
     "ptc_add_texture_rgba8", "ptc_add_mesh", "ptc_add_instance", "ptc_add_instance_matrix", "ptc_set_camera", "ptc_set_env_latlong_rgb32f", "ptc_set_texture_filter", "ptc_set_bvh_builder", "ptc_scene_commit", "ptc_render",
-    "ptc_frame_begin", "ptc_frame_add_samples", "ptc_frame_resolve", "ptc_sync", "ptc_read_radiance_rgba32f",
+    "ptc_frame_begin", "ptc_frame_add_samples", "ptc_frame_reserve", "ptc_frame_resolve", "ptc_sync", "ptc_read_radiance_rgba32f",
     "ptc_radiance_device_ptr", "ptc_write_radiance_rgba32f", "ptc_tonemap_rgba8", "ptc_get_stats",
     "ptc_debug_trace_closest", "ptc_debug_trace_any", "ptc_debug_get_flat_scene", "ptc_debug_get_bvh", "ptc_debug_get_counters",
     "ptc_debug_get_description", "ptc_debug_get_material", "ptc_debug_get_texture", "ptc_debug_get_internals",
@@ -96,6 +96,7 @@ def load_library():
     L.ptc_frame_begin.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int]
     L.ptc_frame_add_samples.argtypes = [vp, C.c_int]
     L.ptc_frame_resolve.argtypes = [vp]
+    L.ptc_frame_reserve.argtypes = [vp]
     L.ptc_sync.argtypes = [vp]
     L.ptc_read_radiance_rgba32f.argtypes = [vp, fp]
     L.ptc_radiance_device_ptr.argtypes = [vp]
@@ -221,6 +222,10 @@ class PathTracer:
 
     def frame_add_samples(self, n):
         self._ck(self._L.ptc_frame_add_samples(self._h, n))
+
+    def frame_reserve(self):
+        """Allocate the frame's queues for full batches now (offline renders; see ptc_frame_reserve)."""
+        self._ck(self._L.ptc_frame_reserve(self._h))
 
     def frame_resolve(self):
         self._ck(self._L.ptc_frame_resolve(self._h))

@@ -73,6 +73,27 @@ def test_queues_follow_the_batches_and_events_stay_bounded(gpu):
     assert pt.stats()["paths"] == 200 * w * h and pt.internals()["spans_waiting"] == 0
 
 
+def test_frame_reserve_allocates_full_batches_up_front(gpu):
+    """ptc_frame_reserve: an offline render sizes its queues for full batches before it starts, so that no growth step (which
+    drains the device and reallocates) falls into the render; the capacity then stays put and the image is the same."""
+    pt = gpu.PathTracer(0).load_scene(gpu.scenes.cornell_box())
+    w, h, spp = 320, 200, 24
+    ref = pt.render(w, h, spp, seed=6)
+    pt.frame_begin(w, h, spp, 6, 8, 0)
+    pt.frame_reserve()
+    it = pt.internals()
+    cap = it["queue_cap"]
+    assert cap == w * h * min(it["per_batch"], spp)
+    for _ in range(spp // 4):
+        pt.frame_add_samples(4)
+    pt.frame_resolve()
+    pt.sync()
+    assert pt.internals()["queue_cap"] == cap
+    assert np.array_equal(pt.read_radiance().view(np.uint32), ref.view(np.uint32))
+    with pytest.raises(gpu.PtcError):
+        gpu.PathTracer(0).frame_reserve()            # no frame
+
+
 def test_small_calls_merge_into_full_batches(gpu, ora):
     """Deferred batching: samples added in small calls are issued as full wavefront batches (launches as wide as one
     big call's), a partial batch goes out at resolve; bits do not depend on how the samples were handed over."""
