@@ -257,24 +257,41 @@ PT_DEV uint32_t next_triangle(uint32_t tbase, uint32_t& tmask) {
   return k;
 }
 
-// Wave-private reservoir of input slots: one atomic fetches TRACE_CHUNK consecutive rays, idle lanes are
-// refilled from it (ballot + mbcnt).  Returns, per lane, whether it received slot `ri`.
+// Wave-private reservoir of input slots: idle lanes are refilled from a chunk of consecutive rays (ballot + mbcnt).  The first
+// chunk of every wave is static (wave w of the grid owns rays [w, w+1) x chunk), the rest of the queue is handed out by one atomic
+// per chunk.  Atomics on one word are served one at a time (~88 per us): when every wave of the persistent grid (8192) opened with
+// one, an all but empty launch took 140 us; a queue the static round covers now costs none (54 us).  (Looking at the counter with
+// an agent-scope load before asking for a chunk, to spare the failing atomics at the end, made the kernels 53 % slower.)
+// Returns, per lane, whether it received slot `ri`.
 struct Reservoir {
-  uint32_t next, end, chunk; bool exhausted;
-  // chunk: TRACE_CHUNK rays per atomic when the queue is long (a single word takes ~88 atomics/us), down to
-  // one wave's worth when it is short, so that a small late-bounce queue still spreads over the whole chip
-  PT_DEV void init(uint32_t n) {
-    next = 0; end = 0; exhausted = false;
-    const uint32_t per_wave = n / (gridDim.x * TRACE_WAVES * 4u);
+  uint32_t next, end, chunk, dyn_base; bool exhausted;
+  // chunk: TRACE_CHUNK rays when the queue is long, down to one wave's worth when it is short, so that a small late-bounce
+  // queue still spreads over the whole chip
+  PT_DEV void init(uint32_t n, uint32_t wave_in_grid) {
+    const uint32_t waves = gridDim.x * TRACE_WAVES;
+    const uint32_t per_wave = n / (waves * 4u);
     chunk = per_wave >= TRACE_CHUNK ? TRACE_CHUNK : (per_wave < 64u ? 64u : (per_wave & ~63u));
+    dyn_base = waves * chunk;
+    const uint32_t first = wave_in_grid * chunk;                    // < 2^23
+    next = first < n ? first : 0u;
+    end = first < n ? (n - first > chunk ? first + chunk : n) : 0u;
+    exhausted = false;
+  }
+  // nothing for any wave of this block: its static chunks lie behind the queue's end and the static round covers the queue
+  static PT_DEV bool block_has_no_work(uint32_t n) {
+    Reservoir r; r.init(n, blockIdx.x * TRACE_WAVES);
+    return r.dyn_base >= n && r.next >= r.end;
   }
   PT_DEV bool refill(uint32_t* ctr, uint32_t n, bool idle, uint32_t lane, uint32_t& ri) {
     const uint64_t mi = __ballot(idle);
     if (!mi) return false;
     if (next >= end && !exhausted) {
-      const uint32_t base = wave_fetch(ctr, chunk, lane);
-      if (base >= n) exhausted = true;
-      else { next = base; end = (base + chunk < n) ? base + chunk : n; }
+      if (dyn_base >= n) exhausted = true;                          // the static round covered the queue: no atomic at all
+      else {
+        const uint64_t base = (uint64_t)dyn_base + wave_fetch(ctr, chunk, lane);
+        if (base >= n) exhausted = true;
+        else { next = (uint32_t)base; end = (base + chunk < n) ? (uint32_t)base + chunk : n; }
+      }
     }
     const uint32_t avail = end - next;
     if (avail == 0) return false;
@@ -326,13 +343,14 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_closest(
   __shared__ uint8_t s_pair[2][TRACE_WAVES][64];   // leaf phase: k-th owner with a second triangle <-> k-th free lane
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t n = q.cnt[CNT_RAYS];
+  if (Reservoir::block_has_no_work(n)) return;     // a short queue: most blocks of the persistent grid leave before staging anything
   const TraceLds L = trace_lds(lds_raw, sc, stack_lds);
   uint8_t* order_tab = L.order_tab;
   for (uint32_t i = threadIdx.x; i < sc.n_lds_units; i += TRACE_BLOCK) lds_raw[i] = sc.recs[i];
   build_order_table(order_tab);
   __syncthreads();
   const RayQ rq = q.ray[qi];
-  const uint32_t n = q.cnt[CNT_RAYS];
   unsigned long long nv = 0, nr = 0, nh = 0;   // wave totals, only updated at wave-uniform points: they live in SGPRs
   uint32_t nt = 0;                               // per lane (updated inside the divergent leaf phase)
   uint32_t d_node = 0, d_tri = 0, d_round = 0;
@@ -343,7 +361,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_closest(
 #else
 #define STAMP(acc) do { } while (0)
 #endif
-  Reservoir res; res.init(n);
+  Reservoir res; res.init(n, (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * TRACE_WAVES + wave)));
   WStack st;
   st.init(L.stack + (size_t)wave * (size_t)stack_lds * 64u + lane,
           sc.stack_ovf + ((size_t)(blockIdx.x * TRACE_WAVES + wave) * sc.ovf_depth) * 64u + lane, stack_lds);
@@ -484,13 +502,14 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_any(DevS
   __shared__ uint8_t s_pair[2][TRACE_WAVES][64];   // leaf phase: k-th owner with a second triangle <-> k-th free lane
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t n = q.cnt[CNT_SHADOW];
+  if (Reservoir::block_has_no_work(n)) return;
   const TraceLds L = trace_lds(lds_raw, sc, stack_lds);
   for (uint32_t i = threadIdx.x; i < sc.n_lds_units; i += TRACE_BLOCK) lds_raw[i] = sc.recs[i];
   __syncthreads();
-  const uint32_t n = q.cnt[CNT_SHADOW];
   unsigned long long nv = 0, nr = 0;
   uint32_t nt = 0;
-  Reservoir res; res.init(n);
+  Reservoir res; res.init(n, (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * TRACE_WAVES + wave)));
   WStack st;
   st.init(L.stack + (size_t)wave * (size_t)stack_lds * 64u + lane,
           sc.stack_ovf + ((size_t)(blockIdx.x * TRACE_WAVES + wave) * sc.ovf_depth) * 64u + lane, stack_lds);
