@@ -61,7 +61,10 @@ PT_DEV unsigned long long wave_sum(unsigned long long v) {
 // =================================================================================================
 // bookkeeping kernels
 __global__ void k_set_counts(uint32_t* cnt, uint32_t n_rays, uint32_t n_shadow) {
-  if (threadIdx.x < CNT_N) cnt[threadIdx.x] = (threadIdx.x == CNT_RAYS) ? n_rays : (threadIdx.x == CNT_SHADOW ? n_shadow : 0u);
+  if (threadIdx.x == 0) {
+    cnt[CNT_RAYS] = n_rays; cnt[CNT_NEXT] = 0; cnt[CNT_SHADOW] = n_shadow;
+    cnt[CNT_WORK_TRACE] = 0; cnt[CNT_WORK_SHADE] = 0; cnt[CNT_WORK_SHADOW] = 0;
+  }
 }
 __global__ void k_advance(uint32_t* cnt) {
   if (threadIdx.x == 0) {
@@ -719,8 +722,8 @@ PT_DEV v3 env_sample(const DevScene& sc, float r1, float r2) {
 // Middle (P5–P8): surface reconstruction, emission with MIS, next-event estimation, BSDF sampling,
 // Russian roulette.
 // Back end (P9): continuation and shadow rays are compacted into the output queues with the same
-// ballot/prefix scheme and ONE atomic per block and queue (same-word atomics cost ≈5.6 ns each, serialised: one per wave
-// made the kernel 6× slower); the stores happen inside the next window's front end, when the atomics have returned.
+// ballot/prefix scheme and ONE 64-bit atomic per block for both queues (atomics on one line are served one at a time, ≈11 ns
+// each: one per wave made the kernel 6× slower); the stores happen inside the next window's front end, when the atomic has returned.
 __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, DevFrame fr, DevQueues q, int qi, uint32_t b) {
   __shared__ uint32_t s_cnt[4][SHADE_WAVES];     // per-wave counts: class0, class1, shadow, next
   __shared__ uint32_t s_base[2];                 // block's base slots in the shadow / next queues
@@ -974,8 +977,11 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene
     }
     out_s = offs + mbcnt64(ms); out_a = offa + mbcnt64(ma);
     if (threadIdx.x == 0) {
-      base_s = tots ? atomicAdd(&q.cnt[CNT_SHADOW], tots) : 0u;
-      base_a = tota ? atomicAdd(&q.cnt[CNT_NEXT], tota) : 0u;
+      static_assert((CNT_NEXT & 1) == 0 && CNT_SHADOW == CNT_NEXT + 1, "k_shade adds to (next, shadow) as one 64-bit word");
+      if (tots | tota) {    // both queues with one atomic: (next, shadow) are the halves of an aligned 64-bit word
+        const unsigned long long r = atomicAdd(reinterpret_cast<unsigned long long*>(&q.cnt[CNT_NEXT]), (unsigned long long)tota | ((unsigned long long)tots << 32));
+        base_a = (uint32_t)r; base_s = (uint32_t)(r >> 32);
+      }
     }
     SSTAMP(t_back);
   }

@@ -62,7 +62,10 @@ struct DevQueues {
   uint32_t cap;    // queue capacity (paths per batch)
 };
 
-enum { CNT_RAYS = 0, CNT_NEXT, CNT_SHADOW, CNT_WORK_TRACE, CNT_WORK_SHADE, CNT_WORK_SHADOW, CNT_N };
+// Device counters of a lane.  Atomics on one 128-byte line are served one at a time (≈11 ns each), so every counter that takes
+// atomics has a line of its own, and k_shade's two output counters are the halves of ONE aligned 64-bit word (one atomic per
+// window for both queues): k_shade −6 % against six adjacent words.
+enum { CNT_RAYS = 0, CNT_NEXT = 32, CNT_SHADOW = 33, CNT_WORK_TRACE = 96, CNT_WORK_SHADE = 128, CNT_WORK_SHADOW = 160, CNT_N = 192 };
 enum { ST_SEGMENTS = 0, ST_SHADOW, ST_HITS, ST_NODES_C, ST_TRIS_C, ST_NODES_A, ST_TRIS_A,
        // wave-level iteration counts of the trace kernels' loops (filled only by a -DPT_DIAG build): lane
        // utilisation of a phase = lane-level count / (64 x wave-level count)
