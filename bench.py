@@ -27,8 +27,9 @@ Extra objects on the JSON line:
                `traffic` = HBM-side bytes per launch from the same PMC profile; `algorithmic_*` = the
                SURVEY §8(d) byte model (counted units × record sizes), labelled as such: those bytes are mostly
                served by LDS / L2 / Infinity Cache and are NOT an HBM roofline.
-               `frac` uses the live HIP-event time of a launch, which includes the time it shares the chip with the other
-               lane's kernels; `frac_exclusive` uses the kernel's exclusive duration from the profile's serialised run.
+               `frac` uses the live HIP-event time of a launch (with PTC_LANES > 1 that includes the time it shares the chip
+               with another lane's kernels; the default is one lane); `frac_exclusive` uses the kernel's exclusive duration
+               from the profile's serialised run.
   kernels      the same two rooflines (valu_issue, hbm) for k_trace_closest, k_trace_any and k_shade.
   whole_frame  VALU issue and HBM rates of the three kernels together over the timed wall time.
   cpu_baseline the oracle (scalar C restatement, kind "port") timed on this box's host cores on a
@@ -235,8 +236,8 @@ def main():
                 gbs = n_units * m["hbm_bytes_per_unit"] / sec / 1e9
                 e["hbm"] = {"achieved": gbs, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
                             "bytes_per_launch": n_units * m["hbm_bytes_per_unit"] / nl}
-            # The live event time of a launch includes the time it shares the chip with the other lane's kernels; the profile's
-            # serialised run gives the kernel's exclusive duration for the same units per launch.
+            # With PTC_LANES > 1 the live event time of a launch includes the time it shares the chip with another lane's kernels;
+            # the profile's serialised run gives the kernel's exclusive duration for the same units per launch.
             if m.get("serialised_ms_per_launch") and m.get("serialised_units_per_launch"):
                 excl_ms = m["serialised_ms_per_launch"] * (n_units / nl) / m["serialised_units_per_launch"]
                 e["exclusive_launch_ms_from_profile"] = excl_ms
@@ -250,7 +251,7 @@ def main():
             winstr = sum(float(d[units[k][0]]) * model[k]["valu_winstr_per_unit"] for k in kernels)
             hbm_b = sum(float(d[units[k][0]]) * model[k]["hbm_bytes_per_unit"] for k in kernels)
             pk = valu_peak_measured or VALU_PEAK_PAPER_GIPS
-            whole = {"note": "the three kernels together over the timed wall time (two lanes share the chip, so per-kernel event times overlap)",
+            whole = {"note": "the three kernels together over the timed wall time",
                      "valu_issue_G_winstr_s": winstr / dt / 1e9, "valu_issue_frac": winstr / dt / 1e9 / pk,
                      "hbm_GBs": hbm_b / dt / 1e9, "hbm_frac": hbm_b / dt / 1e9 / HBM_PEAK_GBS}
         n_launch = max(1, d["launches_trace_closest"])
@@ -287,6 +288,8 @@ def main():
                              f"textured atrium {desc.n_triangles} tris + 1024^2 albedo/normal/metal-rough textures + 2048x1024 env light (BASELINE configs[4])")
                             + f", {args.width}x{args.height}, {S * K} spp = {K} steps x {S} spp, max_bounces {args.max_bounces}, seed {args.seed}",
                 "paths": paths,
+                "batching": "%d lane(s), %d samples per full wavefront batch (%d paths in flight)"
+                            % (int(os.environ.get("PTC_LANES", "1")), pt.internals()["per_batch"], pt.internals()["per_batch"] * (pt.internals()["queue_cap"] // max(1, pt.internals()["per_batch"]))),
                 "scene_source": scene_source,
                 "sharding": (f"32x32 tiles over {world} ranks (each rank: 1/{world} of the pixels x {S} spp per step), {reduce_impl} to rank 0"
                              if world > 1 else "single GPU"),

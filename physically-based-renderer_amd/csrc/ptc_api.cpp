@@ -2,10 +2,10 @@
 //
 // One context = one HIP device + `n_lanes` streams ("lanes").  Everything a frame needs is enqueued without host
 // synchronisation: queue sizes live in device memory and the persistent kernels read them there, so a whole batch
-// (raygen → [trace, shade, shadow, advance] × bounces → accumulate) is a single asynchronous burst.  Successive batches
-// of a frame alternate between the lanes, so one batch's launch tails overlap another batch's full-occupancy phases;
-// only the per-pixel accumulation is ordered (sample order), by events.  The host blocks only in ptc_sync / read-backs /
-// ptc_get_stats.
+// (raygen → [trace, shade, shadow, advance] × bounces → accumulate) is a single asynchronous burst.  With PTC_LANES > 1
+// successive batches of a frame alternate between the lanes, so one batch's launch tails overlap another batch's
+// full-occupancy phases (only the per-pixel accumulation is ordered, in sample order, by events); the default is one lane,
+// which the round-2 kernels make the faster arrangement.  The host blocks only in ptc_sync / read-backs / ptc_get_stats.
 //
 // There is no CPU path in this library: without a usable HIP device ptc_create fails.
 #include "../../include/ptc.h"
@@ -80,8 +80,10 @@ struct ptc_ctx {
   std::string err;
   LaunchCfg cfg{};
   uint32_t toplet_budget = 73;   // 64-byte records staged in LDS: the top three levels (1+8+64 nodes) of the tree = 4.6 KB
-  size_t max_batch_paths = (size_t)1 << 28;   // paths in flight over all lanes: large batches amortise launch tails (sized for 288 GB of HBM:
-                                              // 176 B per path -> 47 GB of queues at 1080p x 64 spp x 2 lanes; 2^27 is 2 % slower, 2^29 1 % faster)
+  size_t max_batch_paths = (size_t)1 << 29;   // paths in flight over all lanes.  Large batches amortise what a launch costs regardless of its size
+                                              // (drain of the persistent waves, small late-bounce launches): 2^29 is 1.5 % faster than 2^28, 2^27 3 % and
+                                              // 2^25 24 % slower.  176 B per path = 94 GB of queues when a 1080p frame is rendered at >= 258 spp — sized
+                                              // for 288 GB of HBM; frame_begin lowers it to what 60 % of the free memory holds.
   bool timing = true;
   // description
   std::vector<HostMaterial> mats;
@@ -102,7 +104,8 @@ struct ptc_ctx {
   std::vector<void*> scene_allocs;
   // lanes: lane 0 is the context's primary stream (resolve, tonemap, conversions, the reduce)
   std::vector<Lane> lanes;
-  int n_lanes = 2;
+  int n_lanes = 1;                  // PTC_LANES: >1 runs successive batches on separate streams.  With the round-2 kernels one lane
+                                    // is 3.7 % faster than two (co-scheduled launches slow each other down by more than the tails they fill)
   uint64_t batches_issued = 0;
   // frame
   bool in_frame = false;
@@ -135,6 +138,7 @@ struct ptc_group {
 
 namespace {
 
+constexpr size_t kQueueBytesPerPath = 176;   // ensure_lane_queues: 2 x 48 (ray ping-pong) + 48 (shadow) + 16 (hit) + 16 (path radiance)
 constexpr size_t kMaxSpans = 1024;   // timing spans (event pairs) kept at most; see run_batch
 int fail(ptc_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
 const char* const kNoDevice = "this context has no device (PTC_DEVICE_NONE): the call needs a gfx950 GPU; there is no CPU path";
@@ -650,7 +654,16 @@ int ptc_frame_begin(ptc_ctx* c, int w, int h, int spp_total, uint64_t seed, int 
   // samples of one full batch: as many as fit max_batch_paths split over the lanes.  The queues themselves are sized by the
   // batches actually issued (frame_add_samples), not by spp_total: a progressive loop adding one sample at a time needs
   // queues for one sample per pixel only.
-  size_t per = owned.empty() ? 1 : c->max_batch_paths / owned.size() / (size_t)c->n_lanes;
+  size_t batch_paths = c->max_batch_paths;
+  {   // no more than 60 % of the device memory that is free now (plus what the lanes' queues already hold) goes into queues
+    size_t free_b = 0, total_b = 0, held = 0;
+    for (const auto& ln : c->lanes) held += (size_t)ln.q.cap * kQueueBytesPerPath;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      const size_t fit = (size_t)(0.6 * (double)(free_b + held)) / kQueueBytesPerPath;
+      if (fit < batch_paths) batch_paths = fit;
+    }
+  }
+  size_t per = owned.empty() ? 1 : batch_paths / owned.size() / (size_t)c->n_lanes;
   if (per < 1) per = 1;
   if (per > 0x7fffffffu) per = 0x7fffffffu;
   if (!owned.empty() && (uint64_t)owned.size() * per > 0xfffffff0ull) per = 0xfffffff0ull / owned.size();

@@ -40,3 +40,24 @@ def rel_l2(a, b):
     a = a[..., :3].astype(np.float64)
     b = b[..., :3].astype(np.float64)
     return float(np.sqrt(((a - b) ** 2).sum()) / max(np.sqrt((b ** 2).sum()), 1e-30))
+
+
+def run_torchrun(nproc, script_args, env=None, cwd=None, timeout=600):
+    """`python -m torch.distributed.run` on 127.0.0.1 with a port the OS just handed out.  Between closing that probe socket and the
+    rendezvous store's bind another process can take the port (or it is still in TIME_WAIT from an earlier run): that one failure,
+    and only that one, is retried with a new port."""
+    import socket
+    import subprocess
+
+    r = None
+    for _ in range(4):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + list(script_args)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(env or os.environ, MASTER_ADDR="127.0.0.1"), cwd=cwd)
+        if r.returncode == 0 or "EADDRINUSE" not in r.stderr:
+            break
+    return r

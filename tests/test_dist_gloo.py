@@ -1,27 +1,16 @@
 """N > 1 path on the CPU: world_size 2 and 3 over gloo (SURVEY §8e — tiles sharded, one reduce)."""
 import os
-import socket
-import subprocess
 import sys
 
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+sys.path.insert(0, HERE)
+from conftest import run_torchrun  # noqa: E402
 
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_tile_sharding_and_reduce_gloo(ora, world):
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(HERE, "_dist_worker.py")]
-    env = dict(os.environ, OMP_NUM_THREADS="1")
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    r = run_torchrun(world, [os.path.join(HERE, "_dist_worker.py")], env=dict(os.environ, OMP_NUM_THREADS="1"), timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "DIST_OK" in r.stdout

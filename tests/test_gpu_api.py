@@ -111,19 +111,21 @@ def test_small_calls_merge_into_full_batches(gpu, ora):
     pt.frame_resolve()
     assert _bits_equal(pt.read_radiance(), ref)
     assert pt.stats()["launches_trace_closest"] == n_big               # one batch, not twelve
-    os.environ["PTC_BATCH_PATHS"] = str(w * h * 5 * 2)                 # per_batch = 5 samples
-    try:
-        small = gpu.PathTracer(0).load_scene(d)
-        small.frame_begin(w, h, spp, 4, 8, 0)
-        assert small.internals()["per_batch"] == 5
-        for k in range(spp):
-            small.frame_add_samples(1)
-            assert small.internals()["pending"] == (k + 1) % 5
-        small.frame_resolve()
-        assert _bits_equal(small.read_radiance(), ref)
-        assert small.stats()["launches_trace_closest"] == 3 * (8 + 1)  # batches of 5, 5 and 2 samples
-    finally:
-        del os.environ["PTC_BATCH_PATHS"]
+    for lanes in (1, 2, 3):                                            # one stream (the default) and batches alternating over 2 and 3
+        os.environ["PTC_BATCH_PATHS"] = str(w * h * 5 * lanes)          # per_batch = 5 samples
+        os.environ["PTC_LANES"] = str(lanes)
+        try:
+            small = gpu.PathTracer(0).load_scene(d)
+            small.frame_begin(w, h, spp, 4, 8, 0)
+            assert small.internals()["per_batch"] == 5
+            for k in range(spp):
+                small.frame_add_samples(1)
+                assert small.internals()["pending"] == (k + 1) % 5
+            small.frame_resolve()
+            assert _bits_equal(small.read_radiance(), ref)
+            assert small.stats()["launches_trace_closest"] == 3 * (8 + 1)  # batches of 5, 5 and 2 samples
+        finally:
+            del os.environ["PTC_BATCH_PATHS"], os.environ["PTC_LANES"]
 
 
 def test_rgba16f_output_matches_numpy_float16(gpu):

@@ -18,7 +18,7 @@ import numpy as np
 import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from conftest import GOLDEN, rel_l2  # noqa: E402
+from conftest import GOLDEN, rel_l2, run_torchrun  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -36,16 +36,6 @@ def gpu(pbr):
 
 def _bits_equal(a, b):
     return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
-
-
-def _free_port():
-    import socket
-
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
 
 
 def _pair(gpu, ora, desc):
@@ -252,12 +242,15 @@ def test_sharding_and_batching_do_not_change_bits(gpu):
             pt.frame_add_samples(k)
         pt.frame_resolve()
         assert _bits_equal(pt.read_radiance(), full)
-    os.environ["PTC_BATCH_PATHS"] = "30000"                                       # forces ~5 internal batches of 1 spp
-    try:
-        small = gpu.PathTracer(0).load_scene(gpu.scenes.atrium(0.05))
-        assert _bits_equal(small.render(w, h, spp, seed=7), full)
-    finally:
-        del os.environ["PTC_BATCH_PATHS"]
+    for lanes in (1, 2, 3):                                                        # batches on one stream, and alternating over 2 and 3
+        os.environ["PTC_BATCH_PATHS"] = str(15000 * lanes)                         # forces ~5 internal batches of 1 spp
+        os.environ["PTC_LANES"] = str(lanes)
+        try:
+            small = gpu.PathTracer(0).load_scene(gpu.scenes.atrium(0.05))
+            assert _bits_equal(small.render(w, h, spp, seed=7), full)
+            assert small.stats()["launches_trace_closest"] >= 5 * 9
+        finally:
+            del os.environ["PTC_BATCH_PATHS"], os.environ["PTC_LANES"]
 
 
 def test_full_size_properties(gpu):
@@ -378,11 +371,9 @@ def test_bench_two_rank_rehearsal(gpu):
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--spp-per-step", "2", "--width", "256", "--height", "192",
-           "--scene-scale", "0.05", "--backend", "gloo", "--share-device", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    args = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--spp-per-step", "2", "--width", "256", "--height", "192",
+            "--scene-scale", "0.05", "--backend", "gloo", "--share-device", "--no-cpu-baseline"]
+    r = run_torchrun(2, args, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(line) == 1, r.stdout
@@ -390,7 +381,7 @@ def test_bench_two_rank_rehearsal(gpu):
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 2       # the default: the frame is fixed, ranks split its pixels
     assert d["config"]["paths"] == 256 * 192 * 2 * 2 and d["value"] > 0              # 2 spp per step, 2 steps, whole frame
     assert d["per_path"]["segments"] > 1.0 and "torch.distributed.reduce" in d["config"]["sharding"]
-    r = subprocess.run(cmd + ["--scaling", "weak"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    r = run_torchrun(2, args + ["--scaling", "weak"], cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["scaling"] == "weak" and d["config"]["paths"] == 256 * 192 * 2 * 2 * 2  # weak (opt-in): 2 spp x 2 ranks per step, 2 steps
@@ -440,9 +431,7 @@ def test_render_sharded_two_ranks_on_one_gpu(gpu, world):
     import sys
 
     here = os.path.dirname(os.path.abspath(__file__))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(here, "_dist_gpu_worker.py")]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    r = run_torchrun(world, [os.path.join(here, "_dist_gpu_worker.py")])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "DIST_GPU_OK" in r.stdout
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (on the GPU box): tools/profile.sh TAG [bench args]   → gpurun_out/prof_TAG/{lane1.txt, kernel_stats.csv, pmc_summary.json, bench*.json}
-# One-lane breakdown, two-lane kernel trace, then counter passes (each in its own run, kernel-trace/stats never combined with --pmc).
+# One-lane breakdown, kernel trace of the default configuration, then counter passes (each in its own run, kernel-trace/stats never combined with --pmc).
 TAG=$1; shift
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
