@@ -8,7 +8,9 @@ cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - > /dev/null
 B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline $*"
 PTC_LANES=1 python3 bench.py --steps 6 --warmup 1 --no-cpu-baseline "$@" 2>/dev/null > $OUT/bench_lane1.json
 python3 -c "import json; d=json.load(open('$OUT/bench_lane1.json')); print('1 lane => %.1f Mpaths/s' % d['value'], {k: round(v,4) for k,v in d['seconds'].items()})" | tee $OUT/lane1.txt
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $B > $OUT/kt.log 2>&1 || exit 1
+# the kernel trace runs bench.py's DEFAULT command (16 steps, 2 warm-up): its per-kernel average durations are the ones the bench line's
+# `avg_launch_ms` must agree with; the counter passes below use 3 steps (they serialise the dispatches and take longer)
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 bench.py --no-cpu-baseline "$@" > $OUT/kt.log 2>&1 || exit 1
 cp $(find $OUT/kt -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv
 head -12 $OUT/kernel_stats.csv
 i=0
