@@ -272,7 +272,8 @@ struct Reservoir {
   // queue still spreads over the whole chip
   PT_DEV void init(uint32_t n, uint32_t wave_in_grid) {
     const uint32_t waves = gridDim.x * TRACE_WAVES;
-    const uint32_t per_wave = n / (waves * 4u);
+    const uint32_t per_wave = n / (waves * 2u);                     // a short queue: one static and about one dynamic chunk per wave (a queue
+                                                                    // below 16.8 M rays used to be cut into 4 chunks per wave: 32 k atomics = 0.36 ms whatever its length)
     chunk = per_wave >= TRACE_CHUNK ? TRACE_CHUNK : (per_wave < 64u ? 64u : (per_wave & ~63u));
     dyn_base = waves * chunk;
     const uint32_t first = wave_in_grid * chunk;                    // < 2^23
