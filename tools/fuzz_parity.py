@@ -11,7 +11,9 @@ n, seed = (int(sys.argv[1]) if len(sys.argv) > 1 else 200), (int(sys.argv[2]) if
 rng = np.random.default_rng(seed)
 bad = 0
 for k in range(n):
+    if k % 50 == 0: print("scene", k, flush=True)
     d = tg._random_scene(pbr.scene, rng, k)
+    d.bvh_builder = "lbvh" if k % 3 == 2 else "sah"          # every third scene through the Morton-LBVH builder
     w, h = int(rng.integers(8, 70)), int(rng.integers(8, 70))
     spp, mb, s = int(rng.integers(1, 6)), int(rng.integers(0, 9)), int(rng.integers(0, 1 << 40))
     pt, o = pbr.PathTracer(0).load_scene(d), ora.Oracle().load_scene(d)
@@ -19,6 +21,6 @@ for k in range(n):
     ok = np.array_equal(g.view(np.uint32), c.view(np.uint32)) and all(pt.stats()[x] == o.stats()[x] for x in tg.COUNTERS)
     if not ok:
         bad += 1
-        print("MISMATCH scene", k, "pixels", int((g != c).any(-1).sum()), flush=True)
+        print("MISMATCH scene", k, d.bvh_builder, "pixels", int((g != c).any(-1).sum()), flush=True)
 print(f"{n} scenes, {bad} mismatches")
 sys.exit(1 if bad else 0)
