@@ -69,6 +69,22 @@ def test_hit_records_golden(ora, pbr):
             assert prim[k] >= 0 and abs(t[k] - tmin) <= 1e-4 * max(1.0, tmin)
 
 
+def test_hit_records_do_not_depend_on_the_builder(ora, pbr):
+    """Closest hit (t, primitive, barycentrics, ties to the lowest primitive id) and occlusion are properties of the triangles, not
+    of the tree: the Morton-LBVH builder must reproduce the golden records of the SAH tree bit for bit."""
+    from golden.make_golden import fixed_rays
+
+    d = pbr.scenes.sphere_scene()
+    d.bvh_builder = "lbvh"
+    o = ora.Oracle().load_scene(d)
+    org, dirs, tmax = fixed_rays(d)
+    g = np.load(os.path.join(GOLDEN, "sphere10k_rays4096.npz"))
+    t, prim, uv = o.trace_closest(org, dirs)
+    assert np.array_equal(t.view(np.uint32), g["t"].view(np.uint32)) and np.array_equal(prim, g["prim"])
+    assert np.array_equal(uv.view(np.uint32), g["uv"].view(np.uint32))
+    assert np.array_equal(o.trace_any(org, dirs, tmax), g["occ"])
+
+
 def test_digests(ora, pbr):
     from golden.make_golden import DIGEST_CASES, box32
 
