@@ -94,6 +94,25 @@ def test_frame_reserve_allocates_full_batches_up_front(gpu):
         gpu.PathTracer(0).frame_reserve()            # no frame
 
 
+def test_batch_size_is_clamped_to_free_device_memory(gpu):
+    """frame_begin sizes a full batch by PTC_BATCH_PATHS but never beyond what 60 % of the free device memory holds in queues
+    (176 B per path), so that an oversized setting (or a card that is partly taken) degrades to smaller batches, not to PTC_E_NOMEM."""
+    import torch
+
+    free_b, total_b = torch.cuda.mem_get_info(0)
+    os.environ["PTC_BATCH_PATHS"] = str(1 << 40)
+    try:
+        pt = gpu.PathTracer(0).load_scene(gpu.scenes.cornell_box())
+        w, h = 1920, 1080
+        pt.frame_begin(w, h, 1 << 20, 1, 4, 0)
+        per = pt.internals()["per_batch"]
+        assert pt.internals()["queue_cap"] == 0                                    # nothing allocated by frame_begin itself
+        assert 0.3 * free_b < per * w * h * 176 <= 0.62 * total_b
+        assert per * w * h < 1 << 32                                               # queue slots are 32-bit
+    finally:
+        del os.environ["PTC_BATCH_PATHS"]
+
+
 def test_small_calls_merge_into_full_batches(gpu, ora):
     """Deferred batching: samples added in small calls are issued as full wavefront batches (launches as wide as one
     big call's), a partial batch goes out at resolve; bits do not depend on how the samples were handed over."""
