@@ -122,3 +122,46 @@ def test_bilinear_filter_option(ora, pbr):
     assert min(row_l) < 0.05 and max(row_l) > 0.95
     d.texture_filter = "nearest"                                                  # scene_begin resets the filter
     assert np.array_equal(o.load_scene(d).render(64, 64, 32, seed=2, max_bounces=2)[..., 0], near)
+
+
+def test_environment_azimuth_and_polar_convention(ora, pbr):
+    """The lat-long convention of include/ptc.h — row 0 = +y, u = atan2(d.z, d.x)/(2 pi) + 1/2 — pinned against physics: one bright
+    texel block; a small Lambert quad facing direction n receives E = L * d_omega * max(0, n.d) from it, with d the direction the
+    DOCUMENTED formula gives for that block.  Facing it: full; 60 degrees off: half; facing away or edge-on: nothing."""
+    sc = pbr.scene
+    h, w = 32, 64
+    r0, c0 = 9, 41                                             # a 2x2 block well away from poles and seam
+    env = np.zeros((h, w, 3), np.float32)
+    L = 4000.0
+    env[r0:r0 + 2, c0:c0 + 2] = L
+    theta = np.pi * (r0 + 1.0) / h                             # block centre: v = (r0 + 1)/h, theta from +y
+    a = 2.0 * np.pi * (c0 + 1.0) / w                           # u = (c0 + 1)/w = atan2(d.z, d.x)/(2 pi) + 1/2  =>  atan2(d.z, d.x) = a - pi
+    dsun = np.array([np.sin(theta) * np.cos(a - np.pi), np.cos(theta), np.sin(theta) * np.sin(a - np.pi)])
+    dom = sum((2 * np.pi / w) * (np.pi / h) * np.sin(np.pi * (r + 0.5) / h) * 2 for r in (r0, r0 + 1))   # two columns per row
+    rho = 0.8
+
+    def radiance(n):
+        n = np.asarray(n, np.float64) / np.linalg.norm(n)
+        t = np.cross(n, [0.3, 0.5, 0.8]); t /= np.linalg.norm(t)
+        b = np.cross(n, t)
+        k = 0.5
+        v, i = pbr.scenes._quad(tuple(-k * t - k * b), tuple(k * t - k * b), tuple(k * t + k * b), tuple(-k * t + k * b))
+        nn = np.cross(np.asarray(v["position"][1]) - np.asarray(v["position"][0]), np.asarray(v["position"][2]) - np.asarray(v["position"][0]))
+        if np.dot(nn, n) < 0:                                  # wind the quad so that its front faces n
+            i = i.reshape(-1, 3)[:, ::-1].reshape(-1).copy()
+        v["normal"][:] = n.astype(np.float32)
+        cam = sc.CameraDesc(tuple(3.0 * n), (0.0, 0.0, 0.0), 0.05, 1.0)
+        d = sc.SceneDesc([sc.Material((rho, rho, rho, 1.0), 0.0, 1.0)], [sc.MeshDesc(v, i, 0)], [sc.InstanceDesc(0)], cam, env=env)
+        img = ora.Oracle().load_scene(d).render(8, 8, 256, seed=5, max_bounces=1)
+        return float(img[..., :3].mean())
+
+    full = rho / np.pi * L * dom
+    assert abs(radiance(dsun) - full) < 0.03 * full
+    # 60 degrees off: rotate dsun about an axis perpendicular to it
+    ax = np.cross(dsun, [0.0, 1.0, 0.0]); ax /= np.linalg.norm(ax)
+    n60 = dsun * 0.5 + np.cross(ax, dsun) * np.sqrt(0.75)
+    assert abs(radiance(n60) - 0.5 * full) < 0.03 * full
+    assert radiance(-dsun) < 1e-3 * full
+    # a quad facing the z-mirrored direction (what the formula with the other sign of z would call the sun) gets the cosine only
+    wrong = dsun * np.array([1.0, 1.0, -1.0])
+    assert abs(radiance(wrong) - max(0.0, float(np.dot(wrong, dsun))) * full) < 0.03 * full and float(np.dot(wrong, dsun)) < 0.9
