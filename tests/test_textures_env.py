@@ -165,3 +165,25 @@ def test_environment_azimuth_and_polar_convention(ora, pbr):
     # a quad facing the z-mirrored direction (what the formula with the other sign of z would call the sun) gets the cosine only
     wrong = dsun * np.array([1.0, 1.0, -1.0])
     assert abs(radiance(wrong) - max(0.0, float(np.dot(wrong, dsun))) * full) < 0.03 * full and float(np.dot(wrong, dsun)) < 0.9
+
+
+@pytest.mark.parametrize("g,b", [(128, 255), (64, 0), (200, 128)])
+def test_metal_rough_texture_channels_are_gltf(ora, pbr, g, b):
+    """glTF metallicRoughnessTexture: roughness in G, metallic in B, both multiplied by the factors.  A uniform texel (R = 77,
+    G = g, B = b) on a material with factors 1 must render, bit for bit, what the untextured material with roughness g/255 and
+    metallic b/255 renders (R is ignored); with factors 1/2 the products are what counts."""
+    env = np.ones((8, 16, 3), np.float32)
+    tex = np.full((4, 4, 4), 255, np.uint8)
+    tex[..., 0], tex[..., 1], tex[..., 2] = 77, g, b
+    base = (0.9, 0.6, 0.3, 1.0)
+    f = lambda x: float(np.float32(x) / np.float32(255))
+    for fm, fr in ((1.0, 1.0), (0.5, 0.5)):
+        textured = _plane_scene(pbr, pbr.scene.Material(base, fm, fr, (0, 0, 0), -1, -1, 0), [tex], env)
+        plain = _plane_scene(pbr, pbr.scene.Material(base, float(np.float32(fm) * np.float32(f(b))), float(np.float32(fr) * np.float32(f(g)))), env=env)
+        a = ora.Oracle().load_scene(textured).render(24, 24, 8, seed=9, max_bounces=3)
+        c = ora.Oracle().load_scene(plain).render(24, 24, 8, seed=9, max_bounces=3)
+        assert np.array_equal(a.view(np.uint32), c.view(np.uint32))
+    swapped = _plane_scene(pbr, pbr.scene.Material(base, f(g), f(b)), env=env)          # G and B read the other way round: a different image
+    w = ora.Oracle().load_scene(swapped).render(24, 24, 8, seed=9, max_bounces=3)
+    if g != b:
+        assert not np.array_equal(w.view(np.uint32), c.view(np.uint32))
