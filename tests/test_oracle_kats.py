@@ -213,3 +213,42 @@ def test_raster_gbuffer16_is_the_quantised_lighting_pass(ora, pbr):
         c = img[4, 4]                                           # centre pixel: P = (0,0,-2) exactly, N = (0,0,1): NdotV = 1, spec = 1
         q = np.round(np.clip(np.asarray(base, np.float64), 0, 1) * 65535) / 65535
         assert np.allclose(c, q * 1.0 + 1.0, rtol=0, atol=2e-7), (c, q)
+
+
+def test_r6_front_face_is_the_vulkan_clockwise_rule(ora, pbr):
+    """R6: the reference culls back faces with frontFace = eClockwise (PbrRenderSystem.cpp:186).  Vulkan decides facing from the
+    sign of the polygon's area in FRAMEBUFFER coordinates (y down, un-flipped viewport): a = -1/2 sum(x_i y_{i+1} - x_{i+1} y_i);
+    clockwise-front means a < 0 is front.  The raster-compat integrator must show exactly the triangles that rule calls front,
+    with the framebuffer positions coming from the reference's own view / projection matrices (KAT'd above), not from the
+    path tracer's determinant test."""
+    sc = pbr.scene
+    rng = np.random.default_rng(21)
+    n_front = n_back = 0
+    for k in range(60):
+        pos = rng.uniform(-2, 2, 3)
+        tgt = pos + rng.normal(size=3)
+        fov, asp = 0.9, 1.0
+        V, P = ora.make_camera(tuple(pos), tuple(tgt), fov, asp)
+        fwd = (tgt - pos) / np.linalg.norm(tgt - pos)
+        ctr = pos + 4.0 * fwd                                             # a triangle around the view axis, 4 units ahead
+        tri = ctr + rng.normal(scale=0.6, size=(3, 3))
+        clip = np.concatenate([tri, np.ones((3, 1))], 1) @ V.astype(np.float64) @ P.astype(np.float64)
+        assert (clip[:, 3] > 0).all()
+        ndc = clip[:, :2] / clip[:, 3:4]
+        fb = (ndc + 1.0) * 0.5 * 64.0                                     # y-down framebuffer, no flip (PbrRenderSystem.cpp:425-430)
+        area = -0.5 * sum(fb[i, 0] * fb[(i + 1) % 3, 1] - fb[(i + 1) % 3, 0] * fb[i, 1] for i in range(3))
+        if abs(area) < 20.0 or (np.abs(ndc) > 0.95).any():                # skip slivers and triangles leaving the frame
+            continue
+        front = area < 0.0                                                # VK_FRONT_FACE_CLOCKWISE
+        v = np.zeros(3, sc.MESH_VERTEX)
+        v["position"] = tri.astype(np.float32)
+        nrm = np.cross(tri[1] - tri[0], tri[2] - tri[0]); nrm /= np.linalg.norm(nrm)
+        v["normal"] = nrm.astype(np.float32)
+        v["tangent"] = (1, 0, 0, 1)
+        d = sc.SceneDesc([sc.Material((0.8, 0.8, 0.8, 1.0))], [sc.MeshDesc(v, np.array([0, 1, 2], np.uint32), 0)], [sc.InstanceDesc(0)],
+                         sc.CameraDesc(tuple(pos), tuple(tgt), fov, asp))
+        img = ora.Oracle().load_scene(d).render(64, 64, 1, integrator=1)
+        visible = bool((img[..., 3] > 0).any())
+        assert visible == front, (k, area)
+        n_front += front; n_back += (not front)
+    assert n_front >= 8 and n_back >= 8
