@@ -252,3 +252,27 @@ def test_r6_front_face_is_the_vulkan_clockwise_rule(ora, pbr):
         assert visible == front, (k, area)
         n_front += front; n_back += (not front)
     assert n_front >= 8 and n_back >= 8
+
+
+@pytest.mark.parametrize("tilt_deg", [0.0, 20.0, 45.0, 70.0])
+def test_r8_blinn_phong_with_the_light_at_the_camera(ora, pbr, tilt_deg):
+    """R8: lighting.glsl:25-28 sets L = V, so BlinnPhong.lib.glsl:4-10 reduces to  out = albedo * NdotV + NdotV^64  on all four
+    channels.  A plane through (0,0,-3) tilted about y, seen by the centre pixel along -z: NdotV = cos(tilt), in float64."""
+    sc = pbr.scene
+    a = math.radians(tilt_deg)
+    n = np.array([math.sin(a), 0.0, math.cos(a)])
+    t, b, c = np.array([math.cos(a), 0.0, -math.sin(a)]), np.array([0.0, 1.0, 0.0]), np.array([0.0, 0.0, -3.0])
+    base = (0.7, 0.35, 0.15, 0.6)
+    shown = None
+    for order in ((0, 1, 2, 3), (3, 2, 1, 0)):                       # one of the two windings faces the camera (R6)
+        corners = [c - 4 * t - 4 * b, c + 4 * t - 4 * b, c + 4 * t + 4 * b, c - 4 * t + 4 * b]
+        v, i = pbr.scenes._quad(*[tuple(corners[k]) for k in order])
+        v["normal"][:] = n.astype(np.float32)
+        d = sc.SceneDesc([sc.Material(base, 0.0, 1.0)], [sc.MeshDesc(v, i, 0)], [sc.InstanceDesc(0)], sc.CameraDesc((0, 0, 0), (0, 0, -1), 0.8, 1.0))
+        img = ora.Oracle().load_scene(d).render(9, 9, 1, integrator=1)
+        if img[4, 4, 3] > 0:
+            shown = img[4, 4].astype(np.float64)
+    assert shown is not None
+    ndv = math.cos(a)
+    expect = np.asarray(base, np.float64) * ndv + ndv ** 64
+    assert np.allclose(shown, expect, rtol=2e-5, atol=2e-6), (shown, expect)
