@@ -40,9 +40,10 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
+        path = os.environ.get("ORA_LIB") or _LIB_PATH      # ORA_LIB: an experimental build of the oracle (tools/tree_quality.py)
+        if path == _LIB_PATH and not os.path.exists(_LIB_PATH):
             build()
-        L = C.CDLL(_LIB_PATH)
+        L = C.CDLL(path)
         vp, fp, u32p, i32p, u8p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
         L.ora_create.restype = vp
         L.ora_destroy.argtypes = [vp]

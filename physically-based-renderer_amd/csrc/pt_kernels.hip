@@ -34,14 +34,11 @@
 #define TRACE_NODE_MIN 40         // leave the node loop when fewer lanes than this are still at interior nodes
 #endif                            // while others wait at a leaf (keeps both phases well populated; 24: -6 %, 32: -1.5 %, 48: -3 %, 56: -18 %)
 #ifndef SHADE_BLOCK
-#define SHADE_BLOCK 512
+#define SHADE_BLOCK 256           // a block only shares the staged light / material tables; its waves never synchronise after that
 #endif
 #ifndef SHADE_MIN_WAVES
-#define SHADE_MIN_WAVES 1
+#define SHADE_MIN_WAVES 4         // <= 128 VGPRs: four independent waves per SIMD
 #endif
-#ifndef SHADE_GRID
-#define SHADE_GRID 2          // blocks per CU = what is resident at 114 VGPRs (4 waves/SIMD): windows are dealt statically, so a third, non-resident
-#endif                        // block per CU only adds a tail (3: +5 % kernel time in the one-lane run); 256-thread blocks: +58 % kernel time
 #define SHADE_WAVES (SHADE_BLOCK / 64)
 #define SHADE_LDS_LIGHTS 64       // emitter table and material table are staged in LDS when they fit
 #define SHADE_LDS_MATS 64
@@ -59,19 +56,62 @@ PT_DEV unsigned long long wave_sum(unsigned long long v) {
 }
 
 // =================================================================================================
-// bookkeeping kernels
-__global__ void k_set_counts(uint32_t* cnt, uint32_t n_rays, uint32_t n_shadow) {
-  if (threadIdx.x == 0) {
-    cnt[CNT_RAYS] = n_rays; cnt[CNT_NEXT] = 0; cnt[CNT_SHADOW] = n_shadow;
-    cnt[CNT_WORK_TRACE] = 0; cnt[CNT_WORK_SHADE] = 0; cnt[CNT_WORK_SHADOW] = 0;
-  }
+// bookkeeping kernels: per-segment counts -> chunk prefix (ptc_internal.h, "SEGMENTED queues")
+//
+// One block of SCAN_BLOCK threads.  The trace kernels hand out rays in chunks that never straddle a segment; the chunk size follows the
+// queue's length: TRACE_CHUNK rays when the queue is long, down to one wave's worth when it is short (about one static and one dynamic
+// chunk per wave of the persistent grid), so that a small late-bounce queue still spreads over the whole chip.
+#define SCAN_BLOCK 1024
+PT_DEV uint32_t block_sum_1024(uint32_t v, uint32_t* s_w /*[16]*/, uint32_t& excl) {   // returns the block total, excl = exclusive prefix of this thread
+  const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if ((int)lane >= o) inc += t; }
+  __syncthreads();                       // s_w may still be read from a previous call
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < SCAN_BLOCK / 64; ++w) { const uint32_t t = s_w[w]; if (w < wave) before += t; total += t; }
+  excl = before + inc - v;
+  return total;
 }
-__global__ void k_advance(uint32_t* cnt) {
-  if (threadIdx.x == 0) {
-    const uint32_t next = cnt[CNT_NEXT];
-    cnt[CNT_RAYS] = next; cnt[CNT_NEXT] = 0; cnt[CNT_SHADOW] = 0;
-    cnt[CNT_WORK_TRACE] = 0; cnt[CNT_WORK_SHADE] = 0; cnt[CNT_WORK_SHADOW] = 0;
+// chunk prefix of one queue: pre[s] = chunks in the segments before s, pre[n_seg] = all chunks; hdr = (total records, chunk size, chunks)
+PT_DEV void scan_chunks(const uint32_t* seg, uint32_t n_seg, uint32_t* pre, uint32_t* hdr, uint32_t trace_waves, uint32_t* s_w) {
+  const uint32_t per = (n_seg + SCAN_BLOCK - 1u) / SCAN_BLOCK;       // consecutive segments per thread (<= 16)
+  const uint32_t s0 = threadIdx.x * per, s1 = s0 + per < n_seg ? s0 + per : n_seg;
+  uint32_t mine = 0, dummy;
+  for (uint32_t sg = s0; sg < s1; ++sg) mine += seg[sg];
+  const uint32_t total = block_sum_1024(mine, s_w, dummy);
+  const uint32_t per_wave = total / (trace_waves * 2u);
+  const uint32_t chunk = per_wave >= TRACE_CHUNK ? TRACE_CHUNK : (per_wave < 64u ? 64u : (per_wave & ~63u));
+  uint32_t chunks = 0;
+  for (uint32_t sg = s0; sg < s1; ++sg) chunks += (seg[sg] + chunk - 1u) / chunk;
+  uint32_t run;
+  const uint32_t all = block_sum_1024(chunks, s_w, run);
+  for (uint32_t sg = s0; sg < s1; ++sg) { pre[sg] = run; run += (seg[sg] + chunk - 1u) / chunk; }
+  if (threadIdx.x == 0) { pre[n_seg] = all; hdr[0] = total; hdr[1] = chunk; hdr[2] = all; }
+}
+// identity layout: n_rays rays at the slots [0, n_rays) of ray[0], n_shadow shadow rays at [0, n_shadow) (k_raygen, test hooks)
+__global__ __launch_bounds__(SCAN_BLOCK) void k_set_counts(DevQueues q, uint32_t n_rays, uint32_t n_shadow, uint32_t trace_waves) {
+  __shared__ uint32_t s_w[SCAN_BLOCK / 64];
+  for (uint32_t sg = threadIdx.x; sg < q.n_seg; sg += SCAN_BLOCK) {
+    const uint64_t lo = (uint64_t)sg * q.seg_len;
+    q.seg_ray[0][sg] = lo >= n_rays ? 0u : (n_rays - lo > q.seg_len ? q.seg_len : (uint32_t)(n_rays - lo));
+    q.seg_ray[1][sg] = 0u;
+    q.seg_sh[sg] = lo >= n_shadow ? 0u : (n_shadow - lo > q.seg_len ? q.seg_len : (uint32_t)(n_shadow - lo));
   }
+  __syncthreads();
+  scan_chunks(q.seg_ray[0], q.n_seg, q.pre_ray, &q.cnt[CNT_RAY_TOTAL], trace_waves, s_w);
+  scan_chunks(q.seg_sh, q.n_seg, q.pre_sh, &q.cnt[CNT_SH_TOTAL], trace_waves, s_w);
+  if (threadIdx.x == 0) { q.cnt[CNT_WORK_TRACE] = 0; q.cnt[CNT_WORK_SHADOW] = 0; }
+}
+// behind k_shade: the rays it wrote to ray[qi_next] are the next bounce's queue, its shadow rays this bounce's shadow queue
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan(DevQueues q, int qi_next, uint32_t trace_waves) {
+  __shared__ uint32_t s_w[SCAN_BLOCK / 64];
+  scan_chunks(q.seg_ray[qi_next], q.n_seg, q.pre_ray, &q.cnt[CNT_RAY_TOTAL], trace_waves, s_w);
+  scan_chunks(q.seg_sh, q.n_seg, q.pre_sh, &q.cnt[CNT_SH_TOTAL], trace_waves, s_w);
+  if (threadIdx.x == 0) { q.cnt[CNT_WORK_TRACE] = 0; q.cnt[CNT_WORK_SHADOW] = 0; }
 }
 
 // =================================================================================================
@@ -260,41 +300,49 @@ PT_DEV uint32_t next_triangle(uint32_t tbase, uint32_t& tmask) {
   return k;
 }
 
-// Wave-private reservoir of input slots: idle lanes are refilled from a chunk of consecutive rays (ballot + mbcnt).  The first
-// chunk of every wave is static (wave w of the grid owns rays [w, w+1) x chunk), the rest of the queue is handed out by one atomic
-// per chunk.  Atomics on one word are served one at a time (~88 per us): when every wave of the persistent grid (8192) opened with
-// one, an all but empty launch took 140 us; a queue the static round covers now costs none (54 us).  (Looking at the counter with
-// an agent-scope load before asking for a chunk, to spare the failing atomics at the end, made the kernels 53 % slower.)
-// Returns, per lane, whether it received slot `ri`.
+// Wave-private reservoir of input slots: idle lanes are refilled from a chunk of consecutive rays of one queue segment (ballot +
+// mbcnt).  Chunks are numbered over the whole queue (k_scan's prefix of chunks per segment); the first chunk of every wave is static
+// (wave w of the grid owns chunk w), the rest are handed out by one atomic per chunk.  Atomics on one word are served one at a time
+// (~88 per us): when every wave of the persistent grid (8192) opened with one, an all but empty launch took 140 us; a queue the static
+// round covers costs none.  (Looking at the counter with an agent-scope load before asking for a chunk, to spare the failing atomics
+// at the end, made the kernels 53 % slower.)
 struct Reservoir {
-  uint32_t next, end, chunk, dyn_base; bool exhausted;
-  // chunk: TRACE_CHUNK rays when the queue is long, down to one wave's worth when it is short, so that a small late-bounce
-  // queue still spreads over the whole chip
-  PT_DEV void init(uint32_t n, uint32_t wave_in_grid) {
-    const uint32_t waves = gridDim.x * TRACE_WAVES;
-    const uint32_t per_wave = n / (waves * 2u);                     // a short queue: one static and about one dynamic chunk per wave (a queue
-                                                                    // below 16.8 M rays used to be cut into 4 chunks per wave: 32 k atomics = 0.36 ms whatever its length)
-    chunk = per_wave >= TRACE_CHUNK ? TRACE_CHUNK : (per_wave < 64u ? 64u : (per_wave & ~63u));
-    dyn_base = waves * chunk;
-    const uint32_t first = wave_in_grid * chunk;                    // < 2^23
-    next = first < n ? first : 0u;
-    end = first < n ? (n - first > chunk ? first + chunk : n) : 0u;
-    exhausted = false;
+  uint32_t next, end, n_chunks, chunk, my_static; bool exhausted, static_left;
+  PT_DEV void init(const uint32_t* hdr, uint32_t wave_in_grid) {
+    chunk = hdr[1]; n_chunks = hdr[2];
+    my_static = wave_in_grid; static_left = wave_in_grid < n_chunks;
+    next = end = 0; exhausted = false;
   }
-  // nothing for any wave of this block: its static chunks lie behind the queue's end and the static round covers the queue
-  static PT_DEV bool block_has_no_work(uint32_t n) {
-    Reservoir r; r.init(n, blockIdx.x * TRACE_WAVES);
-    return r.dyn_base >= n && r.next >= r.end;
+  // nothing for any wave of this block: its static chunks lie behind the queue's end, and then so do all dynamic ones
+  static PT_DEV bool block_has_no_work(const uint32_t* hdr) { return hdr[2] <= blockIdx.x * TRACE_WAVES; }
+  // chunk number -> slots [next, end): 64-ary search of the chunk prefix for the segment, then the chunk's place inside it
+  PT_DEV void open_chunk(const DevQueues& q, const uint32_t* pre, const uint32_t* seg, uint32_t c, uint32_t lane) {
+    uint32_t lo = 0, span = q.n_seg;                       // the answer (largest s with pre[s] <= c) lies in [lo, lo + span)
+    while (span > 1u) {
+      const uint32_t step = (span + 63u) >> 6, idx = lo + lane * step;
+      const uint32_t v = lane * step < span ? pre[idx] : 0xffffffffu;
+      const uint32_t k = (uint32_t)__popcll(__ballot(v <= c)) - 1u;
+      lo += k * step;
+      span = span - k * step < step ? span - k * step : step;
+    }
+    const uint32_t first = pre[lo], cnt = seg[lo];
+    const uint32_t j = c - (uint32_t)__builtin_amdgcn_readfirstlane((int)first), live = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt);
+    lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+    next = lo * q.seg_len + j * chunk;
+    end = lo * q.seg_len + ((j + 1u) * chunk < live ? (j + 1u) * chunk : live);
   }
-  PT_DEV bool refill(uint32_t* ctr, uint32_t n, bool idle, uint32_t lane, uint32_t& ri) {
+  PT_DEV bool refill(const DevQueues& q, const uint32_t* pre, const uint32_t* seg, uint32_t* ctr, bool idle, uint32_t lane, uint32_t& ri) {
     const uint64_t mi = __ballot(idle);
     if (!mi) return false;
     if (next >= end && !exhausted) {
-      if (dyn_base >= n) exhausted = true;                          // the static round covered the queue: no atomic at all
+      if (static_left) { static_left = false; open_chunk(q, pre, seg, my_static, lane); }
       else {
-        const uint64_t base = (uint64_t)dyn_base + wave_fetch(ctr, chunk, lane);
-        if (base >= n) exhausted = true;
-        else { next = (uint32_t)base; end = (base + chunk < n) ? (uint32_t)base + chunk : n; }
+        const uint32_t waves = gridDim.x * TRACE_WAVES;
+        if (n_chunks <= waves) exhausted = true;                     // the static round covered the queue: no atomic at all
+        else {
+          const uint64_t c = (uint64_t)waves + wave_fetch(ctr, 1u, lane);
+          if (c >= n_chunks) exhausted = true; else open_chunk(q, pre, seg, (uint32_t)c, lane);
+        }
       }
     }
     const uint32_t avail = end - next;
@@ -347,8 +395,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_closest(
   __shared__ uint8_t s_pair[2][TRACE_WAVES][64];   // leaf phase: k-th owner with a second triangle <-> k-th free lane
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
-  const uint32_t n = q.cnt[CNT_RAYS];
-  if (Reservoir::block_has_no_work(n)) return;     // a short queue: most blocks of the persistent grid leave before staging anything
+  if (Reservoir::block_has_no_work(&q.cnt[CNT_RAY_TOTAL])) return;     // a short queue: most blocks of the persistent grid leave before staging anything
   const TraceLds L = trace_lds(lds_raw, sc, stack_lds);
   uint8_t* order_tab = L.order_tab;
   for (uint32_t i = threadIdx.x; i < sc.n_lds_units; i += TRACE_BLOCK) lds_raw[i] = sc.recs[i];
@@ -365,7 +412,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_closest(
 #else
 #define STAMP(acc) do { } while (0)
 #endif
-  Reservoir res; res.init(n, (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * TRACE_WAVES + wave)));
+  Reservoir res; res.init(&q.cnt[CNT_RAY_TOTAL], (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * TRACE_WAVES + wave)));
+  const uint32_t* seg_cnt = q.seg_ray[qi];
   WStack st;
   st.init(L.stack + (size_t)wave * (size_t)stack_lds * 64u + lane,
           sc.stack_ovf + ((size_t)(blockIdx.x * TRACE_WAVES + wave) * sc.ovf_depth) * 64u + lane, stack_lds);
@@ -377,7 +425,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_closest(
   bool found = false;
   for (;;) {
     // ---- refill idle lanes from the wave's reservoir ----
-    const bool got = res.refill(&q.cnt[CNT_WORK_TRACE], n, cur == CUR_DONE, lane, ri);
+    const bool got = res.refill(q, q.pre_ray, seg_cnt, &q.cnt[CNT_WORK_TRACE], cur == CUR_DONE, lane, ri);
     nr += (unsigned long long)__popcll(__ballot(got));
     if (got) {
       const float4 A = rq.A[ri], Bq = rq.B[ri];
@@ -506,14 +554,13 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_any(DevS
   __shared__ uint8_t s_pair[2][TRACE_WAVES][64];   // leaf phase: k-th owner with a second triangle <-> k-th free lane
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
-  const uint32_t n = q.cnt[CNT_SHADOW];
-  if (Reservoir::block_has_no_work(n)) return;
+  if (Reservoir::block_has_no_work(&q.cnt[CNT_SH_TOTAL])) return;
   const TraceLds L = trace_lds(lds_raw, sc, stack_lds);
   for (uint32_t i = threadIdx.x; i < sc.n_lds_units; i += TRACE_BLOCK) lds_raw[i] = sc.recs[i];
   __syncthreads();
   unsigned long long nv = 0, nr = 0;
   uint32_t nt = 0;
-  Reservoir res; res.init(n, (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * TRACE_WAVES + wave)));
+  Reservoir res; res.init(&q.cnt[CNT_SH_TOTAL], (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * TRACE_WAVES + wave)));
   WStack st;
   st.init(L.stack + (size_t)wave * (size_t)stack_lds * 64u + lane,
           sc.stack_ovf + ((size_t)(blockIdx.x * TRACE_WAVES + wave) * sc.ovf_depth) * 64u + lane, stack_lds);
@@ -523,7 +570,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_any(DevS
   float tmax = 0.0f;
   bool occluded = false;
   for (;;) {
-    const bool got = res.refill(&q.cnt[CNT_WORK_SHADOW], n, cur == CUR_DONE, lane, ri);
+    const bool got = res.refill(q, q.pre_sh, q.seg_sh, &q.cnt[CNT_WORK_SHADOW], cur == CUR_DONE, lane, ri);
     nr += (unsigned long long)__popcll(__ballot(got));
     if (got) {
       const float4 A = q.shadow.A[ri], Bq = q.shadow.B[ri];
@@ -715,24 +762,30 @@ PT_DEV v3 env_sample(const DevScene& sc, float r1, float r2) {
 }
 
 // =================================================================================================
-// P9 + P5–P8 shading.
-// Front end (P9): a 512-thread block takes a window of 512 consecutive (ray, hit) slots and sorts the
-// surviving paths by material class through LDS — per-wave ballot + mbcnt prefix, per-block prefix over
-// the 8 wave counts — so that waves are uniform in class (Lambert first, GGX after, class boundary
-// rounded up to a wave) and misses are dropped.
-// Middle (P5–P8): surface reconstruction, emission with MIS, next-event estimation, BSDF sampling,
-// Russian roulette.
-// Back end (P9): continuation and shadow rays are compacted into the output queues with the same
-// ballot/prefix scheme and ONE 64-bit atomic per block for both queues (atomics on one line are served one at a time, ≈11 ns
-// each: one per wave made the kernel 6× slower); the stores happen inside the next window's front end, when the atomic has returned.
-__global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene sc, DevFrame fr, DevQueues q, int qi, uint32_t b) {
-  __shared__ uint32_t s_cnt[4][SHADE_WAVES];     // per-wave counts: class0, class1, shadow, next
-  __shared__ uint32_t s_base[2];                 // block's base slots in the shadow / next queues
-  __shared__ uint16_t s_idx[SHADE_BLOCK];        // sorted local slot of each work item (0xffff = none)
-  // small scenes-wide tables staged once per block: emitter records + power cdf, materials
+// P9 + P5–P8 shading.  One WAVE owns one queue segment (ptc_internal.h, "SEGMENTED queues"): no block barrier and no atomic anywhere
+// in the loop, so the four waves a SIMD holds are four independent streams of loads and arithmetic (the round-2 kernel kept the
+// eight waves of a 512-thread block in lockstep at three barriers per window, which left a SIMD two independent streams: 55 % of its
+// wave-cycles waited for memory).
+// P9, material sort per wave: the wave reads the class words of the next 64 slots of its segment, and appends each slot to the ring
+// of its class in LDS (ballot + mbcnt prefix per class present); as soon as a ring holds 64 slots they are shaded as ONE batch, so every
+// batch but a segment's last few is uniform in class (Lambert / GGX / environment miss; 8 classes fit the hit word).  Misses without an
+// environment are dropped here.
+// P5–P8: surface reconstruction, emission with MIS, next-event estimation, BSDF sampling, Russian roulette.
+// P9, compaction: continuation rays and shadow rays of a batch go to the front of the wave's OWN segment of the output arrays (ballot +
+// mbcnt prefix behind a wave-private cursor): a wave never writes more records than it has read, so the segment cannot overflow.
+#define SHADE_RING 128            // slots a class ring holds: a batch is taken as soon as 64 are there, so at most 63 + 64 wait
+PT_DEV void wave_lds_sync() {     // LDS written by some lanes of this wave is read by others
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(const DevScene* __restrict__ scp, DevFrame fr, DevQueues q, int qi, uint32_t b) {
+  // small scene-wide tables staged once per block: emitter records + power cdf, materials
   __shared__ float4 s_light[SHADE_LDS_LIGHTS * 5];
   __shared__ float s_cdf[SHADE_LDS_LIGHTS];
   __shared__ float4 s_mat[SHADE_LDS_MATS * 3];
+  __shared__ uint32_t s_ring[SHADE_WAVES][PTC_MATERIAL_CLASSES][SHADE_RING];
+  const DevScene& sc = *scp;
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
   const bool lds_lights = sc.n_lights <= SHADE_LDS_LIGHTS, lds_mats = sc.n_mats <= SHADE_LDS_MATS;
@@ -743,6 +796,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene
   if (lds_mats)
     for (uint32_t i = threadIdx.x; i < sc.n_mats * 3u; i += SHADE_BLOCK) s_mat[i] = sc.mats[i];
   __syncthreads();
+  const uint32_t seg = blockIdx.x * SHADE_WAVES + wave;
+  if (seg >= q.n_seg) return;
   const float4* lights = lds_lights ? s_light : sc.lights;
   const float* cdf = lds_lights ? s_cdf : sc.cdf;
   const float4* mats = lds_mats ? s_mat : sc.mats;
@@ -750,71 +805,70 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene
   const bool has_env = sc.env_w > 0, env_nee = has_env && sc.env_ok != 0;
   const float p_env = env_nee ? (sc.n_lights > 0u ? 0.5f : 1.0f) : 0.0f, p_area = 1.0f - p_env;
   const RayQ rin = q.ray[qi], rout = q.ray[qi ^ 1];
-  const uint32_t n = q.cnt[CNT_RAYS];
-  const uint32_t n_windows = (n + SHADE_BLOCK - 1u) / SHADE_BLOCK;
-#ifdef PT_STAMP_SHADE   // wave-cycles per phase of a window (tools/stamp_shade.py)
-  unsigned long long t_front = 0, t_load = 0, t_math = 0, t_back = 0, t_store = 0, t_mark = __builtin_amdgcn_s_memtime();
+  const uint32_t base = seg * q.seg_len;                       // first slot of the segment, in every queue array
+  const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.seg_ray[qi][seg]);
+  typedef __attribute__((address_space(3))) volatile uint32_t lds_u32;
+  lds_u32* ring = (lds_u32*)&s_ring[wave][0][0];
+#ifdef PT_STAMP_SHADE   // wave-cycles per phase (tools/stamp_shade.py)
+  unsigned long long t_front = 0, t_load = 0, t_math = 0, t_back = 0, t_mark = __builtin_amdgcn_s_memtime();
 #define SSTAMP(acc) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - t_mark; t_mark = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #define SSTAMP_LOADS(acc) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SSTAMP(acc); } while (0)
 #else
 #define SSTAMP(acc) do { } while (0)
 #define SSTAMP_LOADS(acc) do { } while (0)
 #endif
-  // The back end of a window is finished inside the front end of the next one: the block's atomics on the two output counters
-  // are issued and left in flight, their result (the block's base slots) is published at the next window's first barrier, where the
-  // class words of that window — requested right behind the atomics — are awaited anyway, and the rays are stored after it.
-  bool alive = false, has_shadow = false;            // outputs of the window before
-  float4 oA, oB, oC;                                 // continuation ray
-  float4 sA, sB, sC;                                 // shadow ray
-  oA = oB = oC = sA = sB = sC = make_float4(0, 0, 0, 0);
-  uint32_t out_s = 0, out_a = 0;                     // their slots behind the block's bases
-  uint32_t base_s = 0, base_a = 0;                   // thread 0: the bases (atomic results, in flight)
-  auto publish_bases = [&]() { if (threadIdx.x == 0) { s_base[0] = base_s; s_base[1] = base_a; } };
-  auto store_outputs = [&]() {
-    if (has_shadow) { const uint32_t s = s_base[0] + out_s; q.shadow.A[s] = sA; q.shadow.B[s] = sB; q.shadow.C[s] = sC; }
-    if (alive) { const uint32_t s = s_base[1] + out_a; rout.A[s] = oA; rout.B[s] = oB; rout.C[s] = oC; }
-  };
-  for (uint32_t win = blockIdx.x; win < n_windows; win += gridDim.x) {
-    const uint32_t wbase = win * SHADE_BLOCK;
-    // ---- front end: class sort of the window ----
-    int cls = -1;
-    {
-      const uint32_t i = wbase + threadIdx.x;
-      if (i < n) {
-        const int pc = __float_as_int(q.hit[i].y);
-        if (pc >= 0) cls = (pc >> HIT_CLASS_SHIFT) & 1;
-        else if (has_env) cls = 2;                                       // a miss is shaded only when there is an environment
+  uint32_t out_a = 0, out_s = 0;          // wave cursors: continuation / shadow rays written so far
+  uint32_t fillv = 0;                     // lane c holds the number of slots waiting in ring c
+  uint32_t ready = 0, nonempty = 0;       // class masks: ring holds >= 64 / > 0 slots
+  uint32_t i0 = 0;
+  int w_pref = lane < n ? __float_as_int(q.hit[base + lane].y) : -1;    // class word of the group to be sorted next
+  for (;;) {
+    if (!ready) {
+      if (i0 < n) {
+        // ---- P9 front end: sort the next 64 slots into the class rings ----
+        const uint32_t i = i0 + lane;
+        int cls = -1;
+        if (i < n) cls = w_pref >= 0 ? ((w_pref >> HIT_CLASS_SHIFT) & (PTC_MATERIAL_CLASSES - 1)) : (has_env ? PTC_MATERIAL_CLASSES - 1 : -1);
+        i0 += 64u;
+        w_pref = i0 + lane < n ? __float_as_int(q.hit[base + i0 + lane].y) : -1;
+        uint64_t rem = __ballot(cls >= 0);
+        while (rem) {
+          const int c = __builtin_amdgcn_readlane(cls, __ffsll((unsigned long long)rem) - 1);
+          const uint64_t m = __ballot(cls == c);
+          uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)fillv, c);
+          if (cls == c) ring[(uint32_t)c * SHADE_RING + f + mbcnt64(m)] = i;
+          f += (uint32_t)__popcll(m);
+          if (lane == (uint32_t)c) fillv = f;
+          nonempty |= 1u << c;
+          if (f >= 64u) ready |= 1u << c;
+          rem &= ~m;
+        }
+        SSTAMP(t_front);
+        continue;
       }
+      if (!nonempty) break;
     }
-    const uint64_t m0 = __ballot(cls == 0), m1 = __ballot(cls >= 1);   // misses queue up behind the GGX group
-    if (lane == 0) { s_cnt[0][wave] = (uint32_t)__popcll(m0); s_cnt[1][wave] = (uint32_t)__popcll(m1); }
-    s_idx[threadIdx.x] = 0xffffu;
-    publish_bases();
-    __syncthreads();
-    uint32_t off0 = 0, off1 = 0, tot0 = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < SHADE_WAVES; ++w) {
-      const uint32_t a = s_cnt[0][w], b = s_cnt[1][w];
-      if (w < wave) { off0 += a; off1 += b; }
-      tot0 += a;
+    // ---- take a batch: 64 slots of one class, or what is left of a class at the end of the segment ----
+    const uint32_t c = (uint32_t)__builtin_ctz(ready ? ready : nonempty);
+    const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)fillv, (int)c);
+    const uint32_t take = f < 64u ? f : 64u, rest = f - take;
+    wave_lds_sync();
+    const bool valid = lane < take;
+    const uint32_t item = valid ? ring[c * SHADE_RING + lane] : 0u;
+    if (rest) {
+      const uint32_t mv = lane < rest ? ring[c * SHADE_RING + 64u + lane] : 0u;
+      wave_lds_sync();
+      if (lane < rest) ring[c * SHADE_RING + lane] = mv;
     }
-    const uint32_t start1 = (tot0 + 63u) & ~63u;                       // GGX group starts on a wave boundary
-    if (cls == 0) s_idx[off0 + mbcnt64(m0)] = (uint16_t)threadIdx.x;
-    else if (cls >= 1) {
-      // the padding may push the tail of the GGX group past the block: those (< 64) items fold back into
-      // the padding gap behind the Lambert group (only that one wave is then mixed)
-      uint32_t p = start1 + off1 + mbcnt64(m1);
-      if (p >= SHADE_BLOCK) p = tot0 + (p - SHADE_BLOCK);
-      s_idx[p] = (uint16_t)threadIdx.x;
-    }
-    store_outputs();                                 // of the window before (nothing on the first)
-    __syncthreads();
-    const uint32_t item = s_idx[threadIdx.x];
-    const bool valid = item != 0xffffu;
-    const uint32_t slot = wbase + (valid ? item : 0u);
+    if (lane == c) fillv = rest;
+    ready &= ~(1u << c);
+    if (!rest) nonempty &= ~(1u << c);
+    const uint32_t slot = base + item;
     SSTAMP(t_front);
 
-    alive = false; has_shadow = false;
+    bool alive = false, has_shadow = false;
+    float4 oA, oB, oC, sA, sB, sC;
+    oA = oB = oC = sA = sB = sC = make_float4(0, 0, 0, 0);
     if (valid) {
       const float4 A = rin.A[slot], Bq = rin.B[slot], Cq = rin.C[slot], H = q.hit[slot];
       const v3 d = V3(A.w, Bq.x, Bq.y);
@@ -844,11 +898,11 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene
       v3 ns = normalize3(ni);
       const int mat = __float_as_int(r0.w);
       const float4 M0 = mats[mat * 3 + 0], M1 = mats[mat * 3 + 1], M2 = mats[mat * 3 + 2];
-      float base[4] = {M0.x, M0.y, M0.z, M2.x};
+      float base_c[4] = {M0.x, M0.y, M0.z, M2.x};
       float metallic = M0.w, roughness = M1.w;
       const bool lambert = metallic == 0.0f && roughness >= 1.0f && __float_as_int(M2.w) < 0;
       if (__float_as_int(M2.y) >= 0 || __float_as_int(M2.z) >= 0 || __float_as_int(M2.w) >= 0)
-        apply_textures(sc, prim, hu, hv, hw, M2, ni, base, metallic, roughness, ns);
+        apply_textures(sc, prim, hu, hv, hw, M2, ni, base_c, metallic, roughness, ns);
       const v3 wo = -d;
       const bool front = dot3(ng, wo) > 0.0f;
       if (dot3(ns, ng) < 0.0f) ns = -ns;
@@ -870,7 +924,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene
         q.lpath[path] = L;
       }
       if ((int)b < fr.max_bounces) {
-        const bsdf_t bs = make_bsdf(V3(base[0], base[1], base[2]), metallic, roughness, lambert);
+        const bsdf_t bs = make_bsdf(V3(base_c[0], base_c[1], base_c[2]), metallic, roughness, lambert);
         v3 tx, ty; onb(ns, tx, ty);
         const v3 wol = V3(dot3(tx, wo), dot3(ty, wo), dot3(ns, wo));
         const float ps = spec_prob(bs, fmax2(wol.z, 1e-4f));
@@ -965,34 +1019,17 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(DevScene
       }   // hit
     }
     SSTAMP(t_math);
-    // ---- back end: compaction, ballot + mbcnt prefix per wave, LDS prefix per block, one atomic per queue ----
+    // ---- P9 back end: compaction into the wave's own segment of the output arrays ----
     const uint64_t ms = __ballot(has_shadow), ma = __ballot(alive);
-    if (lane == 0) { s_cnt[2][wave] = (uint32_t)__popcll(ms); s_cnt[3][wave] = (uint32_t)__popcll(ma); }
-    __syncthreads();
-    uint32_t offs = 0, offa = 0, tots = 0, tota = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < SHADE_WAVES; ++w) {
-      const uint32_t a = s_cnt[2][w], b = s_cnt[3][w];
-      if (w < wave) { offs += a; offa += b; }
-      tots += a; tota += b;
-    }
-    out_s = offs + mbcnt64(ms); out_a = offa + mbcnt64(ma);
-    if (threadIdx.x == 0) {
-      static_assert((CNT_NEXT & 1) == 0 && CNT_SHADOW == CNT_NEXT + 1, "k_shade adds to (next, shadow) as one 64-bit word");
-      if (tots | tota) {    // both queues with one atomic: (next, shadow) are the halves of an aligned 64-bit word
-        const unsigned long long r = atomicAdd(reinterpret_cast<unsigned long long*>(&q.cnt[CNT_NEXT]), (unsigned long long)tota | ((unsigned long long)tots << 32));
-        base_a = (uint32_t)r; base_s = (uint32_t)(r >> 32);
-      }
-    }
+    if (has_shadow) { const uint32_t o = base + out_s + mbcnt64(ms); q.shadow.A[o] = sA; q.shadow.B[o] = sB; q.shadow.C[o] = sC; }
+    if (alive) { const uint32_t o = base + out_a + mbcnt64(ma); rout.A[o] = oA; rout.B[o] = oB; rout.C[o] = oC; }
+    out_s += (uint32_t)__popcll(ms); out_a += (uint32_t)__popcll(ma);
     SSTAMP(t_back);
   }
-  publish_bases();
-  __syncthreads();
-  store_outputs();
-  SSTAMP(t_store);
+  if (lane == 0) { q.seg_ray[qi ^ 1][seg] = out_a; q.seg_sh[seg] = out_s; }
 #ifdef PT_STAMP_SHADE
   if (lane == 0) { atomicAdd(&q.stats[ST_DIAG_NODE_ITERS], t_front); atomicAdd(&q.stats[ST_DIAG_TRI_ITERS], t_load); atomicAdd(&q.stats[ST_DIAG_LEAF_VISITS], t_math);
-                   atomicAdd(&q.stats[ST_DIAG_ROUNDS], t_back); atomicAdd(&q.stats[ST_DIAG_REFILLED], t_store); }
+                   atomicAdd(&q.stats[ST_DIAG_ROUNDS], t_back); }
 #endif
 }
 
@@ -1139,8 +1176,14 @@ int pt_trace_blocks_per_cu(size_t lds) {
   return best;
 }
 
-void pt_launch_set_counts(hipStream_t s, const DevQueues& q, uint32_t n_rays, uint32_t n_shadow) { hipLaunchKernelGGL(k_set_counts, dim3(1), dim3(64), 0, s, q.cnt, n_rays, n_shadow); }
-void pt_launch_advance(hipStream_t s, const DevQueues& q) { hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, s, q.cnt); }
+static uint32_t trace_waves(const LaunchCfg& cfg) { return (uint32_t)(cfg.n_cu * cfg.trace_blocks_per_cu) * TRACE_WAVES; }
+void pt_launch_set_counts(hipStream_t s, const LaunchCfg& cfg, const DevQueues& q, uint32_t n_rays, uint32_t n_shadow) {
+  hipLaunchKernelGGL(k_set_counts, dim3(1), dim3(SCAN_BLOCK), 0, s, q, n_rays, n_shadow, trace_waves(cfg));
+}
+void pt_launch_scan(hipStream_t s, const LaunchCfg& cfg, const DevQueues& q, int qi_next) {
+  hipLaunchKernelGGL(k_scan, dim3(1), dim3(SCAN_BLOCK), 0, s, q, qi_next, trace_waves(cfg));
+}
+int pt_shade_block_threads() { return SHADE_BLOCK; }
 
 void pt_launch_raygen(hipStream_t s, const DevCamera& cam, const DevFrame& fr, const DevQueues& q, uint32_t first_sample, uint32_t n_samples, bool raster) {
   const uint32_t n_paths = fr.n_owned * n_samples;
@@ -1163,8 +1206,9 @@ void pt_launch_trace_any(hipStream_t s, const LaunchCfg& cfg, const DevScene& sc
   else hipLaunchKernelGGL(k_trace_any<false>, grid, dim3(TRACE_BLOCK), lds, s, sc, q, cfg.stack_lds, debug_out);
 }
 
-void pt_launch_shade(hipStream_t s, const LaunchCfg& cfg, const DevScene& sc, const DevFrame& fr, const DevQueues& q, int qi, uint32_t bounce) {
-  hipLaunchKernelGGL(k_shade, dim3((unsigned)(cfg.n_cu * SHADE_GRID)), dim3(SHADE_BLOCK), 0, s, sc, fr, q, qi, bounce);
+void pt_launch_shade(hipStream_t s, const LaunchCfg& cfg, const DevScene* sc, const DevFrame& fr, const DevQueues& q, int qi, uint32_t bounce) {
+  (void)cfg;
+  hipLaunchKernelGGL(k_shade, dim3((q.n_seg + SHADE_WAVES - 1u) / SHADE_WAVES), dim3(SHADE_BLOCK), 0, s, sc, fr, q, qi, bounce);   // one wave per segment
 }
 void pt_launch_accumulate(hipStream_t s, const DevFrame& fr, const DevQueues& q, float4* accum, uint32_t n_samples) {
   hipLaunchKernelGGL(k_accumulate, dim3((fr.n_owned + 255u) / 256u), dim3(256), 0, s, fr, (const float4*)q.lpath, accum, n_samples);

@@ -36,6 +36,7 @@ struct Lane {
   DevQueues q{};
   std::vector<void*> allocs;        // the large queue arrays (sized q.cap)
   uint2* stack_ovf = nullptr;       // traversal-stack overflow slab (belongs to the committed scene)
+  DevScene* d_scene = nullptr;      // this lane's DevScene in device memory (k_shade reads it through a pointer instead of ~200 B of kernel arguments)
   hipEvent_t acc_done = nullptr;    // "this lane's last accumulate finished"
 };
 
@@ -196,16 +197,17 @@ int ensure_lane_queues(ptc_ctx* c, uint32_t cap) {
     if (ln.q.cap >= cap) continue;
     free_all(ln.allocs);
     ln.q.cap = 0;
-    DevQueues q = ln.q;   // keeps cnt / stats
+    DevQueues q = ln.q;   // keeps cnt / stats / the per-segment arrays
     int rc = 0;
+    const size_t slots = ptc_seg_slots(cap, (uint32_t)c->cfg.shade_waves);   // segments are padded to multiples of 64 slots
     for (int k = 0; k < 2 && !rc; ++k) {
-      rc = dev_alloc(c, ln.allocs, &q.ray[k].A, cap); if (!rc) rc = dev_alloc(c, ln.allocs, &q.ray[k].B, cap);
-      if (!rc) rc = dev_alloc(c, ln.allocs, &q.ray[k].C, cap);
+      rc = dev_alloc(c, ln.allocs, &q.ray[k].A, slots); if (!rc) rc = dev_alloc(c, ln.allocs, &q.ray[k].B, slots);
+      if (!rc) rc = dev_alloc(c, ln.allocs, &q.ray[k].C, slots);
     }
-    if (!rc) rc = dev_alloc(c, ln.allocs, &q.shadow.A, cap);
-    if (!rc) rc = dev_alloc(c, ln.allocs, &q.shadow.B, cap);
-    if (!rc) rc = dev_alloc(c, ln.allocs, &q.shadow.C, cap);
-    if (!rc) rc = dev_alloc(c, ln.allocs, &q.hit, cap);
+    if (!rc) rc = dev_alloc(c, ln.allocs, &q.shadow.A, slots);
+    if (!rc) rc = dev_alloc(c, ln.allocs, &q.shadow.B, slots);
+    if (!rc) rc = dev_alloc(c, ln.allocs, &q.shadow.C, slots);
+    if (!rc) rc = dev_alloc(c, ln.allocs, &q.hit, slots);
     if (!rc) rc = dev_alloc(c, ln.allocs, &q.lpath, cap);
     if (rc) { free_all(ln.allocs); return rc; }
     q.cap = cap;
@@ -279,6 +281,12 @@ int configure_launch(ptc_ctx* c) {
 }
 
 DevScene lane_scene(ptc_ctx* c, int l) { DevScene d = c->dsc; d.stack_ovf = c->lanes[(size_t)l].stack_ovf; return d; }
+// the lane's queues with the segment layout of a batch of n slots (ptc_internal.h, "SEGMENTED queues")
+DevQueues batch_queues(ptc_ctx* c, int l, uint32_t n) {
+  DevQueues q = c->lanes[(size_t)l].q;
+  ptc_seg_layout(n, (uint32_t)c->cfg.shade_waves, q.n_seg, q.seg_len);
+  return q;
+}
 bool is_raster(int integrator) { return integrator == PTC_INTEGRATOR_RASTER_COMPAT || integrator == PTC_INTEGRATOR_RASTER_GBUFFER16; }
 
 // One wavefront batch of n samples per owned pixel on lane `l`, fully asynchronous.
@@ -286,14 +294,14 @@ int run_batch(ptc_ctx* c, int l, uint32_t first_sample, uint32_t n_samples) {
   const uint32_t n_paths = c->fr.n_owned * n_samples;
   Lane& ln = c->lanes[(size_t)l];
   hipStream_t st = ln.stream;
-  const DevQueues& q = ln.q;
+  const DevQueues q = batch_queues(c, l, n_paths);
   const DevScene sc = lane_scene(c, l);
   if (c->spans.size() > kMaxSpans) {      // bounded event pool: harvest what has completed; if the host runs far ahead of
     collect_times(c, false);              // the device, wait for the oldest batch (back-pressure) instead of growing
     if (c->spans.size() > kMaxSpans) { (void)hipEventSynchronize(c->spans[c->spans.size() - kMaxSpans].b); collect_times(c, false); }
   }
   ScopedSpan whole(c, st, 3);
-  pt_launch_set_counts(st, q, n_paths, 0);
+  pt_launch_set_counts(st, c->cfg, q, n_paths, 0);
   if (is_raster(c->integrator)) {
     pt_launch_raygen(st, c->cam, c->fr, q, 0, 1, true);
     { ScopedSpan t(c, st, 0); pt_launch_trace_closest(st, c->cfg, sc, q, 0, true); c->stats.launches_trace_closest++; }
@@ -302,11 +310,12 @@ int run_batch(ptc_ctx* c, int l, uint32_t first_sample, uint32_t n_samples) {
     pt_launch_raygen(st, c->cam, c->fr, q, first_sample, n_samples, false);
     for (int b = 0; b <= c->fr.max_bounces; ++b) {
       { ScopedSpan t(c, st, 0); pt_launch_trace_closest(st, c->cfg, sc, q, b & 1, false); c->stats.launches_trace_closest++; }
-      { ScopedSpan t(c, st, 2); pt_launch_shade(st, c->cfg, sc, c->fr, q, b & 1, (uint32_t)b); }
-      if (b < c->fr.max_bounces && (sc.n_lights > 0 || sc.env_ok)) {
+      { ScopedSpan t(c, st, 2); pt_launch_shade(st, c->cfg, ln.d_scene, c->fr, q, b & 1, (uint32_t)b); }
+      if (b == c->fr.max_bounces) break;                         // the last bounce's shade produces no rays
+      pt_launch_scan(st, c->cfg, q, (b + 1) & 1);
+      if (sc.n_lights > 0 || sc.env_ok) {
         ScopedSpan t(c, st, 1); pt_launch_trace_any(st, c->cfg, sc, q, nullptr); c->stats.launches_trace_any++;
       }
-      pt_launch_advance(st, q);
     }
     // sample-order accumulation: wait for the previous batch's accumulate (it ran on the previous lane)
     if (c->n_lanes > 1 && c->batches_issued > 0) {
@@ -431,6 +440,12 @@ ptc_ctx* ptc_create(int device_id) {
   c->cfg.n_cu = prop.multiProcessorCount;
   c->cfg.trace_blocks_per_cu = 4;
   c->cfg.stack_lds = 6;
+  {   // segments of a queue = waves of k_shade's grid: 16 per CU is what is resident at 4 waves per SIMD
+    int per_cu = 16;
+    if (const char* s = std::getenv("PTC_SEGMENTS_PER_CU")) { int v = std::atoi(s); if (v >= 1 && v <= 64) per_cu = v; }
+    uint32_t n = (uint32_t)(c->cfg.n_cu * per_cu);
+    c->cfg.shade_waves = (int)(n > PTC_MAX_SEGMENTS ? PTC_MAX_SEGMENTS : n);
+  }
   if (const char* s = std::getenv("PTC_NODELETS")) c->toplet_budget = (uint32_t)std::strtoul(s, nullptr, 10);
   if (const char* s = std::getenv("PTC_BATCH_PATHS")) { size_t v = std::strtoull(s, nullptr, 10); if (v >= 1024) c->max_batch_paths = v; }
   if (const char* s = std::getenv("PTC_TIMING")) c->timing = std::atoi(s) != 0;
@@ -442,6 +457,11 @@ ptc_ctx* ptc_create(int device_id) {
     ok = ok && hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ln.acc_done, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc((void**)&ln.q.cnt, CNT_N * sizeof(uint32_t)) == hipSuccess && hipMalloc((void**)&ln.q.stats, ST_N * sizeof(unsigned long long)) == hipSuccess;
     ok = ok && hipMemset(ln.q.cnt, 0, CNT_N * sizeof(uint32_t)) == hipSuccess && hipMemset(ln.q.stats, 0, ST_N * sizeof(unsigned long long)) == hipSuccess;
+    uint32_t* segs = nullptr;                                     // seg_ray[2], seg_sh, pre_ray, pre_sh: one allocation
+    const size_t per = PTC_MAX_SEGMENTS + 64;
+    ok = ok && hipMalloc((void**)&segs, 5 * per * sizeof(uint32_t)) == hipSuccess && hipMemset(segs, 0, 5 * per * sizeof(uint32_t)) == hipSuccess;
+    if (ok) { ln.q.seg_ray[0] = segs; ln.q.seg_ray[1] = segs + per; ln.q.seg_sh = segs + 2 * per; ln.q.pre_ray = segs + 3 * per; ln.q.pre_sh = segs + 4 * per; }
+    ok = ok && hipMalloc((void**)&ln.d_scene, sizeof(DevScene)) == hipSuccess;
   }
   if (!ok) { g_create_error = "ptc_create: could not create the lane streams / events / counters"; ptc_destroy(c); return nullptr; }
   return c;
@@ -460,6 +480,8 @@ void ptc_destroy(ptc_ctx* c) {
     free_all(ln.allocs);
     if (ln.q.cnt) (void)hipFree(ln.q.cnt);
     if (ln.q.stats) (void)hipFree(ln.q.stats);
+    if (ln.q.seg_ray[0]) (void)hipFree(ln.q.seg_ray[0]);
+    if (ln.d_scene) (void)hipFree(ln.d_scene);
     if (ln.stream) (void)hipStreamDestroy(ln.stream);
   }
   free_all(c->scene_allocs);
@@ -618,6 +640,10 @@ int ptc_scene_commit(ptc_ctx* c) {
   for (int k = 0; k < 3; ++k) { d.grid_lo[k] = B.grid_lo[k]; d.grid_step[k] = B.grid_step[k]; }
   c->dsc = d;
   { int rc2 = configure_launch(c); if (rc2) { free_all(c->scene_allocs); return rc2; } }
+  for (int l = 0; l < c->n_lanes; ++l) {
+    const DevScene ds = lane_scene(c, l);
+    HIP_TRY(c, hipMemcpy(c->lanes[(size_t)l].d_scene, &ds, sizeof ds, hipMemcpyHostToDevice));
+  }
   c->committed = true;
   std::memset(&c->stats, 0, sizeof c->stats);
   c->stats.seconds_commit = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -913,8 +939,9 @@ int ptc_debug_trace_closest(ptc_ctx* c, const float* origins, const float* dirs,
   }
   HIP_TRY(c, hipMemcpy(ln.q.ray[0].A, A.data(), n * sizeof(float4), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(ln.q.ray[0].B, B.data(), n * sizeof(float4), hipMemcpyHostToDevice));
-  pt_launch_set_counts(ln.stream, ln.q, n, 0);
-  pt_launch_trace_closest(ln.stream, c->cfg, lane_scene(c, 0), ln.q, 0, false);
+  const DevQueues q = batch_queues(c, 0, n);
+  pt_launch_set_counts(ln.stream, c->cfg, q, n, 0);
+  pt_launch_trace_closest(ln.stream, c->cfg, lane_scene(c, 0), q, 0, false);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipStreamSynchronize(ln.stream));
   std::vector<float4> H(n);
@@ -940,8 +967,9 @@ int ptc_debug_trace_any(ptc_ctx* c, const float* origins, const float* dirs, con
   HIP_TRY(c, hipMemcpy(ln.q.shadow.B, B.data(), n * sizeof(float4), hipMemcpyHostToDevice));
   uint8_t* d_out = nullptr;
   HIP_TRY(c, hipMalloc((void**)&d_out, n));
-  pt_launch_set_counts(ln.stream, ln.q, 0, n);
-  pt_launch_trace_any(ln.stream, c->cfg, lane_scene(c, 0), ln.q, d_out);
+  const DevQueues q = batch_queues(c, 0, n);
+  pt_launch_set_counts(ln.stream, c->cfg, q, 0, n);
+  pt_launch_trace_any(ln.stream, c->cfg, lane_scene(c, 0), q, d_out);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(ln.stream);
   if (e == hipSuccess) e = hipMemcpy(out_occluded, d_out, n, hipMemcpyDeviceToHost);

@@ -49,39 +49,65 @@ struct DevFrame {
 //   raster/debug rays reuse B.zw as (tmin,tmax)
 // hit record   : H=(t,prim,u,v)                                                            (16 B)
 // shadow record: A=(o.xyz,d.x) B=(d.y,d.z,tmax,path_id) C=(contrib.rgb,-)                  (48 B)
+//
+// SEGMENTED queues (round 3).  A queue of a batch is cut into `n_seg` segments of `seg_len` slots (a multiple of 64): segment s owns
+// the slots [s*seg_len, (s+1)*seg_len) of every queue array and holds seg_*[s] live records packed at its front.  k_raygen fills the
+// segments back to back (slot = path id), and ONE WAVE of k_shade owns one segment: it reads the segment's rays and writes the
+// continuation rays and the shadow rays it produces to the front of the SAME segment of the output arrays, so output compaction needs
+// no atomic and no block barrier (a wave never produces more records than it consumes).  The trace kernels balance their load over
+// chunks of <= 512 rays that never straddle a segment: k_scan turns the per-segment counts into a prefix sum of chunks per segment
+// (pre_*), and a trace wave maps a chunk number to (segment, offset) by a 64-ary search of that prefix.
 struct RayQ { float4* A; float4* B; float4* C; };   // 48 B per ray; the bounce index is a launch constant, not a field
 struct ShadowQ { float4* A; float4* B; float4* C; };
 
 struct DevQueues {
-  RayQ ray[2];     // ping-pong: bounce b reads ray[b&1] (compact [0, cnt[CNT_RAYS])), shade writes ray[(b+1)&1]
-  ShadowQ shadow;  // compact [0, cnt[CNT_SHADOW])
+  RayQ ray[2];     // ping-pong: bounce b reads ray[b&1], shade writes ray[(b+1)&1]
+  ShadowQ shadow;
   float4* hit;     // hit record of ray slot i, written in place by k_trace_closest: (t, prim | class<<28, u, v)
   float4* lpath;   // per-path radiance (rgb,-), single owner
-  uint32_t* cnt;   // device counters, see CNT_*
+  uint32_t* cnt;   // header words and the two work counters of the trace kernels, see CNT_*
+  uint32_t* seg_ray[2];   // live rays per segment of ray[k]
+  uint32_t* seg_sh;       // live shadow rays per segment
+  uint32_t* pre_ray;      // [n_seg + 1] exclusive prefix of chunks per segment of the CURRENT ray queue
+  uint32_t* pre_sh;       // the same for the shadow queue
   unsigned long long* stats;  // device statistics, see ST_*
-  uint32_t cap;    // queue capacity (paths per batch)
+  uint32_t cap;    // queue capacity in paths (the arrays hold ptc_seg_slots(cap) slots)
+  uint32_t n_seg, seg_len;   // segment layout of the batch in flight (host-chosen per batch: ptc_seg_layout)
 };
 
-// Device counters of a lane.  Atomics on one 128-byte line are served one at a time (≈11 ns each), so every counter that takes
-// atomics has a line of its own, and k_shade's two output counters are the halves of ONE aligned 64-bit word (one atomic per
-// window for both queues): k_shade −6 % against six adjacent words.
-enum { CNT_RAYS = 0, CNT_NEXT = 32, CNT_SHADOW = 33, CNT_WORK_TRACE = 96, CNT_WORK_SHADE = 128, CNT_WORK_SHADOW = 160, CNT_N = 192 };
+// Header words in `cnt` (written by k_set_counts / k_scan, read by the trace kernels) and the two work counters, each of which takes
+// atomics and therefore has a 128-byte line of its own (atomics on one line are served one at a time, ~11 ns each).
+enum { CNT_RAY_TOTAL = 0, CNT_RAY_CHUNK, CNT_RAY_NCHUNKS, CNT_SH_TOTAL, CNT_SH_CHUNK, CNT_SH_NCHUNKS, CNT_WORK_TRACE = 32, CNT_WORK_SHADOW = 64, CNT_N = 96 };
+#define PTC_MAX_SEGMENTS 16384u     // upper bound of n_seg (sizes the per-segment arrays)
+#define PTC_MATERIAL_CLASSES 8      // classes a hit word can carry (3 bits above the 28-bit primitive id); class 7 = miss under an environment
 enum { ST_SEGMENTS = 0, ST_SHADOW, ST_HITS, ST_NODES_C, ST_TRIS_C, ST_NODES_A, ST_TRIS_A,
        // wave-level iteration counts of the trace kernels' loops (filled only by a -DPT_DIAG build): lane
        // utilisation of a phase = lane-level count / (64 x wave-level count)
        ST_DIAG_NODE_ITERS, ST_DIAG_TRI_ITERS, ST_DIAG_LEAF_VISITS, ST_DIAG_ROUNDS, ST_DIAG_REFILLED, ST_N };
 
-struct LaunchCfg { int n_cu; int trace_blocks_per_cu; int stack_lds; /* stack entries kept in LDS per lane */ };
+// Segment layout of a batch of n slots over at most max_seg segments: n_seg = min(max_seg, ceil(n / 64)) (at least 1), seg_len =
+// ceil(n / n_seg) rounded up to a multiple of 64.  n_seg * seg_len <= ptc_seg_slots(n, max_seg).
+inline void ptc_seg_layout(uint32_t n, uint32_t max_seg, uint32_t& n_seg, uint32_t& seg_len) {
+  uint32_t s = (n + 63u) / 64u;
+  if (s > max_seg) s = max_seg;
+  if (s < 1u) s = 1u;
+  const uint32_t per = (n + s - 1u) / s;
+  n_seg = s; seg_len = per ? ((per + 63u) & ~63u) : 64u;
+}
+inline size_t ptc_seg_slots(uint32_t cap, uint32_t max_seg) { return (size_t)cap + 64u * (size_t)max_seg + 64u; }
+
+struct LaunchCfg { int n_cu; int trace_blocks_per_cu; int stack_lds; /* stack entries kept in LDS per lane */ int shade_waves; /* waves of k_shade's grid = upper bound of n_seg */ };
 
 // ---- kernel launchers (pt_kernels.hip) ------------------------------------------------------------
 int pt_trace_block_threads();   // threads per block of the trace kernels (compile-time constant of pt_kernels.hip)
 size_t pt_trace_lds_bytes(const LaunchCfg&, const DevScene&);   // dynamic LDS of a trace block (the larger, closest-hit, figure)
 int pt_trace_blocks_per_cu(size_t lds_bytes);                    // resident trace blocks per CU at that LDS size (runtime occupancy query)
-void pt_launch_set_counts(hipStream_t, const DevQueues&, uint32_t n_rays, uint32_t n_shadow);
-void pt_launch_advance(hipStream_t, const DevQueues&);
+void pt_launch_set_counts(hipStream_t, const LaunchCfg&, const DevQueues&, uint32_t n_rays, uint32_t n_shadow);   // identity layout: ray i at slot i
+void pt_launch_scan(hipStream_t, const LaunchCfg&, const DevQueues&, int qi_next);   // after k_shade: chunk prefixes of the rays it wrote to ray[qi_next] and of its shadow rays
+int pt_shade_block_threads();
 void pt_launch_raygen(hipStream_t, const DevCamera&, const DevFrame&, const DevQueues&, uint32_t first_sample, uint32_t n_samples, bool raster);
 void pt_launch_trace_closest(hipStream_t, const LaunchCfg&, const DevScene&, const DevQueues&, int qi, bool cull);
-void pt_launch_shade(hipStream_t, const LaunchCfg&, const DevScene&, const DevFrame&, const DevQueues&, int qi, uint32_t bounce);   // every ray of a wavefront launch is at the same bounce
+void pt_launch_shade(hipStream_t, const LaunchCfg&, const DevScene* scene_on_device, const DevFrame&, const DevQueues&, int qi, uint32_t bounce);   // every ray of a wavefront launch is at the same bounce
 void pt_launch_trace_any(hipStream_t, const LaunchCfg&, const DevScene&, const DevQueues&, uint8_t* debug_out /*or null*/);
 void pt_launch_accumulate(hipStream_t, const DevFrame&, const DevQueues&, float4* accum, uint32_t n_samples);
 void pt_launch_shade_raster(hipStream_t, const DevScene&, const DevCamera&, const DevFrame&, const DevQueues&, float4* accum, bool gbuffer16);
