@@ -218,62 +218,13 @@ PT_DEV void build_order_table(uint8_t* tab) {
 // axis is entered first, so near/far need no min/max (identical values to min(t0,t1) / max(t0,t1): fma is monotonic in
 // the plane coordinate).  plane distance = fma(q, 2^(e-127)·inv, fma(org, inv, -ood)), org = fma(oq, grid_step, grid_lo).
 //
-// Which instructions (round 3, tools/valu_mix_bench.hip -> profiles/r03_valu_mix.json).  A SIMD of gfx950 issues v_fma / v_mul / v_add /
-// v_sub / v_mov and the plain integer and / or / xor / add / sub in 2 cycles per wave64 instruction, and EVERYTHING ELSE — conversions,
-// min / max, compares, v_cndmask, shifts, bit-field and SDWA forms, v_fma_mix — in 4, and the two kinds overlap: a stream of 12 "slow"
-// and 6 "fast" instructions (the round-2 slot test: 6 v_cvt_f32_ubyte, 6 fma, 4 min/max, v_cmp + v_addc) takes the 48 cycles of its slow
-// ones.  So the visit is written to need few slow instructions, at the price of more fast ones:
-//  * NV_HITFAST: the hit bit of a slot is the sign of tf - tn (a correctly rounded difference has the sign of the exact one, and is -0 never),
-//    copied onto 1.0 with and / or and accumulated as +-2^slot by an fma; one conversion at the end gives the mask (4 fast instead of 2 slow);
-//  * NV_FASTCONV: the bytes at positions 0 and 1 of a word become floats without a conversion instruction: (w & 0xff) | 0x4b000000 is the
-//    float 2^23 + q, and 2^23 is subtracted exactly; byte 1 gives 256 q the same way and meets a scale divided by 256 (3 fast instead of 1 slow).
-// Both give the same bits as the plain form: every product and sum is the same real number, rounded once in the same fma.
-#ifndef NV_HITFAST
-#define NV_HITFAST 1
-#endif
-#ifndef NV_FASTCONV
-#define NV_FASTCONV 1
-#endif
-PT_DEV float byte0_as_float(uint32_t w) {          // (float)(w & 255), by v_and + v_or + v_sub
-  uint32_t r;
-  asm("v_and_b32 %0, 0xff, %1\n\tv_or_b32 %0, 0x4b000000, %0" : "=v"(r) : "v"(w));
-  return __uint_as_float(r) - 8388608.0f;
-}
-PT_DEV float byte1_times_256_as_float(uint32_t w) { // 256 * (float)((w >> 8) & 255)
-  uint32_t r;
-  asm("v_and_b32 %0, 0xff00, %1\n\tv_or_b32 %0, 0x4b000000, %0" : "=v"(r) : "v"(w));
-  return __uint_as_float(r) - 8388608.0f;
-}
-PT_DEV float sign_as_one(float d) {                 // +1.0 for d >= +0, -1.0 for d < 0 (and for -0, which a difference of finite floats never is)
-  uint32_t r;
-  asm("v_and_b32 %0, 0x80000000, %1\n\tv_or_b32 %0, 1.0, %0" : "=v"(r) : "v"(d));
-  return __uint_as_float(r);
-}
-template <int I> PT_DEV float plane_dist(uint32_t w, float a, float a256, float b) {
-#if NV_FASTCONV
-  if (I == 0) return pt_fma(byte0_as_float(w), a, b);
-  if (I == 1) return pt_fma(byte1_times_256_as_float(w), a256, b);
-#endif
-  (void)a256;
-  return pt_fma(ubyte_f(w, I), a, b);
-}
-struct SlabRay { float ax, ay, az, ax256, ay256, az256, bx, by, bz; };
-template <int I> PT_DEV void slot_test(const SlabRay& k, uint32_t nqx, uint32_t nqy, uint32_t nqz, uint32_t fqx, uint32_t fqy, uint32_t fqz, float tmin, float tlimit,
-                                       int slot, uint32_t& hits, float& hacc) {
-  const float tn = hw_max(hw_max(hw_max(plane_dist<I>(nqx, k.ax, k.ax256, k.bx), plane_dist<I>(nqy, k.ay, k.ay256, k.by)), plane_dist<I>(nqz, k.az, k.az256, k.bz)), tmin);
-  const float tf = hw_min(hw_min(hw_min(plane_dist<I>(fqx, k.ax, k.ax256, k.bx), plane_dist<I>(fqy, k.ay, k.ay256, k.by)), plane_dist<I>(fqz, k.az, k.az256, k.bz)), tlimit);
-#if NV_HITFAST
-  (void)hits;
-  hacc = pt_fma(sign_as_one(tf - tn), (float)(1u << slot), hacc);
-#else
-  (void)hacc; (void)slot;
-#ifndef PT_NO_ADDC
-  asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hits) : "v"(tn), "v"(tf) : "vcc");   // hits = 2·hits + (tn <= tf)
-#else
-  hits = hits + hits + (tn <= tf ? 1u : 0u);
-#endif
-#endif
-}
+// Instruction economy (round 3, tools/valu_mix_bench.hip -> profiles/r03_valu_mix.json): on gfx950 a stream of v_fma / v_mul / v_add /
+// v_mov or plain integer and / or / add issues one wave64 instruction per 2 cycles and SIMD, a stream of anything else (conversions, min /
+// max, compares, v_cndmask, shifts, SDWA forms, v_fma_mix) one per 4; mixed, every instruction costs about one 2-cycle slot and the
+// 4-cycle kinds bind only where they run back to back.  The slot test below — 6 v_cvt_f32_ubyte, 6 fma, 4 min/max, v_cmp + v_addc — takes
+// the time of its 12 four-cycle instructions and of its 18 issue slots alike, so trading slow instructions for more fast ones loses: the
+// hit mask from the sign of tf - tn by and / or / fma (4 fast for 2 slow) -1 %, bytes 0 and 1 converted by and / or / sub (3 fast for 1 slow)
+// -4 %, both -5 % (commit c436d48, profiles/r03_node_visit_variants.txt).
 PT_DEV uint32_t node_visit(const DevScene& sc, uint32_t node_addr, int cur, const ray_t& r, uint32_t oct, float tmin, float tlimit,
                            uint32_t& block, uint32_t& masks) {
   typedef float fx4 __attribute__((ext_vector_type(4)));
@@ -290,34 +241,33 @@ PT_DEV uint32_t node_visit(const DevScene& sc, uint32_t node_addr, int cur, cons
   const uint32_t w0 = __float_as_uint(f0.x), w1 = __float_as_uint(f0.y), w2 = __float_as_uint(f0.z);
   const float ox = pt_fma((float)(w0 & 0xffffu), sc.grid_step[0], sc.grid_lo[0]), oy = pt_fma((float)(w0 >> 16), sc.grid_step[1], sc.grid_lo[1]),
               oz = pt_fma((float)(w1 & 0xffffu), sc.grid_step[2], sc.grid_lo[2]);
-  SlabRay k;
-  k.ax = __uint_as_float(((w1 >> 16) & 255u) << 23) * r.inv.x; k.ay = __uint_as_float((w1 >> 24) << 23) * r.inv.y;
-  k.az = __uint_as_float((w2 & 255u) << 23) * r.inv.z;
-  k.ax256 = k.ax * 0.00390625f; k.ay256 = k.ay * 0.00390625f; k.az256 = k.az * 0.00390625f;
+  const float ax = __uint_as_float(((w1 >> 16) & 255u) << 23) * r.inv.x, ay = __uint_as_float((w1 >> 24) << 23) * r.inv.y,
+              az = __uint_as_float((w2 & 255u) << 23) * r.inv.z;
   // o·inv is recomputed here (the same product make_ray forms) instead of living in three registers for the ray's lifetime:
   // that is what keeps the kernel within the 64 VGPRs of 8 waves per SIMD without spilling
-  k.bx = pt_fma(ox, r.inv.x, -(r.o.x * r.inv.x)); k.by = pt_fma(oy, r.inv.y, -(r.o.y * r.inv.y)); k.bz = pt_fma(oz, r.inv.z, -(r.o.z * r.inv.z));
+  const float bx = pt_fma(ox, r.inv.x, -(r.o.x * r.inv.x)), by = pt_fma(oy, r.inv.y, -(r.o.y * r.inv.y)), bz = pt_fma(oz, r.inv.z, -(r.o.z * r.inv.z));
   const bool px = (oct & 1u) != 0u, py = (oct & 2u) != 0u, pz = (oct & 4u) != 0u;
   // [0]: slots 0-3, [1]: slots 4-7
   const uint32_t lx[2] = {__float_as_uint(f1.x), __float_as_uint(f1.y)}, ly[2] = {__float_as_uint(f1.z), __float_as_uint(f1.w)},
                  lz[2] = {__float_as_uint(f2.x), __float_as_uint(f2.y)}, hx[2] = {__float_as_uint(f2.z), __float_as_uint(f2.w)},
                  hy[2] = {__float_as_uint(f3.x), __float_as_uint(f3.y)}, hz[2] = {__float_as_uint(f3.z), __float_as_uint(f3.w)};
   uint32_t hits = 0;
-  float hacc = 0.0f;
 #pragma unroll
   for (int h = 1; h >= 0; --h) {
     const uint32_t nqx = px ? lx[h] : hx[h], fqx = px ? hx[h] : lx[h];
     const uint32_t nqy = py ? ly[h] : hy[h], fqy = py ? hy[h] : ly[h];
     const uint32_t nqz = pz ? lz[h] : hz[h], fqz = pz ? hz[h] : lz[h];
-    // slot 4h+i; descending, so that (without NV_HITFAST) shifting the results in leaves slot s in bit s
-    slot_test<3>(k, nqx, nqy, nqz, fqx, fqy, fqz, tmin, tlimit, 4 * h + 3, hits, hacc);
-    slot_test<2>(k, nqx, nqy, nqz, fqx, fqy, fqz, tmin, tlimit, 4 * h + 2, hits, hacc);
-    slot_test<1>(k, nqx, nqy, nqz, fqx, fqy, fqz, tmin, tlimit, 4 * h + 1, hits, hacc);
-    slot_test<0>(k, nqx, nqy, nqz, fqx, fqy, fqz, tmin, tlimit, 4 * h + 0, hits, hacc);
-  }
-#if NV_HITFAST
-  hits = (uint32_t)((int)hacc + 255) >> 1;      // sum of +-2^s over the 8 slots -> bit s set where the sign was +
+#pragma unroll
+    for (int i = 3; i >= 0; --i) {      // slot 4h+i; descending, so that shifting the results in leaves slot s in bit s
+      const float tn = hw_max(hw_max(hw_max(pt_fma(ubyte_f(nqx, i), ax, bx), pt_fma(ubyte_f(nqy, i), ay, by)), pt_fma(ubyte_f(nqz, i), az, bz)), tmin);
+      const float tf = hw_min(hw_min(hw_min(pt_fma(ubyte_f(fqx, i), ax, bx), pt_fma(ubyte_f(fqy, i), ay, by)), pt_fma(ubyte_f(fqz, i), az, bz)), tlimit);
+#ifndef PT_NO_ADDC
+      asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hits) : "v"(tn), "v"(tf) : "vcc");   // hits = 2·hits + (tn <= tf)
+#else
+      hits = hits + hits + (tn <= tf ? 1u : 0u);
 #endif
+    }
+  }
   masks = w2 >> 8;
   block = __float_as_uint(f0.w);
   return hits & ((masks | (masks >> 8)) & 255u);
