@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
                     help="N > 1: strong (default) = the metric's fixed 1024-spp frame, a rank traces 1/N of the pixels; weak = every step adds spp-per-step x N samples")
+    ap.add_argument("--rehearse-tiles", type=int, default=0,
+                    help="N = 1 only: render tile rank 0 of this many (what ONE rank of an N-GPU strong-scaling run does, without the reduce); the JSON "
+                         "line's value is then that rank's share, not the metric")
     ap.add_argument("--reduce", choices=["cabi", "torch"], default="cabi",
                     help="N > 1: cabi = ncclReduce through the C-ABI (ptc_comm_*), the id shipped over torch.distributed; torch = torch.distributed.reduce on the zero-copy tensor")
     args = ap.parse_args()
@@ -124,15 +127,27 @@ def main():
 
         from pbr_amd import gltf
 
-        with tempfile.TemporaryDirectory() as td:
-            glb = os.path.join(td, f"bench_rank{rank}.glb")
-            gltf.write_glb(desc, glb)
-            n_tri, _, _ = gltf.load_into(pt, glb, camera=desc.camera, env=getattr(desc, "env", None))
-            assert n_tri == desc.n_triangles, (n_tri, desc.n_triangles)
-            scene_source = f"binary glTF ({os.path.getsize(glb) / 1e6:.1f} MB) written from the generator, loaded by ptc_gltf_load"
+        # rank 0 writes the file once; every rank (one process per GPU) loads it through the library's own loader
+        box = [None]
+        td = None
+        if rank == 0:
+            td = tempfile.TemporaryDirectory()
+            box[0] = os.path.join(td.name, "bench_scene.glb")
+            gltf.write_glb(desc, box[0])
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        glb = box[0]
+        n_tri, _, _ = gltf.load_into(pt, glb, camera=desc.camera, env=getattr(desc, "env", None))
+        assert n_tri == desc.n_triangles, (n_tri, desc.n_triangles)
+        scene_source = f"binary glTF ({os.path.getsize(glb) / 1e6:.1f} MB) written from the generator by rank 0, loaded by ptc_gltf_load"
+        if world > 1:
+            dist.barrier()              # nobody is still reading when rank 0 removes the file
+        if td is not None:
+            td.cleanup()
     K, W, S = args.steps, args.warmup, args.spp_per_step * (world if args.scaling == "weak" else 1)
     spp_total = (K + W) * S
-    pt.frame_begin(args.width, args.height, spp_total, args.seed, args.max_bounces, pbr_amd.INTEGRATOR_PATH, tile_rank=rank, tile_count=world)
+    tile_count = world if world > 1 else max(1, args.rehearse_tiles)
+    pt.frame_begin(args.width, args.height, spp_total, args.seed, args.max_bounces, pbr_amd.INTEGRATOR_PATH, tile_rank=rank, tile_count=tile_count)
     pt.frame_reserve()          # queues for full batches now: no allocation (and no drain of the device for one) inside the timed region
     reduce_impl = None
     if world > 1:
@@ -210,12 +225,35 @@ def main():
         dist.all_reduce(v, op=dist.ReduceOp.SUM)
         tot = {k: float(x) for k, x in zip(keys, v.tolist())}
 
+    # per-rank times, so that a poor scaling point can be attributed: tile imbalance (spread of the kernel sums), the collective
+    # (reduce_ms: the collective as each rank's stream sees it, i.e. including the wait for the slowest rank) or launch tails
+    per_rank = None
+    if world > 1:
+        mine = torch.tensor([d["seconds_trace_closest"], d["seconds_trace_any"], d["seconds_shade"], t1 - t0, d.get("seconds_reduce", 0.0), float(d["paths"])],
+                            dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rows = [[float(x) for x in r.tolist()] for r in allr]
+        names = ["seconds_trace_closest", "seconds_trace_any", "seconds_shade", "wall", "seconds_reduce", "paths"]
+        per_rank = {n: {"min": min(r[i] for r in rows), "max": max(r[i] for r in rows), "ranks": [r[i] for r in rows]} for i, n in enumerate(names)}
+        per_rank["reduce_ms"] = {"min": per_rank["seconds_reduce"]["min"] * 1e3, "max": per_rank["seconds_reduce"]["max"] * 1e3}
+
     if rank == 0:
         paths = args.width * args.height * S * K
-        assert abs(tot["paths"] - paths) < 0.5, (tot["paths"], paths)
+        if tile_count == world:
+            assert abs(tot["paths"] - paths) < 0.5, (tot["paths"], paths)
+        else:
+            paths = int(tot["paths"])       # a rehearsal of one rank's share
         # Rooflines of the three kernels that carry the frame, on this rank.  Units are counted by the kernels; the
         # per-unit instruction and HBM-byte figures come from the committed PMC profile of the same workload.
-        model = _load_json(os.path.join(ROOT, "profiles", "r02_kernel_model.json" if args.workload == "atrium" else "r02_textured_kernel_model.json")) or {}
+        model_name = "kernel_model.json" if args.workload == "atrium" else "textured_kernel_model.json"
+        model_path = next((p for p in (os.path.join(ROOT, "profiles", f"r{r:02d}_{model_name}") for r in (3, 2)) if os.path.exists(p)), None)
+        model = (_load_json(model_path) if model_path else None) or {}
+        # The per-unit figures are only as good as the kernels they were measured on: the library carries the sha256 of the kernel sources
+        # it was built from (ptc_build_info), the model the sha256 of the sources that were profiled.  A mismatch is reported, not hidden.
+        build_info = pbr_amd.load_library().ptc_build_info().decode()
+        lib_sha = build_info.rsplit(" ", 1)[-1]
+        model_stale = not model or model.get("kernel_source_sha256") != lib_sha
         valu = _load_json(os.path.join(ROOT, "profiles", "r02_valu_issue.json")) or {}
         ns_per_instr = valu.get("ns_per_instr_per_simd_at_7_waves")
         valu_peak_measured = N_SIMD / ns_per_instr if ns_per_instr else None          # G wave-instr/s
@@ -229,9 +267,13 @@ def main():
             e = {"unit_counted": ukey, "units_per_launch": n_units / nl, "avg_launch_ms": sec / nl * 1e3, "launches": nl}
             if m.get("valu_winstr_per_unit") and sec > 0:
                 gips = n_units * m["valu_winstr_per_unit"] / sec / 1e9
-                e["valu_issue"] = {"achieved": gips, "unit": "G wave-instr/s", "peak": valu_peak_measured or VALU_PEAK_PAPER_GIPS,
-                                   "peak_kind": "measured all-fma stream, 7 waves/SIMD" if valu_peak_measured else "paper: 1024 SIMD x 2.4 GHz / 2 cycles",
-                                   "frac": gips / (valu_peak_measured or VALU_PEAK_PAPER_GIPS), "frac_of_paper_peak": gips / VALU_PEAK_PAPER_GIPS}
+                e["valu_issue"] = {"achieved": gips, "unit": "G wave-instr/s", "peak": VALU_PEAK_PAPER_GIPS,
+                                   "peak_kind": "MI355X_MICROARCH.md: 1024 SIMD x 2.4 GHz / 2 cycles per wave64 instruction",
+                                   "frac": gips / VALU_PEAK_PAPER_GIPS,
+                                   "measured_ceiling": valu_peak_measured, "measured_ceiling_kind": "all-v_fma_f32 stream, 7 waves/SIMD (clocks down under power: profiles/r02_valu_issue.json)",
+                                   "frac_of_measured_ceiling": gips / valu_peak_measured if valu_peak_measured else None,
+                                   # issue slots used per SIMD cycle in the profiled run: SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)
+                                   "issue_duty_per_cycle": m.get("valu_issue_duty_per_cycle")}
             if m.get("hbm_bytes_per_unit") and sec > 0:
                 gbs = n_units * m["hbm_bytes_per_unit"] / sec / 1e9
                 e["hbm"] = {"achieved": gbs, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
@@ -242,7 +284,7 @@ def main():
                 excl_ms = m["serialised_ms_per_launch"] * (n_units / nl) / m["serialised_units_per_launch"]
                 e["exclusive_launch_ms_from_profile"] = excl_ms
                 if "valu_issue" in e:
-                    e["valu_issue"]["frac_exclusive"] = n_units / nl * m["valu_winstr_per_unit"] / (excl_ms * 1e-3) / 1e9 / e["valu_issue"]["peak"]
+                    e["valu_issue"]["frac_exclusive"] = n_units / nl * m["valu_winstr_per_unit"] / (excl_ms * 1e-3) / 1e9 / VALU_PEAK_PAPER_GIPS
                 if "hbm" in e:
                     e["hbm"]["frac_exclusive"] = n_units / nl * m["hbm_bytes_per_unit"] / (excl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             kernels[kname] = e
@@ -250,8 +292,8 @@ def main():
         if all("valu_issue" in kernels[k] and "hbm" in kernels[k] for k in kernels):
             winstr = sum(float(d[units[k][0]]) * model[k]["valu_winstr_per_unit"] for k in kernels)
             hbm_b = sum(float(d[units[k][0]]) * model[k]["hbm_bytes_per_unit"] for k in kernels)
-            pk = valu_peak_measured or VALU_PEAK_PAPER_GIPS
-            whole = {"note": "the three kernels together over the timed wall time",
+            pk = VALU_PEAK_PAPER_GIPS
+            whole = {"note": "the three kernels together over the timed wall time; fractions against the guide's peaks (1228.8 G wave-instr/s, 8 TB/s)",
                      "valu_issue_G_winstr_s": winstr / dt / 1e9, "valu_issue_frac": winstr / dt / 1e9 / pk,
                      "hbm_GBs": hbm_b / dt / 1e9, "hbm_frac": hbm_b / dt / 1e9 / HBM_PEAK_GBS}
         n_launch = max(1, d["launches_trace_closest"])
@@ -260,13 +302,16 @@ def main():
         tc = kernels["k_trace_closest"]
         if "valu_issue" in tc:
             roof = {"bound": "valu_issue", "kernel": "k_trace_closest", "achieved": tc["valu_issue"]["achieved"], "peak": tc["valu_issue"]["peak"],
-                    "unit": "G wave-instr/s", "frac": tc["valu_issue"]["frac"], "frac_of_paper_peak": tc["valu_issue"]["frac_of_paper_peak"],
+                    "unit": "G wave-instr/s", "frac": tc["valu_issue"]["frac"], "frac_of_measured_ceiling": tc["valu_issue"]["frac_of_measured_ceiling"],
+                    "measured_ceiling": tc["valu_issue"]["measured_ceiling"], "issue_duty_per_cycle": tc["valu_issue"]["issue_duty_per_cycle"],
                     "frac_exclusive": tc["valu_issue"].get("frac_exclusive"), "exclusive_launch_ms_from_profile": tc.get("exclusive_launch_ms_from_profile"),
                     "peak_kind": tc["valu_issue"]["peak_kind"], "traffic": tc.get("hbm", {}).get("bytes_per_launch"),
                     "hbm_achieved_GBs": tc.get("hbm", {}).get("achieved"), "hbm_frac": tc.get("hbm", {}).get("frac")}
         else:   # no committed profile to calibrate from: report the physical side as unknown rather than a byte model as a bound
             roof = {"bound": "valu_issue", "kernel": "k_trace_closest", "achieved": None, "peak": VALU_PEAK_PAPER_GIPS, "unit": "G wave-instr/s", "frac": None, "traffic": None}
-        roof.update({"avg_launch_ms": tc_sec / n_launch * 1e3, "launches": n_launch,
+        roof.update({"model": os.path.relpath(model_path, ROOT) if model_path else None, "model_commit": model.get("git_commit"),
+                     "model_kernel_sha256": model.get("kernel_source_sha256"), "library_kernel_sha256": lib_sha, "model_stale": model_stale,
+                     "avg_launch_ms": tc_sec / n_launch * 1e3, "launches": n_launch,
                      "algorithmic_bytes_per_launch": tc_bytes / n_launch,
                      "algorithmic_GBs": tc_bytes / tc_sec / 1e9 if tc_sec > 0 else 0.0,
                      "algorithmic_note": "SURVEY 8(d) byte model (counted units x record sizes); served mostly by LDS/L2/Infinity Cache, not an HBM bound"})
@@ -294,9 +339,12 @@ def main():
                 "sharding": (f"32x32 tiles over {world} ranks (each rank: 1/{world} of the pixels x {S} spp per step), {reduce_impl} to rank 0"
                              if world > 1 else "single GPU"),
             },
+            "library": build_info,
             "roofline": roof,
             "kernels": kernels,
             "whole_frame": whole,
+            "per_rank": per_rank,
+            "rehearsal": (f"tile rank 0 of {tile_count} on one GPU: value is that rank's share of the frame, not the metric" if tile_count != world else None),
             "whole_path_algorithmic_GBs": tot["algorithmic_bytes"] / dt / 1e9,
             "scene_commit_seconds": s1.get("seconds_commit"),    # flatten + SAH BVH + upload, once per scene, outside the timed region
             "seconds": {"wall": dt, "trace_closest": d["seconds_trace_closest"], "trace_any": d["seconds_trace_any"], "shade": d["seconds_shade"],

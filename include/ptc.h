@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PTC_ABI_VERSION 2
+#define PTC_ABI_VERSION 3
 
 typedef struct ptc_ctx ptc_ctx;
 
@@ -83,6 +83,7 @@ typedef struct ptc_stats {
   double seconds_trace_any;
   double seconds_shade;
   double seconds_commit;      /* flatten + BVH build + upload                               */
+  double seconds_reduce;      /* HIP-event time of ptc_comm_reduce_radiance on this rank's stream (includes waiting for the slowest rank) */
   uint32_t launches_trace_closest;
   uint32_t launches_trace_any;
   uint32_t n_triangles;
@@ -104,6 +105,9 @@ void ptc_destroy(ptc_ctx*);
 /* Last error text of the context (or of the last failed ptc_create when ctx == NULL). */
 const char* ptc_last_error(const ptc_ctx*);
 int ptc_abi_version(void);
+/* "ptc abi N gfx950 kernels-sha256 <64 hex digits>": the hash is over the kernel sources this library was built from
+ * (csrc/Makefile); bench.py compares it with the hash in the committed kernel model its roofline block is calibrated on. */
+const char* ptc_build_info(void);
 
 /* ---- scene description --------------------------------------------------------------------
  * Replaces gltf::Asset::loadScene → MeshBuilder::build → TransferStager
@@ -236,6 +240,10 @@ int ptc_comm_destroy(ptc_ctx*);
 typedef struct ptc_group ptc_group;
 ptc_group* ptc_group_create(const int* device_ids, int n_devices);
 int ptc_group_size(const ptc_group*);
+/* Commit ONE scene to every device of the group: the scene is described on ptc_group_ctx(g, 0) only; this call flattens it and
+ * builds the BVH once on the host (unless device 0 has committed it already: that build is then used) and uploads that one build to
+ * every device (N contexts committing on their own would each repeat the build, one after the other on the calling thread). */
+int ptc_group_scene_commit(ptc_group*);
 ptc_ctx* ptc_group_ctx(ptc_group*, int i);
 int ptc_group_render(ptc_group*, int w, int h, int spp, uint64_t seed, int max_bounces, int integrator);
 const char* ptc_group_last_error(const ptc_group*);

@@ -882,6 +882,27 @@ int ora_get_flat_scene(ora_ctx* c, uint32_t* nv, uint32_t* nt, void* verts, uint
   return 0;
 }
 
+/* Material class of a triangle (the key the product's shading kernel sorts hits by; the oracle itself has no use for it and only
+ * exports it with the triangles): a texture SET is a distinct (colour, normal, metal-rough) triple of texture ids among the materials
+ * that have a texture, numbered in material order; class 0 = untextured Lambert (metallic 0, roughness >= 1), 1 = untextured GGX,
+ * 2 + set % 5 = textured (7 is the product's class of an environment miss). */
+static uint32_t material_class(const ora_ctx* c, int32_t mi) {
+  const material_t* m = &c->mats[mi];
+  if (m->tex_color < 0 && m->tex_normal < 0 && m->tex_mr < 0) return (m->metallic == 0.0f && m->roughness >= 1.0f) ? 0u : 1u;
+  uint32_t set = 0;
+  for (int i = 0; i < mi; ++i) {                 /* distinct textured triples before this material's first occurrence */
+    const material_t* a = &c->mats[i];
+    if (a->tex_color < 0 && a->tex_normal < 0 && a->tex_mr < 0) continue;
+    if (a->tex_color == m->tex_color && a->tex_normal == m->tex_normal && a->tex_mr == m->tex_mr) break;   /* mi's set was first seen here */
+    int seen = 0;
+    for (int k = 0; k < i; ++k) {
+      const material_t* b = &c->mats[k];
+      if (b->tex_color == a->tex_color && b->tex_normal == a->tex_normal && b->tex_mr == a->tex_mr && !(b->tex_color < 0 && b->tex_normal < 0 && b->tex_mr < 0)) { seen = 1; break; }
+    }
+    if (!seen) ++set;
+  }
+  return 2u + set % 5u;
+}
 int ora_get_bvh(ora_ctx* c, uint32_t* nn, uint32_t* nt, float* nodes, float* tris) {
   if (!c->committed) return fail(c, "get_bvh: scene not committed");
   if (nn) *nn = c->n_wnodes;
@@ -889,8 +910,7 @@ int ora_get_bvh(ora_ctx* c, uint32_t* nn, uint32_t* nt, float* nodes, float* tri
   if (nodes) memcpy(nodes, c->wnodes, sizeof(wnode_t) * c->n_wnodes);
   if (tris) for (uint32_t i = 0; i < c->n_tris; ++i) {
     float* o = tris + (size_t)i * 12; uint32_t p = c->order[i];
-    const material_t* m = &c->mats[c->tri_mat[p]];
-    uint32_t cls = (m->metallic == 0.0f && m->roughness >= 1.0f && m->tex_mr < 0) ? 0u : 1u;
+    uint32_t cls = material_class(c, c->tri_mat[p]);
     o[0] = c->tv0[i].x; o[1] = c->tv0[i].y; o[2] = c->tv0[i].z; memcpy(&o[3], &p, 4);
     o[4] = c->te1[i].x; o[5] = c->te1[i].y; o[6] = c->te1[i].z; memcpy(&o[7], &cls, 4);
     o[8] = c->te2[i].x; o[9] = c->te2[i].y; o[10] = c->te2[i].z; o[11] = 0.0f;

@@ -34,7 +34,8 @@
 #define TRACE_NODE_MIN 40         // leave the node loop when fewer lanes than this are still at interior nodes
 #endif                            // while others wait at a leaf (keeps both phases well populated; 24: -6 %, 32: -1.5 %, 48: -3 %, 56: -18 %)
 #ifndef SHADE_BLOCK
-#define SHADE_BLOCK 256           // a block only shares the staged light / material tables; its waves never synchronise after that
+#define SHADE_BLOCK 512           // a block only shares the staged light / material tables; its waves never synchronise after that (64: +19 % kernel time,
+                                  // 128: +1 %, 256: 0, 512: -2 %: profiles/r03_shade_variants.txt)
 #endif
 #ifndef SHADE_MIN_WAVES
 #define SHADE_MIN_WAVES 4         // <= 128 VGPRs: four independent waves per SIMD
@@ -42,6 +43,7 @@
 #define SHADE_WAVES (SHADE_BLOCK / 64)
 #define SHADE_LDS_LIGHTS 64       // emitter table and material table are staged in LDS when they fit
 #define SHADE_LDS_MATS 64
+#define SHADE_LDS_ENV_ROWS 2048   // rows of an environment map whose row cdf is staged in LDS (8 KB)
 #define HIT_CLASS_SHIFT 28
 
 // ---- small helpers --------------------------------------------------------------------------------
@@ -711,19 +713,67 @@ PT_DEV float4 tex_fetch(const DevScene& sc, int tex, float u, float v) {
   return make_float4(pt_fma(ty, bx - ax, ax), pt_fma(ty, by - ay, ay), pt_fma(ty, bz - az, az), pt_fma(ty, bw - aw, aw));
 }
 
+// Texel address inside a texture set: 8x8 tiles row-major over the image, Morton order inside a tile (ptc_scene.cpp).
+PT_DEV size_t set_texel_at(int4 si, int x, int y) {
+  const uint32_t lx = (uint32_t)x & 7u, ly = (uint32_t)y & 7u;
+  const uint32_t mo = (lx & 1u) | ((ly & 1u) << 1) | ((lx & 2u) << 1) | ((ly & 2u) << 2) | ((lx & 4u) << 2) | ((ly & 4u) << 3);
+  return (size_t)si.x + ((size_t)((uint32_t)y >> 3) * (size_t)si.w + ((uint32_t)x >> 3)) * 64u + mo;
+}
+PT_DEV float4 unorm8x4(uint32_t p) {
+  return make_float4((float)(p & 255u) / 255.0f, (float)((p >> 8) & 255u) / 255.0f, (float)((p >> 16) & 255u) / 255.0f, (float)(p >> 24) / 255.0f);
+}
+// The three texels (colour, normal, metal-rough) of a texture set at (u, v): ONE 16-byte gather per tap instead of three 4-byte gathers from
+// three textures.  Same arithmetic per texture as tex_fetch (the set's textures share one size, so the tap coordinates are the same).
+PT_DEV void set_fetch(const DevScene& sc, int4 si, float u, float v, float4& c, float4& n, float4& m) {
+  const float fu = u - __builtin_floorf(u), fv = v - __builtin_floorf(v);
+  if (!sc.tex_linear) {
+    int x = (int)(fu * (float)si.y), y = (int)(fv * (float)si.z);
+    if (x > si.y - 1) x = si.y - 1;
+    if (y > si.z - 1) y = si.z - 1;
+    const uint4 t = sc.set_texels[set_texel_at(si, x, y)];
+    c = unorm8x4(t.x); n = unorm8x4(t.y); m = unorm8x4(t.z);
+    return;
+  }
+  const float x = pt_fma(fu, (float)si.y, -0.5f), y = pt_fma(fv, (float)si.z, -0.5f);
+  const float x0f = __builtin_floorf(x), y0f = __builtin_floorf(y);
+  const float tx = x - x0f, ty = y - y0f;
+  int x0 = (int)x0f, y0 = (int)y0f;
+  int x1 = x0 + 1, y1 = y0 + 1;
+  if (x0 < 0) x0 += si.y;
+  if (y0 < 0) y0 += si.z;
+  if (x1 > si.y - 1) x1 -= si.y;
+  if (y1 > si.z - 1) y1 -= si.z;
+  const uint4 t00 = sc.set_texels[set_texel_at(si, x0, y0)], t10 = sc.set_texels[set_texel_at(si, x1, y0)],
+              t01 = sc.set_texels[set_texel_at(si, x0, y1)], t11 = sc.set_texels[set_texel_at(si, x1, y1)];
+  auto bil = [&](uint32_t p00, uint32_t p10, uint32_t p01, uint32_t p11) {
+    const float4 c00 = unorm8x4(p00), c10 = unorm8x4(p10), c01 = unorm8x4(p01), c11 = unorm8x4(p11);
+    const float ax = pt_fma(tx, c10.x - c00.x, c00.x), ay = pt_fma(tx, c10.y - c00.y, c00.y), az = pt_fma(tx, c10.z - c00.z, c00.z), aw = pt_fma(tx, c10.w - c00.w, c00.w);
+    const float bx = pt_fma(tx, c11.x - c01.x, c01.x), by = pt_fma(tx, c11.y - c01.y, c01.y), bz = pt_fma(tx, c11.z - c01.z, c01.z), bw = pt_fma(tx, c11.w - c01.w, c01.w);
+    return make_float4(pt_fma(ty, bx - ax, ax), pt_fma(ty, by - ay, ay), pt_fma(ty, bz - az, az), pt_fma(ty, bw - aw, aw));
+  };
+  c = bil(t00.x, t10.x, t01.x, t11.x); n = bil(t00.y, t10.y, t01.y, t11.y); m = bil(t00.z, t10.z, t01.z, t11.z);
+}
+
 // Textured surface attributes of primitive `prim` at barycentrics (hu, hv): base colour × texel, metallic-roughness texel
 // (glTF: G = roughness, B = metallic), tangent-space normal map through the interpolated TBN (fragment.glsl:24-30).
-// ni = interpolated (un-normalised) vertex normal.  Updates base/metallic/roughness/ns in place.
-PT_DEV void apply_textures(const DevScene& sc, uint32_t prim, float hu, float hv, float hw, float4 M2, v3 ni, float base[4], float& metallic, float& roughness, v3& ns) {
+// ni = interpolated (un-normalised) vertex normal.  Updates base/metallic/roughness/ns in place.  `set` is the material's texture
+// set (M3.x): when the set has an interleaved copy the three texels come with one gather, else one fetch per texture.
+PT_DEV void apply_textures(const DevScene& sc, const float4* tr, float hu, float hv, float hw, float4 M2, int set, v3 ni, float base[4], float& metallic, float& roughness, v3& ns) {
   const int tex_color = __float_as_int(M2.y), tex_normal = __float_as_int(M2.z), tex_mr = __float_as_int(M2.w);
-  const float4* tr = sc.shade_tex + (size_t)prim * 6;
   const float4 t0 = tr[0], t1 = tr[1];
   const float tu = pt_fma(t1.x, hv, pt_fma(t0.z, hu, t0.x * hw)), tv = pt_fma(t1.y, hv, pt_fma(t0.w, hu, t0.y * hw));
-  if (tex_color >= 0) { const float4 c = tex_fetch(sc, tex_color, tu, tv); base[0] = base[0] * c.x; base[1] = base[1] * c.y; base[2] = base[2] * c.z; base[3] = base[3] * c.w; }
-  if (tex_mr >= 0) { const float4 c = tex_fetch(sc, tex_mr, tu, tv); roughness = roughness * c.y; metallic = metallic * c.z; }
+  float4 cc = make_float4(1, 1, 1, 1), cn = make_float4(0.5f, 0.5f, 1.0f, 1.0f), cm = make_float4(1, 1, 1, 1);
+  const int4 si = sc.set_info[set < 0 ? 0 : set];
+  if (set >= 0 && si.x >= 0) set_fetch(sc, si, tu, tv, cc, cn, cm);
+  else {
+    if (tex_color >= 0) cc = tex_fetch(sc, tex_color, tu, tv);
+    if (tex_mr >= 0) cm = tex_fetch(sc, tex_mr, tu, tv);
+    if (tex_normal >= 0) cn = tex_fetch(sc, tex_normal, tu, tv);
+  }
+  if (tex_color >= 0) { base[0] = base[0] * cc.x; base[1] = base[1] * cc.y; base[2] = base[2] * cc.z; base[3] = base[3] * cc.w; }
+  if (tex_mr >= 0) { roughness = roughness * cm.y; metallic = metallic * cm.z; }
   if (tex_normal >= 0) {
-    const float4 c = tex_fetch(sc, tex_normal, tu, tv);
-    const float nx = 2.0f * c.x - 1.0f, ny = 2.0f * c.y - 1.0f, nz = 2.0f * c.z - 1.0f;
+    const float nx = 2.0f * cn.x - 1.0f, ny = 2.0f * cn.y - 1.0f, nz = 2.0f * cn.z - 1.0f;
     const float4 t2 = tr[2], t3 = tr[3], t4 = tr[4], t5 = tr[5];
     // tangents: a = (t1.z, t1.w, t2.x) b = (t2.y, t2.z, t2.w) c = (t3.x, t3.y, t3.z); bitangents: a = (t3.w, t4.x, t4.y) b = (t4.z, t4.w, t5.x) c = (t5.y, t5.z, t5.w)
     const v3 ti = V3(pt_fma(t3.x, hv, pt_fma(t2.y, hu, t1.z * hw)), pt_fma(t3.y, hv, pt_fma(t2.z, hu, t1.w * hw)), pt_fma(t3.z, hv, pt_fma(t2.w, hu, t2.x * hw)));
@@ -753,12 +803,21 @@ PT_DEV uint32_t cdf_search(const float* cdf, uint32_t n, float r) {
   return lo;
 }
 // Importance-sample the environment: row by the marginal cdf, column by the row's conditional cdf, uniform inside the texel.
-PT_DEV v3 env_sample(const DevScene& sc, float r1, float r2) {
-  const uint32_t y = cdf_search(sc.env_marg, (uint32_t)sc.env_h, r1);
-  const float m0 = y ? sc.env_marg[y - 1u] : 0.0f, m1 = sc.env_marg[y];
+// cdf_search over [guide[b], guide[b + 1]], b = floor(PTC_ENV_GUIDE r): the same index as the search over the whole table (the answer is monotonic in r
+// and guide[b] is the answer for r = b/64), after 2 + log2(range) instead of log2(n) dependent loads
+PT_DEV uint32_t cdf_search_guided(const float* cdf, const uint16_t* guide, float r) {
+  const uint32_t b = (uint32_t)(r * (float)PTC_ENV_GUIDE);
+  uint32_t lo = guide[b], hi = guide[b + 1u];
+  while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cdf[mid] > r) hi = mid; else lo = mid + 1u; }
+  return lo;
+}
+// marg / marg_guide: the row cdf and its guide — the scene's arrays, or k_shade's copies in LDS
+PT_DEV v3 env_sample(const DevScene& sc, const float* marg, const uint16_t* marg_guide, float r1, float r2) {
+  const uint32_t y = cdf_search_guided(marg, marg_guide, r1);
+  const float m0 = y ? marg[y - 1u] : 0.0f, m1 = marg[y];
   float xi_v = m1 > m0 ? (r1 - m0) / (m1 - m0) : 0.5f;
   const float* cc = sc.env_cond + (size_t)y * (size_t)sc.env_w;
-  const uint32_t x = cdf_search(cc, (uint32_t)sc.env_w, r2);
+  const uint32_t x = cdf_search_guided(cc, sc.env_cond_guide + (size_t)y * (PTC_ENV_GUIDE + 1u), r2);
   const float c0 = x ? cc[x - 1u] : 0.0f, c1 = cc[x];
   float xi_u = c1 > c0 ? (r2 - c0) / (c1 - c0) : 0.5f;
   xi_u = fmin2(fmax2(xi_u, 0.0f), 0.999999f); xi_v = fmin2(fmax2(xi_v, 0.0f), 0.999999f);
@@ -782,6 +841,8 @@ PT_DEV v3 env_sample(const DevScene& sc, float r1, float r2) {
 // P9, compaction: continuation rays and shadow rays of a batch go to the front of the wave's OWN segment of the output arrays (ballot +
 // mbcnt prefix behind a wave-private cursor): a wave never writes more records than it has read, so the segment cannot overflow.
 #define SHADE_RING 128            // slots a class ring holds: a batch is taken as soon as 64 are there, so at most 63 + 64 wait
+// (Emptying the rings every 128 / 256 / 512 / 1024 slots, so that a slot's record is read soon after its neighbours', was slower: k_shade +6 % / +3.5 % /
+// +1 % / +1 % on the atrium and +44 % / +17 % / +11 % on the textured atrium — partial batches cost more than the re-read lines: profiles/r03_shade_variants.txt.)
 PT_DEV void wave_lds_sync() {     // LDS written by some lanes of this wave is read by others
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -791,8 +852,10 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(const De
   // small scene-wide tables staged once per block: emitter records + power cdf, materials
   __shared__ float4 s_light[SHADE_LDS_LIGHTS * 5];
   __shared__ float s_cdf[SHADE_LDS_LIGHTS];
-  __shared__ float4 s_mat[SHADE_LDS_MATS * 3];
+  __shared__ float4 s_mat[SHADE_LDS_MATS * 4];
   __shared__ uint32_t s_ring[SHADE_WAVES][PTC_MATERIAL_CLASSES][SHADE_RING];
+  __shared__ float s_marg[SHADE_LDS_ENV_ROWS];                   // the environment's row cdf and its guide, when the map is at most this high
+  __shared__ uint16_t s_marg_guide[PTC_ENV_GUIDE + 2];
   const DevScene& sc = *scp;
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
@@ -802,8 +865,15 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(const De
     for (uint32_t i = threadIdx.x; i < sc.n_lights; i += SHADE_BLOCK) s_cdf[i] = sc.cdf[i];
   }
   if (lds_mats)
-    for (uint32_t i = threadIdx.x; i < sc.n_mats * 3u; i += SHADE_BLOCK) s_mat[i] = sc.mats[i];
+    for (uint32_t i = threadIdx.x; i < sc.n_mats * 4u; i += SHADE_BLOCK) s_mat[i] = sc.mats[i];
+  const bool lds_marg = sc.env_ok != 0 && sc.env_h <= SHADE_LDS_ENV_ROWS;
+  if (lds_marg) {
+    for (uint32_t i = threadIdx.x; i < (uint32_t)sc.env_h; i += SHADE_BLOCK) s_marg[i] = sc.env_marg[i];
+    for (uint32_t i = threadIdx.x; i <= PTC_ENV_GUIDE; i += SHADE_BLOCK) s_marg_guide[i] = sc.env_marg_guide[i];
+  }
   __syncthreads();
+  const float* env_marg = lds_marg ? s_marg : sc.env_marg;
+  const uint16_t* env_marg_guide = lds_marg ? s_marg_guide : sc.env_marg_guide;
   const uint32_t seg = blockIdx.x * SHADE_WAVES + wave;
   if (seg >= q.n_seg) return;
   const float4* lights = lds_lights ? s_light : sc.lights;
@@ -894,7 +964,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(const De
       } else {
       const uint32_t prim = (uint32_t)__float_as_int(H.y) & ((1u << HIT_CLASS_SHIFT) - 1u);
       // ---- P5 surface reconstruction from the primitive's shading record (five 16-byte loads) ----
-      const float4* rec = sc.shade + (size_t)prim * 5;
+      const float4* rec = sc.shade + (size_t)prim * sc.shade_stride;
       const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4];
       SSTAMP_LOADS(t_load);
       const v3 Pa = V3(r0.x, r0.y, r0.z), Pb = V3(r1.x, r1.y, r1.z), Pc = V3(r2.x, r2.y, r2.z);
@@ -905,12 +975,12 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(const De
       const v3 ni = V3(pt_fma(Nc.x, hv, pt_fma(Nb.x, hu, Na.x * hw)), pt_fma(Nc.y, hv, pt_fma(Nb.y, hu, Na.y * hw)), pt_fma(Nc.z, hv, pt_fma(Nb.z, hu, Na.z * hw)));
       v3 ns = normalize3(ni);
       const int mat = __float_as_int(r0.w);
-      const float4 M0 = mats[mat * 3 + 0], M1 = mats[mat * 3 + 1], M2 = mats[mat * 3 + 2];
+      const float4 M0 = mats[mat * 4 + 0], M1 = mats[mat * 4 + 1], M2 = mats[mat * 4 + 2];
       float base_c[4] = {M0.x, M0.y, M0.z, M2.x};
       float metallic = M0.w, roughness = M1.w;
       const bool lambert = metallic == 0.0f && roughness >= 1.0f && __float_as_int(M2.w) < 0;
       if (__float_as_int(M2.y) >= 0 || __float_as_int(M2.z) >= 0 || __float_as_int(M2.w) >= 0)
-        apply_textures(sc, prim, hu, hv, hw, M2, ni, base_c, metallic, roughness, ns);
+        apply_textures(sc, rec + 5, hu, hv, hw, M2, __float_as_int(mats[mat * 4 + 3].x), ni, base_c, metallic, roughness, ns);
       const v3 wo = -d;
       const bool front = dot3(ng, wo) > 0.0f;
       if (dot3(ns, ng) < 0.0f) ns = -ns;
@@ -943,7 +1013,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(const De
         if (env_nee) use_env = sc.n_lights == 0u || rng_f(key, rb, 7) < p_env;
         if (use_env) {
           const float r1 = rng_f(key, rb, 1), r2 = rng_f(key, rb, 2);
-          const v3 wi = env_sample(sc, r1, r2);
+          const v3 wi = env_sample(sc, env_marg, env_marg_guide, r1, r2);
           const v3 wil = V3(dot3(tx, wi), dot3(ty, wi), dot3(ns, wi));
           if (wil.z > 0.0f && dot3(ng, wi) > 0.0f) {
             v3 Le; float pe; env_lookup(sc, wi, Le, pe);
@@ -1090,17 +1160,17 @@ __global__ __launch_bounds__(256) void k_shade_raster(DevScene sc, DevCamera cam
   if (pc >= 0) {
     const int prim = pc & ((1 << HIT_CLASS_SHIFT) - 1);
     const float hu = H.z, hv = H.w, hw = 1.0f - hu - hv;
-    const float4* rec = sc.shade + (size_t)prim * 5;
+    const float4* rec = sc.shade + (size_t)prim * sc.shade_stride;
     const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4];
     v3 P = V3(pt_fma(r2.x, hv, pt_fma(r1.x, hu, r0.x * hw)), pt_fma(r2.y, hv, pt_fma(r1.y, hu, r0.y * hw)), pt_fma(r2.z, hv, pt_fma(r1.z, hu, r0.z * hw)));
     const v3 ni = V3(pt_fma(r4.y, hv, pt_fma(r3.z, hu, r2.w * hw)), pt_fma(r4.z, hv, pt_fma(r3.w, hu, r3.x * hw)), pt_fma(r4.w, hv, pt_fma(r4.x, hu, r3.y * hw)));
     v3 N = normalize3(ni);
     const int mat = __float_as_int(r0.w);
-    const float4 M0 = sc.mats[mat * 3 + 0], M1 = sc.mats[mat * 3 + 1], M2 = sc.mats[mat * 3 + 2];
+    const float4 M0 = sc.mats[mat * 4 + 0], M1 = sc.mats[mat * 4 + 1], M2 = sc.mats[mat * 4 + 2];
     float base[4] = {M0.x, M0.y, M0.z, M2.x};
     float metallic = M0.w, roughness = M1.w;
     if (__float_as_int(M2.y) >= 0 || __float_as_int(M2.z) >= 0 || __float_as_int(M2.w) >= 0)
-      apply_textures(sc, (uint32_t)prim, hu, hv, hw, M2, ni, base, metallic, roughness, N);
+      apply_textures(sc, rec + 5, hu, hv, hw, M2, __float_as_int(sc.mats[mat * 4 + 3].x), ni, base, metallic, roughness, N);
     if (GBUF16) {
       P = V3(round_f16(P.x), round_f16(P.y), round_f16(P.z));
       N = V3(round_f16(N.x), round_f16(N.y), round_f16(N.z));

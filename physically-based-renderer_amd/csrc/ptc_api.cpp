@@ -17,13 +17,16 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
+#define PTC_STR2(x) #x
+#define PTC_STR(x) PTC_STR2(x)
 namespace {
 std::string g_create_error;
 
-struct Span { hipEvent_t a, b; int kind; };   // kind: 0 trace_closest, 1 trace_any, 2 shade, 3 whole batch
+struct Span { hipEvent_t a, b; int kind; };   // kind: 0 trace_closest, 1 trace_any, 2 shade, 3 whole batch, 4 the RCCL reduce
 
 template <class T> struct DevBuf {
   T* p = nullptr; size_t n = 0;
@@ -99,7 +102,7 @@ struct ptc_ctx {
   int bvh_builder = PTC_BVH_SAH;         // builder of the scene being described
   // committed scene
   bool committed = false;
-  HostBuilt built;
+  std::shared_ptr<HostBuilt> built = std::make_shared<HostBuilt>();   // the host build; the contexts of a ptc_group share one (ptc_group_scene_commit)
   DevScene dsc{};
   DevCamera cam{};
   std::vector<void*> scene_allocs;
@@ -236,6 +239,7 @@ void collect_times(ptc_ctx* c, bool all_done) {
       if (s.kind == 0) c->stats.seconds_trace_closest += sec;
       else if (s.kind == 1) c->stats.seconds_trace_any += sec;
       else if (s.kind == 2) c->stats.seconds_shade += sec;
+      else if (s.kind == 4) c->stats.seconds_reduce += sec;
       else c->stats.seconds_render += sec;
     }
     c->free_events.push_back(s.a); c->free_events.push_back(s.b);
@@ -257,7 +261,7 @@ int configure_launch(ptc_ctx* c) {
   // Traversal stack: at most one group of pending children per tree level, so a ray needs at most depth+1 entries.
   // `stack_lds` of them live in LDS (8 B each, 512 B per level and wave), the rest in a global overflow slab.
   // LDS per block = staged top of the tree (4.6 KB) + waves·stack_lds·512 B + the 2-KiB slot-order table.
-  const int need = (int)c->built.max_depth + 2;
+  const int need = (int)c->built->max_depth + 2;
   int l = 6;    // stack entries per lane kept in LDS: 18.6 KB per block, 8 blocks (32 waves, the register limit) share a CU
   if (const char* e = std::getenv("PTC_STACK_LDS")) { int v = std::atoi(e); if (v >= 1 && v <= 64) l = v; }
   if (l > need) l = need;
@@ -419,6 +423,11 @@ extern "C" {
 
 int ptc_abi_version(void) { return PTC_ABI_VERSION; }
 
+#ifndef PTC_KERNEL_SHA
+#define PTC_KERNEL_SHA "unknown"
+#endif
+const char* ptc_build_info(void) { return "ptc abi " PTC_STR(PTC_ABI_VERSION) " gfx950 kernels-sha256 " PTC_KERNEL_SHA; }
+
 ptc_ctx* ptc_create(int device_id) {
   if (device_id == PTC_DEVICE_NONE) {   // description-only context: host flatten + BVH build, no rendering
     ptc_ctx* c = new ptc_ctx();
@@ -440,8 +449,10 @@ ptc_ctx* ptc_create(int device_id) {
   c->cfg.n_cu = prop.multiProcessorCount;
   c->cfg.trace_blocks_per_cu = 4;
   c->cfg.stack_lds = 6;
-  {   // segments of a queue = waves of k_shade's grid: 16 per CU is what is resident at 4 waves per SIMD
-    int per_cu = 16;
+  {   // segments of a queue = waves of k_shade's grid.  16 per CU are resident at 4 waves per SIMD; 32 (two rounds, the tail of one under the
+      // start of the next) is 3 % faster, 64 the same, 8 (two waves per SIMD) only 7 % slower and 4 62 %: k_shade runs at the rate of the CUs'
+      // memory path, not at the latency of its loads (profiles/r03_shade_variants.txt)
+    int per_cu = 32;
     if (const char* s = std::getenv("PTC_SEGMENTS_PER_CU")) { int v = std::atoi(s); if (v >= 1 && v <= 64) per_cu = v; }
     uint32_t n = (uint32_t)(c->cfg.n_cu * per_cu);
     c->cfg.shade_waves = (int)(n > PTC_MAX_SEGMENTS ? PTC_MAX_SEGMENTS : n);
@@ -590,35 +601,28 @@ int ptc_set_bvh_builder(ptc_ctx* c, int builder) {
 int ptc_set_env_latlong_rgb32f(ptc_ctx* c, const float* rgb, int w, int h) {
   if (!c) return PTC_E_ARG;
   if (!rgb) { c->env = HostEnv{}; return PTC_OK; }
-  if (w <= 0 || h <= 0 || (uint64_t)w * (uint64_t)h > (1u << 28)) return fail(c, PTC_E_ARG, "set_env: bad size");
+  if (w <= 0 || h <= 0 || w > 65536 || h > 65536 || (uint64_t)w * (uint64_t)h > (1u << 28)) return fail(c, PTC_E_ARG, "set_env: bad size");
   c->env.rgb.assign(rgb, rgb + (size_t)w * h * 3); c->env.w = w; c->env.h = h;
   return PTC_OK;
 }
 
-int ptc_scene_commit(ptc_ctx* c) {
-  if (!c) return PTC_E_ARG;
-  if (!c->have_cam) return fail(c, PTC_E_STATE, "scene_commit: no camera");
-  if (c->device >= 0) {
-    HIP_TRY(c, hipSetDevice(c->device));
-    { int rs = sync_all_lanes(c); if (rs) return rs; }
-  }
-  const auto t0 = std::chrono::steady_clock::now();
-  const std::string e = ptc_build_scene(c->mats, c->meshes, c->insts, c->texs, c->env, c->toplet_budget, c->bvh_builder, c->built);
-  if (!e.empty()) return fail(c, PTC_E_STATE, e);
+namespace {
+// Device half of a commit: upload c->built, size the launches.  The caller has set c->built, the camera and seconds_commit's start.
+int commit_upload(ptc_ctx* c, std::chrono::steady_clock::time_point t0) {
   ptc_make_camera(c->cam_pos, c->cam_target, c->cam_fov, c->cam_aspect, c->cam);
   c->in_frame = false; c->pending = 0;
   if (c->device < 0) {   // description-only context: nothing to upload
     c->committed = true;
     std::memset(&c->stats, 0, sizeof c->stats);
     c->stats.seconds_commit = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    c->stats.n_triangles = c->built.n_tris; c->stats.n_bvh_nodes = c->built.n_nodes; c->stats.n_emitters = c->built.n_lights;
-    c->stats.bvh_max_depth = c->built.max_depth;
+    c->stats.n_triangles = c->built->n_tris; c->stats.n_bvh_nodes = c->built->n_nodes; c->stats.n_emitters = c->built->n_lights;
+    c->stats.bvh_max_depth = c->built->max_depth;
     return PTC_OK;
   }
   c->committed = false;
   free_all(c->scene_allocs);
   for (auto& ln : c->lanes) ln.stack_ovf = nullptr;
-  const HostBuilt& B = c->built;
+  const HostBuilt& B = *c->built;
   DevScene d{};
   int rc = 0;
   {
@@ -626,9 +630,13 @@ int ptc_scene_commit(ptc_ctx* c) {
     auto up = [&](const std::vector<float>& v, const float4** out) { if (!rc) { rc = dev_upload(c, c->scene_allocs, &p, v); *out = (const float4*)p; } };
     up(B.recs, &d.recs); up(B.mats, &d.mats); up(B.lights, &d.lights);
     if (!rc) rc = dev_upload(c, c->scene_allocs, &d.cdf, B.cdf);
-    up(B.shade, &d.shade); up(B.shade_tex, &d.shade_tex);
+    up(B.shade, &d.shade);
     if (!rc) rc = dev_upload(c, c->scene_allocs, &d.texels, B.texels);
     if (!rc) { const int32_t* ti = nullptr; rc = dev_upload(c, c->scene_allocs, &ti, B.tex_info); d.tex_info = (const int4*)ti; }
+    if (!rc) { const uint32_t* st = nullptr; rc = dev_upload(c, c->scene_allocs, &st, B.set_texels); d.set_texels = (const uint4*)st; }
+    if (!rc) { const int32_t* si = nullptr; rc = dev_upload(c, c->scene_allocs, &si, B.set_info); d.set_info = (const int4*)si; }
+    if (!rc) rc = dev_upload(c, c->scene_allocs, &d.env_marg_guide, B.env_marg_guide);
+    if (!rc) rc = dev_upload(c, c->scene_allocs, &d.env_cond_guide, B.env_cond_guide);
     up(B.env, &d.env);
     if (!rc) rc = dev_upload(c, c->scene_allocs, &d.env_marg, B.env_marg);
     if (!rc) rc = dev_upload(c, c->scene_allocs, &d.env_cond, B.env_cond);
@@ -636,6 +644,7 @@ int ptc_scene_commit(ptc_ctx* c) {
   if (rc) { free_all(c->scene_allocs); return rc; }
   d.env_w = B.env_w; d.env_h = B.env_h; d.env_ok = B.env_ok;
   d.tex_linear = c->tex_linear;
+  d.shade_stride = B.shade_stride;
   d.n_lights = B.n_lights; d.n_mats = (uint32_t)c->mats.size(); d.n_lds_units = B.n_lds_units; d.ray_eps = B.ray_eps;
   for (int k = 0; k < 3; ++k) { d.grid_lo[k] = B.grid_lo[k]; d.grid_step[k] = B.grid_step[k]; }
   c->dsc = d;
@@ -649,6 +658,22 @@ int ptc_scene_commit(ptc_ctx* c) {
   c->stats.seconds_commit = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   c->stats.n_triangles = B.n_tris; c->stats.n_bvh_nodes = B.n_nodes; c->stats.n_emitters = B.n_lights; c->stats.bvh_max_depth = B.max_depth;
   return PTC_OK;
+}
+}  // namespace
+
+int ptc_scene_commit(ptc_ctx* c) {
+  if (!c) return PTC_E_ARG;
+  if (!c->have_cam) return fail(c, PTC_E_STATE, "scene_commit: no camera");
+  if (c->device >= 0) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    { int rs = sync_all_lanes(c); if (rs) return rs; }
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  auto built = std::make_shared<HostBuilt>();
+  const std::string e = ptc_build_scene(c->mats, c->meshes, c->insts, c->texs, c->env, c->toplet_budget, c->bvh_builder, *built);
+  if (!e.empty()) return fail(c, PTC_E_STATE, e);
+  c->built = built;
+  return commit_upload(c, t0);
 }
 
 int ptc_frame_begin(ptc_ctx* c, int w, int h, int spp_total, uint64_t seed, int max_bounces, int integrator, int tile_rank, int tile_count) {
@@ -858,6 +883,7 @@ int ptc_comm_reduce_radiance(ptc_ctx* c, int root) {
   if (root < 0 || root >= c->comm_size) return fail(c, PTC_E_ARG, "comm_reduce_radiance: bad root");
   if (!c->radiance.p || c->rad_w == 0) return fail(c, PTC_E_STATE, "comm_reduce_radiance: nothing rendered");
   // in place on stream 0, behind the resolve: ranks own disjoint tiles and hold zeros elsewhere, so the fp32 sum is x + 0
+  ScopedSpan t(c, c->lanes[0].stream, 4);            // seconds_reduce: the collective as this rank's stream sees it (it includes waiting for the slowest rank)
   NCCL_TRY(c, g_rccl.Reduce(c->radiance.p, c->radiance.p, (size_t)c->rad_w * c->rad_h * 4, ncclFloat32, ncclSum, root, c->comm, c->lanes[0].stream));
   return PTC_OK;
 }
@@ -892,6 +918,26 @@ ptc_group* ptc_group_create(const int* device_ids, int n_devices) {
 }
 
 int ptc_group_size(const ptc_group* g) { return g ? (int)g->ctx.size() : 0; }
+
+int ptc_group_scene_commit(ptc_group* g) {
+  if (!g || g->ctx.empty()) return PTC_E_ARG;
+  ptc_ctx* c0 = g->ctx[0];
+  int rc = c0->committed ? PTC_OK : ptc_scene_commit(c0);     // flatten + BVH build, once, on the host (a scene device 0 has committed already is taken as it is)
+  if (rc) { g->err = std::string("device 0: ") + ptc_last_error(c0); return rc; }
+  for (size_t i = 1; i < g->ctx.size(); ++i) {
+    ptc_ctx* c = g->ctx[i];
+    if (hipSetDevice(c->device) != hipSuccess) { g->err = "ptc_group_scene_commit: hipSetDevice failed"; return PTC_E_DEVICE; }
+    if ((rc = sync_all_lanes(c))) { g->err = "device " + std::to_string(i) + ": " + ptc_last_error(c); return rc; }
+    const auto t0 = std::chrono::steady_clock::now();
+    // the description travels too (materials are counted from it, a later ptc_scene_commit on this context rebuilds from it)
+    c->mats = c0->mats; c->meshes = c0->meshes; c->insts = c0->insts; c->texs = c0->texs; c->env = c0->env;
+    std::memcpy(c->cam_pos, c0->cam_pos, 12); std::memcpy(c->cam_target, c0->cam_target, 12); c->cam_fov = c0->cam_fov; c->cam_aspect = c0->cam_aspect;
+    c->have_cam = true; c->tex_linear = c0->tex_linear; c->bvh_builder = c0->bvh_builder; c->toplet_budget = c0->toplet_budget;
+    c->built = c0->built;                             // shared, read-only from here on
+    if ((rc = commit_upload(c, t0))) { g->err = "device " + std::to_string(i) + ": " + ptc_last_error(c); return rc; }
+  }
+  return PTC_OK;
+}
 ptc_ctx* ptc_group_ctx(ptc_group* g, int i) { return (g && i >= 0 && (size_t)i < g->ctx.size()) ? g->ctx[(size_t)i] : nullptr; }
 const char* ptc_group_last_error(const ptc_group* g) { return g ? g->err.c_str() : g_create_error.c_str(); }
 
@@ -981,7 +1027,7 @@ int ptc_debug_trace_any(ptc_ctx* c, const float* origins, const float* dirs, con
 int ptc_debug_get_flat_scene(ptc_ctx* c, uint32_t* n_verts, uint32_t* n_tris, ptc_vertex* verts, uint32_t* indices, int32_t* tri_material) {
   if (!c) return PTC_E_ARG;
   if (!c->committed) return fail(c, PTC_E_STATE, "debug_get_flat_scene: scene not committed");
-  const HostBuilt& B = c->built;
+  const HostBuilt& B = *c->built;
   if (n_verts) *n_verts = (uint32_t)B.wverts.size();
   if (n_tris) *n_tris = B.n_tris;
   if (verts) std::memcpy(verts, B.wverts.data(), B.wverts.size() * sizeof(ptc_vertex));
@@ -1030,7 +1076,7 @@ int ptc_debug_get_counters(ptc_ctx* c, uint64_t* out, int n) {
 int ptc_debug_get_bvh(ptc_ctx* c, uint32_t* n_nodes, uint32_t* n_tris, uint32_t* n_units, float* units, float grid[6]) {
   if (!c) return PTC_E_ARG;
   if (!c->committed) return fail(c, PTC_E_STATE, "debug_get_bvh: scene not committed");
-  const HostBuilt& B = c->built;
+  const HostBuilt& B = *c->built;
   if (n_nodes) *n_nodes = B.n_nodes;
   if (n_tris) *n_tris = B.n_tri_records;
   if (n_units) *n_units = B.n_units;

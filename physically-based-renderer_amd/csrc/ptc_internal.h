@@ -13,16 +13,25 @@ struct DevScene {
                               // children-block address, 8-bit child planes) and 48-byte triangle records (v0,prim) (e1,class) (e2,-) in the
                               // children blocks of their nodes; addresses are unit indices, the root is at 0 (layout: ptc_scene.cpp)
   float grid_lo[3], grid_step[3];   // node origin = fma(oq, grid_step, grid_lo)
-  const float4* shade;        // 5 × float4 per original primitive id (80 B): the three R1 vertex records de-indexed to what
-                              // shading reads: (Pa,mat) (Pb,light) (Pc,Na.x) (Na.yz,Nb.xy) (Nb.z,Nc.xyz)
-  const float4* mats;         // 3 × float4 per material: (base.rgb, metallic) (emissive.rgb, roughness) (base.a, tex_color, tex_normal, tex_mr)
-  const float4* shade_tex;    // 6 × float4 per primitive, only when a material has a texture: uv ×3, world tangent ×3, world bitangent ×3
+  const float4* shade;        // shade_stride × float4 per original primitive id.  The first 5 (80 B): the three R1 vertex records de-indexed to what
+                              // shading reads: (Pa,mat) (Pb,light) (Pc,Na.x) (Na.yz,Nb.xy) (Nb.z,Nc.xyz).  Scenes with a textured material append the 6
+                              // units of uv ×3, world tangent ×3, world bitangent ×3 and one of padding: a 192-byte record on a 64-byte boundary, three
+                              // whole sectors per gather instead of the four to five of an 80-byte and a 96-byte record in two tables
+  uint32_t shade_stride;      // 5 or 12
+  const float4* mats;         // 4 × float4 per material: (base.rgb, metallic) (emissive.rgb, roughness) (base.a, tex_color, tex_normal, tex_mr) (texture set, -, -, -)
   const uint32_t* texels;     // all RGBA8 textures back to back
   const int4* tex_info;       // per texture: (offset into texels, width, height, 0)
+  const uint4* set_texels;    // texture SETS: the (colour, normal, metal-rough) textures of a material interleaved texel by texel — one 16-byte gather
+                              // instead of three 4-byte ones from three lines — and stored in 8x8 tiles, Morton order inside a tile (a 128-byte line = a
+                              // 4x2 block of texels); same texel values as `texels`, so NEAREST and LINEAR results are untouched
+  const int4* set_info;       // per set: (offset into set_texels or -1 when the set's textures differ in size, width, height, tiles per row)
   int tex_linear;             // 0 = NEAREST (the reference's sampler), 1 = bilinear
   const float4* env;          // lat-long environment: (radiance.rgb, texel pmf) per texel, row 0 = +y
   const float* env_marg;      // row cdf (env_h)
   const float* env_cond;      // per-row column cdf (env_w × env_h)
+  const uint16_t* env_marg_guide;   // [PTC_ENV_GUIDE + 1]: guide[b] = cdf_search(env_marg, r = b / PTC_ENV_GUIDE): the search for r runs inside [guide[b], guide[b+1]],
+                                    // b = floor(PTC_ENV_GUIDE r) — same index as the search over the whole table, after ~1 instead of ~10 dependent loads
+  const uint16_t* env_cond_guide;   // [env_h][PTC_ENV_GUIDE + 1]: the same per row
   int env_w, env_h, env_ok;   // env_ok: the map has non-zero power, i.e. it can be importance-sampled
   const float4* lights;       // 5 × float4 per emitter: (v0,area) (e1,pmf) (e2,-) (ng,-) (Le,-)
   const float* cdf;           // emitter power cdf
@@ -79,6 +88,7 @@ struct DevQueues {
 // atomics and therefore has a 128-byte line of its own (atomics on one line are served one at a time, ~11 ns each).
 enum { CNT_RAY_TOTAL = 0, CNT_RAY_CHUNK, CNT_RAY_NCHUNKS, CNT_SH_TOTAL, CNT_SH_CHUNK, CNT_SH_NCHUNKS, CNT_WORK_TRACE = 32, CNT_WORK_SHADOW = 64, CNT_N = 96 };
 #define PTC_MAX_SEGMENTS 16384u     // upper bound of n_seg (sizes the per-segment arrays)
+#define PTC_ENV_GUIDE 256u          // buckets of the environment cdf guide tables (a power of two: r * PTC_ENV_GUIDE is exact)
 #define PTC_MATERIAL_CLASSES 8      // classes a hit word can carry (3 bits above the 28-bit primitive id); class 7 = miss under an environment
 enum { ST_SEGMENTS = 0, ST_SHADOW, ST_HITS, ST_NODES_C, ST_TRIS_C, ST_NODES_A, ST_TRIS_A,
        // wave-level iteration counts of the trace kernels' loops (filled only by a -DPT_DIAG build): lane
@@ -128,15 +138,18 @@ struct HostBuilt {
   std::vector<uint32_t> widx;
   std::vector<int32_t> tri_mat;
   std::vector<int32_t> prim_light;
-  std::vector<float> shade;      // 20 floats per primitive (see DevScene::shade)
-  std::vector<float> shade_tex;  // 24 floats per primitive, empty when no material is textured
+  std::vector<float> shade;      // 4 * shade_stride floats per primitive (see DevScene::shade)
+  uint32_t shade_stride = 5;
   std::vector<uint32_t> texels;  // RGBA8 texels of all textures
   std::vector<int32_t> tex_info; // 4 ints per texture
+  std::vector<uint32_t> set_texels;   // 4 words per texel of every texture set (see DevScene::set_texels)
+  std::vector<int32_t> set_info;      // 4 ints per set
+  std::vector<uint16_t> env_marg_guide, env_cond_guide;
   std::vector<float> env, env_marg, env_cond;   // 4 floats per texel; cdfs
   int env_w = 0, env_h = 0, env_ok = 0;
   std::vector<float> recs;       // the BVH as 16-byte units (4 floats each): nodes + triangle records (see DevScene::recs)
   float grid_lo[3] = {0, 0, 0}, grid_step[3] = {1, 1, 1};
-  std::vector<float> mats;       // 12 floats per material
+  std::vector<float> mats;       // 16 floats per material
   std::vector<float> lights;     // 20 floats per emitter
   std::vector<float> cdf;
   uint32_t n_nodes = 0, n_tris = 0, n_tri_records = 0, n_lights = 0, max_depth = 0, n_units = 0, n_lds_units = 0;

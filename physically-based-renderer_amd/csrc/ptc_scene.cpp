@@ -350,14 +350,33 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
   B.ray_eps = 1e-4f * (diag > 1e-6f ? diag : 1e-6f);
   std::vector<uint32_t> ord(n);        // position in BVH order → original primitive id (partitioned by the build)
   for (uint32_t p = 0; p < n; ++p) ord[p] = p;
+  // ---- texture sets and material classes ------------------------------------------------------------------------------------
+  // A texture SET is a distinct (colour, normal, metal-rough) triple of texture ids among the materials that have a texture, numbered in
+  // material order.  The material CLASS travels in the triangle record and the hit word and is what k_shade sorts by (a wave shades 64
+  // hits of one class): 0 = untextured Lambert, 1 = untextured GGX, 2..6 = textured, 2 + set % 5; 7 is reserved for environment misses.
+  std::vector<int32_t> mat_set(mats.size(), -1);
+  std::vector<int32_t> set_tex;     // 3 ids per set
+  for (size_t i = 0; i < mats.size(); ++i) {
+    const HostMaterial& m = mats[i];
+    if (m.tex_color < 0 && m.tex_normal < 0 && m.tex_mr < 0) continue;
+    int32_t found = -1;
+    for (size_t k = 0; k * 3 < set_tex.size(); ++k)
+      if (set_tex[k * 3] == m.tex_color && set_tex[k * 3 + 1] == m.tex_normal && set_tex[k * 3 + 2] == m.tex_mr) { found = (int32_t)k; break; }
+    if (found < 0) { found = (int32_t)(set_tex.size() / 3); set_tex.push_back(m.tex_color); set_tex.push_back(m.tex_normal); set_tex.push_back(m.tex_mr); }
+    mat_set[i] = found;
+  }
+  auto material_class = [&](int32_t mi) -> uint32_t {
+    const HostMaterial& hm = mats[(size_t)mi];
+    if (mat_set[(size_t)mi] >= 0) return 2u + (uint32_t)mat_set[(size_t)mi] % 5u;
+    return (hm.metallic == 0.0f && hm.roughness >= 1.0f) ? 0u : 1u;
+  };
   // triangle record of sorted position i: (v0, prim id) (e1, class) (e2, 0); emitted below in node order
   auto tri_record = [&](uint32_t i, float* o) {
     const uint32_t p = ord[i];
     const float* a = B.wverts[B.widx[p * 3 + 0]].position;
     const float* b = B.wverts[B.widx[p * 3 + 1]].position;
     const float* c = B.wverts[B.widx[p * 3 + 2]].position;
-    const HostMaterial& hm = mats[(size_t)B.tri_mat[p]];
-    const uint32_t cls = (hm.metallic == 0.0f && hm.roughness >= 1.0f && hm.tex_mr < 0) ? 0u : 1u;
+    const uint32_t cls = material_class(B.tri_mat[p]);
     o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; std::memcpy(&o[3], &p, 4);
     o[4] = b[0] - a[0]; o[5] = b[1] - a[1]; o[6] = b[2] - a[2]; std::memcpy(&o[7], &cls, 4);
     o[8] = c[0] - a[0]; o[9] = c[1] - a[1]; o[10] = c[2] - a[2]; o[11] = 0.0f;
@@ -644,9 +663,10 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
   B.n_tri_records = n_tri_records;
   B.n_lds_units = B.n_units < toplet_budget * 4u ? B.n_units : toplet_budget * 4u;
   // ---- materials --------------------------------------------------------------------------------------
-  B.mats.resize(mats.size() * 12);
+  B.mats.assign(mats.size() * 16, 0.0f);
   for (size_t i = 0; i < mats.size(); ++i) {
-    float* o = &B.mats[i * 12];
+    float* o = &B.mats[i * 16];
+    std::memcpy(&o[12], &mat_set[i], 4);
     const HostMaterial& m = mats[i];
     o[0] = m.base[0]; o[1] = m.base[1]; o[2] = m.base[2]; o[3] = m.metallic;
     o[4] = m.emissive[0]; o[5] = m.emissive[1]; o[6] = m.emissive[2]; o[7] = m.roughness;
@@ -686,31 +706,30 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
     B.cdf[i] = run / total;
     B.lights[i * 20 + 7] = weight[i] / total;
   }
-  // ---- per-primitive shading records: positions + normals of the three vertices, material, emitter index
-  B.shade.resize((size_t)n * 20);
+  // ---- per-primitive shading records: positions + normals of the three vertices, material, emitter index; with a textured material in
+  // the scene also uv / tangent / bitangent of the three vertices (units 5..10) and a unit of padding
+  bool any_tex = false;
+  for (const auto& m : mats) any_tex = any_tex || m.tex_color >= 0 || m.tex_normal >= 0 || m.tex_mr >= 0;
+  B.shade_stride = any_tex ? 12u : 5u;
+  const size_t fl = (size_t)B.shade_stride * 4;
+  B.shade.assign((size_t)n * fl, 0.0f);
   for (uint32_t p = 0; p < n; ++p) {
     const HostVertex& a = B.wverts[B.widx[p * 3 + 0]];
     const HostVertex& b = B.wverts[B.widx[p * 3 + 1]];
     const HostVertex& c = B.wverts[B.widx[p * 3 + 2]];
-    float* o = &B.shade[(size_t)p * 20];
+    float* o = &B.shade[(size_t)p * fl];
     o[0] = a.position[0]; o[1] = a.position[1]; o[2] = a.position[2]; std::memcpy(&o[3], &B.tri_mat[p], 4);
     o[4] = b.position[0]; o[5] = b.position[1]; o[6] = b.position[2]; std::memcpy(&o[7], &B.prim_light[p], 4);
     o[8] = c.position[0]; o[9] = c.position[1]; o[10] = c.position[2]; o[11] = a.normal[0];
     o[12] = a.normal[1]; o[13] = a.normal[2]; o[14] = b.normal[0]; o[15] = b.normal[1];
     o[16] = b.normal[2]; o[17] = c.normal[0]; o[18] = c.normal[1]; o[19] = c.normal[2];
-  }
-  // ---- textured materials: uv / tangent / bitangent of the three vertices per primitive, texel store -----------
-  bool any_tex = false;
-  for (const auto& m : mats) any_tex = any_tex || m.tex_color >= 0 || m.tex_normal >= 0 || m.tex_mr >= 0;
-  if (any_tex) {
-    B.shade_tex.resize((size_t)n * 24);
-    for (uint32_t p = 0; p < n; ++p) {
-      float* o = &B.shade_tex[(size_t)p * 24];
-      for (int c = 0; c < 3; ++c) {
-        const uint32_t vi = B.widx[p * 3 + (uint32_t)c];
+    if (any_tex) {
+      float* t = o + 20;
+      for (int k = 0; k < 3; ++k) {
+        const uint32_t vi = B.widx[p * 3 + (uint32_t)k];
         const HostVertex& v = B.wverts[vi];
-        o[c * 2 + 0] = v.texcoord[0]; o[c * 2 + 1] = v.texcoord[1];
-        for (int k = 0; k < 3; ++k) { o[6 + c * 3 + k] = v.tangent[k]; o[15 + c * 3 + k] = wbt[(size_t)vi * 3 + (size_t)k]; }
+        t[k * 2 + 0] = v.texcoord[0]; t[k * 2 + 1] = v.texcoord[1];
+        for (int j = 0; j < 3; ++j) { t[6 + k * 3 + j] = v.tangent[j]; t[15 + k * 3 + j] = wbt[(size_t)vi * 3 + (size_t)j]; }
       }
     }
   }
@@ -725,6 +744,38 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
   }
   if (B.texels.empty()) B.texels.push_back(0u);
   if (B.tex_info.empty()) B.tex_info.assign(4, 0);
+  // texture sets: the set's textures interleaved per texel (absent texture: 0), 8x8 tiles row-major over the image (width and height
+  // padded to multiples of 8), Morton order inside a tile
+  for (size_t k = 0; k * 3 < set_tex.size(); ++k) {
+    int w = -1, h = -1; bool same = true;
+    for (int j = 0; j < 3; ++j) {
+      const int32_t t = set_tex[k * 3 + (size_t)j];
+      if (t < 0) continue;
+      if (w < 0) { w = texs[(size_t)t].w; h = texs[(size_t)t].h; }
+      else if (texs[(size_t)t].w != w || texs[(size_t)t].h != h) same = false;
+    }
+    if (!same || w <= 0) { const int32_t info[4] = {-1, 0, 0, 0}; B.set_info.insert(B.set_info.end(), info, info + 4); continue; }
+    const uint32_t tw = ((uint32_t)w + 7u) / 8u, th = ((uint32_t)h + 7u) / 8u;
+    const size_t off = B.set_texels.size() / 4;
+    if (off + (size_t)tw * th * 64 > 0x7fffffffull) { const int32_t info[4] = {-1, 0, 0, 0}; B.set_info.insert(B.set_info.end(), info, info + 4); continue; }
+    const int32_t info[4] = {(int32_t)off, w, h, (int32_t)tw};
+    B.set_info.insert(B.set_info.end(), info, info + 4);
+    B.set_texels.resize((off + (size_t)tw * th * 64) * 4, 0u);
+    for (int y = 0; y < h; ++y)
+      for (int x = 0; x < w; ++x) {
+        const uint32_t lx = (uint32_t)x & 7u, ly = (uint32_t)y & 7u;
+        const uint32_t mo = (lx & 1u) | ((ly & 1u) << 1) | ((lx & 2u) << 1) | ((ly & 2u) << 2) | ((lx & 4u) << 2) | ((ly & 4u) << 3);
+        const size_t at = off + ((size_t)((uint32_t)y >> 3) * tw + ((uint32_t)x >> 3)) * 64 + mo;
+        for (int j = 0; j < 3; ++j) {
+          const int32_t t = set_tex[k * 3 + (size_t)j];
+          if (t < 0) continue;
+          uint32_t u; std::memcpy(&u, &texs[(size_t)t].px[((size_t)y * (size_t)w + (size_t)x) * 4], 4);
+          B.set_texels[at * 4 + (size_t)j] = u;
+        }
+      }
+  }
+  if (B.set_texels.empty()) B.set_texels.assign(4, 0u);
+  if (B.set_info.empty()) { const int32_t info[4] = {-1, 0, 0, 0}; B.set_info.assign(info, info + 4); }
   // ---- environment light: radiance + pmf per texel, row-marginal and per-row conditional cdfs ---------------
   B.env_w = env.w; B.env_h = env.h; B.env_ok = 0;
   if (env.w > 0 && env.h > 0) {
@@ -758,6 +809,20 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
     } else {
       for (size_t i = 0; i < np; ++i) B.env[i * 4 + 3] = 0.0f;
     }
+  }
+  // guide tables of the two cdf searches of env_sample: guide[b] = the index the search returns for r = b / PTC_ENV_GUIDE (16 bits: maps up to 65536 texels wide and high)
+  {
+    auto search = [](const float* cdf, uint32_t n, float r) { uint32_t lo = 0, hi = n - 1u; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cdf[mid] > r) hi = mid; else lo = mid + 1u; } return lo; };
+    if (B.env_ok) {
+      const uint32_t G = PTC_ENV_GUIDE;
+      B.env_marg_guide.resize(G + 1);
+      for (uint32_t b = 0; b <= G; ++b) B.env_marg_guide[b] = (uint16_t)search(B.env_marg.data(), (uint32_t)B.env_h, (float)b / (float)G);
+      B.env_cond_guide.resize((size_t)B.env_h * (G + 1));
+      for (int y = 0; y < B.env_h; ++y)
+        for (uint32_t b = 0; b <= G; ++b) B.env_cond_guide[(size_t)y * (G + 1) + b] = (uint16_t)search(&B.env_cond[(size_t)y * (size_t)B.env_w], (uint32_t)B.env_w, (float)b / (float)G);
+    }
+    if (B.env_marg_guide.empty()) B.env_marg_guide.assign(PTC_ENV_GUIDE + 1, 0);
+    if (B.env_cond_guide.empty()) B.env_cond_guide.assign(PTC_ENV_GUIDE + 1, 0);
   }
   if (!B.cdf.empty()) B.cdf.back() = 1.0f;
   if (B.cdf.empty()) B.cdf.push_back(1.0f);

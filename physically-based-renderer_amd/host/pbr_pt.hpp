@@ -134,8 +134,8 @@ private:
   int _w = 0, _h = 0;
 };
 
-// Several GPUs driven by one process (ptc_group: one context per device + an RCCL communicator): the same scene is committed on
-// every device, render() traces device i's 32x32-pixel tiles on device i and reduces the framebuffer onto device 0 (ncclReduce).
+// Several GPUs driven by one process (ptc_group: one context per device + an RCCL communicator): the scene described on device(0) is
+// committed to every device by commitScene(), render() traces device i's 32x32-pixel tiles on device i and reduces the framebuffer onto device 0 (ncclReduce).
 // The reference has a single vk::Device (core/GpuHandle.cpp:94-101); this is the build's multi-GPU addition.
 class DeviceGroup {
 public:
@@ -148,6 +148,8 @@ public:
   auto operator=(DeviceGroup const&) -> DeviceGroup& = delete;
   [[nodiscard]] auto size() const -> int { return (int)_views.size(); }
   auto device(int i) -> PathTraceRenderSystem& { return *_views[(std::size_t)i]; }
+  // the scene described (and possibly committed) on device(0) goes to every device with one host build
+  void commitScene() { if (ptc_group_scene_commit(_g) < 0) throw std::runtime_error(ptc_group_last_error(_g)); }
   auto render(int w, int h, int spp, std::uint64_t seed, int maxBounces, int integrator = PTC_INTEGRATOR_PATH) -> std::vector<float> {
     if (ptc_group_render(_g, w, h, spp, seed, maxBounces, integrator) < 0) throw std::runtime_error(ptc_group_last_error(_g));
     return _views[0]->readRadiance(w, h);

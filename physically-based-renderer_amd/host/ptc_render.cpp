@@ -183,7 +183,8 @@ int main(int argc, char** argv) {
       std::vector<int> ids;
       for (int i = 0; i < gpus; ++i) ids.push_back(device + i);
       group.reset(new pbr::DeviceGroup(ids));
-      for (int i = 0; i < gpus; ++i) buildScene(group->device(i));
+      buildScene(group->device(0));
+      group->commitScene();          // one flatten + BVH build on the host, uploaded to every device
       img = group->render(w, h, spp, seed, bounces, integrator);
     }
     pbr::PathTraceRenderSystem& rs = single ? *single : group->device(0);

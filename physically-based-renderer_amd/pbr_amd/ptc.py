@@ -25,11 +25,11 @@ INTEGRATOR_PATH = 0
 INTEGRATOR_RASTER_COMPAT = 1
 INTEGRATOR_RASTER_GBUFFER16 = 2   # raster-compat lit from the reference's G-buffer formats (RGBA16F P/N, UNORM16 albedo)
 COMM_ID_BYTES = 128
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/ptc.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
-    "ptc_create", "ptc_destroy", "ptc_last_error", "ptc_abi_version", "ptc_scene_begin", "ptc_add_material",
+    "ptc_create", "ptc_destroy", "ptc_last_error", "ptc_abi_version", "ptc_build_info", "ptc_scene_begin", "ptc_add_material",
     "ptc_add_texture_rgba8", "ptc_add_mesh", "ptc_add_instance", "ptc_add_instance_matrix", "ptc_set_camera", "ptc_set_env_latlong_rgb32f", "ptc_set_texture_filter", "ptc_set_bvh_builder", "ptc_scene_commit", "ptc_render",
     "ptc_frame_begin", "ptc_frame_add_samples", "ptc_frame_reserve", "ptc_frame_resolve", "ptc_sync", "ptc_read_radiance_rgba32f",
     "ptc_radiance_device_ptr", "ptc_write_radiance_rgba32f", "ptc_tonemap_rgba8", "ptc_get_stats",
@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     "ptc_debug_get_description", "ptc_debug_get_material", "ptc_debug_get_texture", "ptc_debug_get_internals",
     "ptc_read_radiance_rgba16f", "ptc_radiance_rgba16f_device_ptr",
     "ptc_comm_unique_id", "ptc_comm_init", "ptc_comm_reduce_radiance", "ptc_comm_destroy",
-    "ptc_group_create", "ptc_group_size", "ptc_group_ctx", "ptc_group_render", "ptc_group_last_error", "ptc_group_destroy",
+    "ptc_group_create", "ptc_group_size", "ptc_group_scene_commit", "ptc_group_ctx", "ptc_group_render", "ptc_group_last_error", "ptc_group_destroy",
 ]
 
 
@@ -47,7 +47,7 @@ class PtcStats(C.Structure):
         ("node_visits_closest", C.c_uint64), ("tri_tests_closest", C.c_uint64),
         ("node_visits_any", C.c_uint64), ("tri_tests_any", C.c_uint64), ("algorithmic_bytes", C.c_uint64),
         ("seconds_render", C.c_double), ("seconds_trace_closest", C.c_double), ("seconds_trace_any", C.c_double),
-        ("seconds_shade", C.c_double), ("seconds_commit", C.c_double),
+        ("seconds_shade", C.c_double), ("seconds_commit", C.c_double), ("seconds_reduce", C.c_double),
         ("launches_trace_closest", C.c_uint32), ("launches_trace_any", C.c_uint32),
         ("n_triangles", C.c_uint32), ("n_bvh_nodes", C.c_uint32), ("n_emitters", C.c_uint32), ("bvh_max_depth", C.c_uint32),
     ]
@@ -81,6 +81,7 @@ def load_library():
     L.ptc_last_error.restype = C.c_char_p
     L.ptc_last_error.argtypes = [vp]
     L.ptc_abi_version.restype = C.c_int
+    L.ptc_build_info.restype = C.c_char_p
     L.ptc_scene_begin.argtypes = [vp]
     L.ptc_add_material.argtypes = [vp, fp, C.c_float, C.c_float, fp, C.c_int, C.c_int, C.c_int]
     L.ptc_add_texture_rgba8.argtypes = [vp, u8p, C.c_int, C.c_int]
@@ -123,6 +124,7 @@ def load_library():
     L.ptc_group_create.argtypes = [C.POINTER(C.c_int), C.c_int]
     L.ptc_group_create.restype = vp
     L.ptc_group_size.argtypes = [vp]
+    L.ptc_group_scene_commit.argtypes = [vp]
     L.ptc_group_ctx.argtypes = [vp, C.c_int]
     L.ptc_group_ctx.restype = vp
     L.ptc_group_render.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int]
@@ -367,8 +369,11 @@ class Group:
         return self._ctx[i]
 
     def load_scene(self, desc):
-        for c in self._ctx:
-            c.load_scene(desc)
+        """Describe the scene on device 0 and commit it to every device with ONE host build (ptc_group_scene_commit)."""
+        self._ctx[0].load_scene(desc)
+        rc = self._L.ptc_group_scene_commit(self._g)
+        if rc < 0:
+            raise PtcError(f"ptc error {rc}: {self._L.ptc_group_last_error(self._g).decode()}")
         return self
 
     def render(self, w, h, spp, seed=1, max_bounces=8, integrator=INTEGRATOR_PATH):

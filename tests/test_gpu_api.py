@@ -216,8 +216,10 @@ def test_rccl_through_the_c_abi_single_rank(gpu):
         pt.comm_reduce_radiance(3)                                 # bad root
     pt.sync()
     assert _bits_equal(pt.read_radiance(), ref)
+    assert pt.stats()["seconds_reduce"] > 0.0                      # the collective is event-timed on the context's stream (bench.py reports it per rank)
     pt.comm_destroy()
-    g = gpu.Group([0]).load_scene(gpu.scenes.cornell_box())
+    g = gpu.Group([0]).load_scene(gpu.scenes.cornell_box())        # ptc_group_scene_commit: described on device 0, one host build for the group
+    assert g.ctx(0).stats()["n_triangles"] == 12
     assert len(g) == 1 and _bits_equal(g.render(96, 64, 4, seed=6), ref)
     g.close()
     with pytest.raises(gpu.PtcError):

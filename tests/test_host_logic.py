@@ -85,7 +85,8 @@ def _canon(decoded):
 
 
 @pytest.mark.parametrize("builder", ["sah", "lbvh"])
-@pytest.mark.parametrize("name,kw", [("cornell", {}), ("sphere10k", {}), ("two_tris_sphere", {}), ("atrium", {"scale": 0.05}), ("atrium", {})])
+@pytest.mark.parametrize("name,kw", [("cornell", {}), ("sphere10k", {}), ("two_tris_sphere", {}), ("atrium", {"scale": 0.05}), ("atrium", {}),
+                                     ("textured_objects", {}), ("textured_atrium", {"scale": 0.05, "tex_size": 32, "env_size": (32, 16)})])
 def test_flatten_and_bvh_equal_oracle(ora, pbr, name, kw, builder):
     d = pbr.scenes.by_name(name, **kw)
     d.bvh_builder = builder
@@ -259,3 +260,30 @@ def test_lbvh_is_the_morton_radix_tree(ora, pbr):
             % os.path.dirname(os.path.dirname(pbr.__file__)))
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PTC_BVH="lbvh"), capture_output=True, text=True, check=True).stdout.split()
     assert out[0] == u_l.tobytes().hex()[:64] and int(out[1]) == u_l.shape[0]
+
+
+def test_material_classes_follow_the_texture_sets(ora, pbr):
+    """The class word of a triangle record (what k_shade sorts hits by): 0 untextured Lambert, 1 untextured GGX, 2 + set % 5 for textured
+    materials, a set being a distinct (colour, normal, metal-rough) triple numbered in material order.  Checked on the triangle records
+    of the product's tree dump and of the oracle's, against classes worked out here."""
+    d = pbr.scenes.textured_objects()
+    # materials: 0 (0,1,2) -> set 0; 1 (0,-1,-1) -> set 1; 2 untextured Lambert emitter (unused mesh dropped); 3 (-1,1,-1) -> set 2
+    from pbr_amd.scene import Material
+    d.materials.append(Material((0.5, 0.5, 0.5, 1.0), 0.0, 0.4, (0, 0, 0), 0, 1, 2))      # 4: same triple as material 0 -> set 0 again
+    d.materials.append(Material((0.5, 0.5, 0.5, 1.0), 0.3, 1.0))                            # 5: untextured GGX (metallic > 0)
+    d.materials.append(Material((0.5, 0.5, 0.5, 1.0), 0.0, 1.0))                            # 6: untextured Lambert
+    qv, qi = pbr.scenes._quad((-1, 3, -1), (1, 3, -1), (1, 3, 1), (-1, 3, 1))
+    from pbr_amd.scene import MeshDesc, InstanceDesc
+    for k, mat in enumerate((4, 5, 6)):
+        d.meshes.append(MeshDesc(qv, qi, mat))
+        d.instances.append(InstanceDesc(len(d.meshes) - 1, (3.0 * k, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0), (1.0, 1.0, 1.0)))
+    want = {0: 2, 1: 3, 3: 4, 4: 2, 5: 1, 6: 0}
+    pt = pbr.PathTracer(pbr.DEVICE_NONE).load_scene(d)
+    o = ora.Oracle().load_scene(d)
+    _, _, tri_mat = pt.flat_scene()
+    _, t2 = o.bvh()
+    prim = t2.view(np.uint32)[:, 3]
+    cls = t2.view(np.uint32)[:, 7]
+    assert len(prim) == len(tri_mat)
+    for p, c in zip(prim, cls):
+        assert c == want[int(tri_mat[p])], (p, tri_mat[p], c)

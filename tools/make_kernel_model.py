@@ -6,9 +6,21 @@ usage: tools/make_kernel_model.py gpurun_out/prof_TAG profiles/r02_kernel_model.
 FETCH_SIZE is in KiB and, on gfx950, tallies 128-byte requests at 64 bytes (MI355X_MICROARCH.md §HBM): it is doubled here; the
 correction is calibrated for wide streaming reads, not for 16-byte gathers, so the true read traffic of the trace kernels lies
 between 0.5x and 1x of `fetch_bytes` (stated in the output)."""
-import json, os, re, sys
+import hashlib, json, os, re, subprocess, sys
 
 prof, out = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "physically-based-renderer_amd", "csrc")
+
+
+def kernel_source_sha256():
+    """The recipe of csrc/Makefile's KERNEL_SHA: sha256 over pt_kernels.hip, pt_device.h, ptc_internal.h in that order."""
+    h = hashlib.sha256()
+    for f in ("pt_kernels.hip", "pt_device.h", "ptc_internal.h"):
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()
+
+
 pmc = json.load(open(os.path.join(prof, "pmc_summary.json")))
 bench = None
 for line in open(os.path.join(prof, "pmc1.log")):
@@ -19,7 +31,12 @@ lane1 = json.load(open(os.path.join(prof, "bench_lane1.json")))      # PTC_LANES
 K, W = bench["steps"], bench["warmup"]
 scale = (K + W) / K                                   # the counters cover warm-up + timed steps, the bench line the timed steps
 units = {"k_trace_closest": bench["kernels"]["k_trace_closest"], "k_trace_any": bench["kernels"]["k_trace_any"], "k_shade": bench["kernels"]["k_shade"]}
-model = {"source": f"{prof}: rocprofv3 --pmc passes of `bench.py --steps {K} --warmup {W}` ({bench['config']['workload']})",
+profiled_sha = bench.get("library", "").rsplit(" ", 1)[-1]                 # the library that ran under the profiler says what it was built from
+assert profiled_sha == kernel_source_sha256(), f"the profile was taken on kernels {profiled_sha[:12]}, the tree holds {kernel_source_sha256()[:12]}: profile again"
+commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
+dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", CSRC], capture_output=True, text=True).stdout.strip()
+model = {"git_commit": commit + ("+uncommitted csrc changes" if dirty else ""), "kernel_source_sha256": profiled_sha,
+         "source": f"{prof}: rocprofv3 --pmc passes of `bench.py --steps {K} --warmup {W}` ({bench['config']['workload']})",
          "fetch_note": "fetch bytes = FETCH_SIZE KiB x 1024 x 2 (gfx950 tallies 128-B requests at 64 B; calibrated for streaming reads, uncalibrated for 16-B gathers: true value between 0.5x and 1x)"}
 for kname, u in units.items():
     key = [k for k in pmc if kname in k and "<true" not in k]
@@ -39,6 +56,8 @@ for kname, u in units.items():
         "serialised_ms_per_launch": lane1["kernels"][kname]["avg_launch_ms"],
         "serialised_units_per_launch": lane1["kernels"][kname]["units_per_launch"],
         "gui_active_cycles_per_launch": p.get("GRBM_GUI_ACTIVE", 0) / 8.0 / p.get("dispatches", 1) if p.get("GRBM_GUI_ACTIVE") else None,
+        # VALU issue slots used per SIMD cycle: a wave64 instruction takes 2 cycles of a SIMD32; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        "valu_issue_duty_per_cycle": (p["SQ_INSTS_VALU"] * 2.0 / (1024.0 * p["GRBM_GUI_ACTIVE"] / 8.0)) if p.get("GRBM_GUI_ACTIVE") else None,
     }
 json.dump(model, open(out, "w"), indent=1)
 print(json.dumps(model, indent=1))
