@@ -144,6 +144,9 @@ def main():
             dist.barrier()              # nobody is still reading when rank 0 removes the file
         if td is not None:
             td.cleanup()
+    # scene dynamics: what a transform change costs (ptc_scene_refit of the unchanged scene re-computes and re-uploads exactly what a real one does)
+    pt.scene_refit()
+    refit_seconds = pt.stats()["seconds_refit"]
     K, W, S = args.steps, args.warmup, args.spp_per_step * (world if args.scaling == "weak" else 1)
     spp_total = (K + W) * S
     tile_count = world if world > 1 else max(1, args.rehearse_tiles)
@@ -347,6 +350,7 @@ def main():
             "rehearsal": (f"tile rank 0 of {tile_count} on one GPU: value is that rank's share of the frame, not the metric" if tile_count != world else None),
             "whole_path_algorithmic_GBs": tot["algorithmic_bytes"] / dt / 1e9,
             "scene_commit_seconds": s1.get("seconds_commit"),    # flatten + SAH BVH + upload, once per scene, outside the timed region
+            "scene_refit_seconds": refit_seconds,                # ptc_scene_refit: flatten + refit of the committed tree + upload of what moved
             "seconds": {"wall": dt, "trace_closest": d["seconds_trace_closest"], "trace_any": d["seconds_trace_any"], "shade": d["seconds_shade"],
                         "batches": d.get("seconds_render", 0.0)},
             "per_path": {"segments": tot["segments"] / paths, "shadow_rays": tot["shadow_rays"] / paths,

@@ -84,6 +84,7 @@ typedef struct ptc_stats {
   double seconds_shade;
   double seconds_commit;      /* flatten + BVH build + upload                               */
   double seconds_reduce;      /* HIP-event time of ptc_comm_reduce_radiance on this rank's stream (includes waiting for the slowest rank) */
+  double seconds_refit;       /* the last ptc_scene_refit: re-flatten + refit of the committed tree + upload                */
   uint32_t launches_trace_closest;
   uint32_t launches_trace_any;
   uint32_t n_triangles;
@@ -139,6 +140,21 @@ int ptc_add_instance(ptc_ctx*, int mesh, const float t[3], const float q_wxyz[4]
 /* makeModelPushConstant(glm::mat4x4 model) (ModelPushConstant.hpp:33-38): an instance by its column-major
  * 4x4 model matrix (used by the glTF loader, which composes parent transforms). */
 int ptc_add_instance_matrix(ptc_ctx*, int mesh, const float model[16]);
+
+/* Scene dynamics.  The viewer turns its nodes every frame (src/gltf_viewer/App.cpp:306-313) and draws each node with its own
+ * model matrix (the push constant of PbrRenderSystem.cpp:444-448), so a transform change costs the reference nothing.  Here the
+ * triangles live in one world-space tree, so a change is two steps: ptc_update_instance / ptc_update_instance_matrix give instance
+ * `instance` (the value ptc_add_instance* returned) a new transform, any number of them; ptc_scene_refit then re-flattens the
+ * vertices and REFITS the committed tree — same topology, same slots, same layout; every box re-computed bottom-up and re-quantised,
+ * triangle records, shading records and emitters rewritten — and overwrites those arrays on the device in place (textures,
+ * environment and materials are not touched).  No re-build: 250 k triangles refit in a fraction of ptc_scene_commit's time
+ * (ptc_stats.seconds_refit beside seconds_commit).  A refitted tree renders the same image as a fresh commit of the same transforms
+ * (closest hit = minimum of (t, primitive id), whatever the tree); its traversal counters are those of the refitted tree, and the
+ * oracle refits the same way.  Meshes, materials or the number of instances cannot change this way: that is a new scene.
+ * A frame in progress ends (call ptc_frame_begin again).  PTC_E_STATE before the first ptc_scene_commit. */
+int ptc_update_instance(ptc_ctx*, int instance, const float t[3], const float q_wxyz[4], const float s[3]);
+int ptc_update_instance_matrix(ptc_ctx*, int instance, const float model[16]);
+int ptc_scene_refit(ptc_ctx*);
 
 /* pbr::makeCameraData (engine/pbr/CameraData.hpp:22-32): lookAtRH(pos,target,up=(0,-1,0)),
  * perspective fovY/aspect; y-down un-flipped viewport (PbrRenderSystem.cpp:425-430). */

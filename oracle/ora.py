@@ -59,6 +59,9 @@ def lib():
         L.ora_atan2f.argtypes = [C.c_float, C.c_float]
         L.ora_atan2f.restype = C.c_float
         L.ora_add_instance.argtypes = [vp, C.c_int, fp, fp, fp]
+        L.ora_update_instance.argtypes = [vp, C.c_int, fp, fp, fp]
+        L.ora_update_instance_matrix.argtypes = [vp, C.c_int, fp]
+        L.ora_scene_refit.argtypes = [vp]
         L.ora_add_instance_matrix.argtypes = [vp, C.c_int, fp]
         L.ora_set_camera.argtypes = [vp, fp, fp, C.c_float, C.c_float]
         L.ora_scene_commit.argtypes = [vp]
@@ -148,6 +151,17 @@ class Oracle:
         c = desc.camera
         self._ck(L.ora_set_camera(h, _f(c.position)[1], _f(c.target)[1], c.fov_y, c.aspect))
         self._ck(L.ora_scene_commit(h))
+        return self
+
+    def update_instance(self, instance, t=None, q_wxyz=None, s=None, matrix=None):
+        if matrix is not None:
+            self._ck(self._L.ora_update_instance_matrix(self._h, instance, _f(np.asarray(matrix, np.float32).reshape(16))[1]))
+        else:
+            self._ck(self._L.ora_update_instance(self._h, instance, _f(t)[1], _f(q_wxyz)[1], _f(s)[1]))
+        return self
+
+    def scene_refit(self):
+        self._ck(self._L.ora_scene_refit(self._h))
         return self
 
     def render(self, w, h, spp, seed=1, max_bounces=8, integrator=0, tile_rank=0, tile_count=1, n_threads=0):

@@ -708,6 +708,29 @@ static void dp_forest(const ora_ctx* c, const dp_t* dp, const node_t* parent, in
   dp_forest(c, dp, nd, 1, min7(i - kk), list, n);
 }
 
+/* Origin and quantised planes of a wide node from the exact boxes of its children (by slot; used[s] = slot s holds a child): the origin on
+ * the 16-bit scene grid, rounded down (the largest q with fmaf(q, step, lo) <= the node's lower bound), then quantize_axis per axis. */
+static void quantise_wnode(const ora_ctx* c, wnode_t* w, float blo[ORA_W][3], float bhi[ORA_W][3], const int used[ORA_W]) {
+  for (int k = 0; k < 3; ++k) {
+    float clo[ORA_W], chi[ORA_W]; uint32_t qlo[ORA_W], qhi[ORA_W]; int sl_of[ORA_W], n = 0;
+    float nlo = INFINITY, nhi = -INFINITY;
+    for (int sl = 0; sl < ORA_W; ++sl) {
+      if (!used[sl]) continue;
+      sl_of[n] = sl; clo[n] = blo[sl][k]; chi[n] = bhi[sl][k];
+      nlo = fmin2(nlo, clo[n]); nhi = fmax2(nhi, chi[n]); ++n;
+    }
+    float fq = floorf((nlo - c->scene_lo[k]) / c->grid_step[k]);
+    if (fq < 0.0f) fq = 0.0f;
+    if (fq > 65535.0f) fq = 65535.0f;
+    uint32_t oq = (uint32_t)fq;
+    while (oq > 0u && fmaf((float)oq, c->grid_step[k], c->scene_lo[k]) > nlo) --oq;
+    w->oq[k] = oq; w->org[k] = fmaf((float)oq, c->grid_step[k], c->scene_lo[k]);
+    quantize_axis(clo, chi, n, w->org[k], nhi, &w->e[k], qlo, qhi);
+    for (int sl = 0; sl < ORA_W; ++sl) { w->qlo[k][sl] = 255; w->qhi[k][sl] = 0; }
+    for (int i = 0; i < n; ++i) { w->qlo[k][sl_of[i]] = qlo[i]; w->qhi[k][sl_of[i]] = qhi[i]; }
+  }
+}
+
 static int32_t widen(ora_ctx* c, const dp_t* dp, int32_t bin_idx, uint32_t depth, uint32_t* next, uint32_t* maxd) {
   uint32_t me = (*next)++;
   if (depth > *maxd) *maxd = depth;
@@ -726,19 +749,10 @@ static int32_t widen(ora_ctx* c, const dp_t* dp, int32_t bin_idx, uint32_t depth
   }
   int slot_of[ORA_W];
   assign_slots(list, n, nlo3, nhi3, slot_of);
-  for (int k = 0; k < 3; ++k) {
-    float clo[ORA_W], chi[ORA_W]; uint32_t qlo[ORA_W], qhi[ORA_W];
-    for (int i = 0; i < n; ++i) { clo[i] = list[i].lo[k]; chi[i] = list[i].hi[k]; }
-    /* origin on the 16-bit scene grid, rounded down: the largest q with fmaf(q, step, lo) <= the node's lower bound */
-    float fq = floorf((nlo3[k] - c->scene_lo[k]) / c->grid_step[k]);
-    if (fq < 0.0f) fq = 0.0f;
-    if (fq > 65535.0f) fq = 65535.0f;
-    uint32_t oq = (uint32_t)fq;
-    while (oq > 0u && fmaf((float)oq, c->grid_step[k], c->scene_lo[k]) > nlo3[k]) --oq;
-    w.oq[k] = oq; w.org[k] = fmaf((float)oq, c->grid_step[k], c->scene_lo[k]);
-    quantize_axis(clo, chi, n, w.org[k], nhi3[k], &w.e[k], qlo, qhi);
-    for (int sl = 0; sl < ORA_W; ++sl) { w.qlo[k][sl] = 255; w.qhi[k][sl] = 0; }
-    for (int i = 0; i < n; ++i) { w.qlo[k][slot_of[i]] = qlo[i]; w.qhi[k][slot_of[i]] = qhi[i]; }
+  {
+    float blo[ORA_W][3], bhi[ORA_W][3]; int used[ORA_W] = {0};
+    for (int i = 0; i < n; ++i) { used[slot_of[i]] = 1; memcpy(blo[slot_of[i]], list[i].lo, 12); memcpy(bhi[slot_of[i]], list[i].hi, 12); }
+    quantise_wnode(c, &w, blo, bhi, used);
   }
   /* recurse in slot order */
   int child_of_slot[ORA_W];
@@ -753,10 +767,71 @@ static int32_t widen(ora_ctx* c, const dp_t* dp, int32_t bin_idx, uint32_t depth
   return (int32_t)me;
 }
 
-int ora_scene_commit(ora_ctx* c) {
-  free_committed(c);
-  if (!c->have_cam) return fail(c, "scene_commit: no camera");
-  if (c->n_insts == 0) return fail(c, "scene_commit: no instances");
+/* triangle boxes; scene bounds, ray offset and the 16-bit origin grid that follow from them */
+static void triangle_boxes_and_bounds(ora_ctx* c, float* tlo, float* thi) {
+  uint32_t n = c->n_tris;
+  for (int k = 0; k < 3; ++k) { c->scene_lo[k] = INFINITY; c->scene_hi[k] = -INFINITY; }
+  for (uint32_t p = 0; p < n; ++p) {
+    for (int k = 0; k < 3; ++k) {
+      float a = c->wv[c->widx[p * 3 + 0]].position[k], b = c->wv[c->widx[p * 3 + 1]].position[k], d = c->wv[c->widx[p * 3 + 2]].position[k];
+      float lo = fmin2(fmin2(a, b), d), hi = fmax2(fmax2(a, b), d);
+      tlo[p * 3 + k] = lo; thi[p * 3 + k] = hi;
+      c->scene_lo[k] = fmin2(c->scene_lo[k], lo); c->scene_hi[k] = fmax2(c->scene_hi[k], hi);
+    }
+  }
+  float diag = fmax2(fmax2(c->scene_hi[0] - c->scene_lo[0], c->scene_hi[1] - c->scene_lo[1]), c->scene_hi[2] - c->scene_lo[2]);
+  c->ray_eps = 1e-4f * fmax2(diag, 1e-6f);
+  for (int k = 0; k < 3; ++k) { float st = (c->scene_hi[k] - c->scene_lo[k]) / 65535.0f; c->grid_step[k] = st > 0.0f ? st : 1.0f; }
+}
+/* (v0, e1, e2) per sorted position */
+static void sorted_triangles(ora_ctx* c) {
+  uint32_t n = c->n_tris;
+  free(c->tv0); free(c->te1); free(c->te2);
+  c->tv0 = (v3*)malloc(sizeof(v3) * n); c->te1 = (v3*)malloc(sizeof(v3) * n); c->te2 = (v3*)malloc(sizeof(v3) * n);
+  for (uint32_t i = 0; i < n; ++i) {
+    uint32_t p = c->order[i];
+    const float* a = c->wv[c->widx[p * 3 + 0]].position; const float* bq = c->wv[c->widx[p * 3 + 1]].position; const float* d = c->wv[c->widx[p * 3 + 2]].position;
+    c->tv0[i] = V3(a[0], a[1], a[2]);
+    c->te1[i] = V3(bq[0] - a[0], bq[1] - a[1], bq[2] - a[2]);
+    c->te2[i] = V3(d[0] - a[0], d[1] - a[1], d[2] - a[2]);
+  }
+}
+/* P7: emitter table in original primitive order, power pmf/cdf */
+static void emitter_table(ora_ctx* c) {
+  uint32_t n = c->n_tris;
+  free(c->prim_light); free(c->lights); free(c->cdf);
+  c->prim_light = (int32_t*)malloc(4u * n);
+  uint32_t nl = 0;
+  for (uint32_t p = 0; p < n; ++p) {
+    const material_t* m = &c->mats[c->tri_mat[p]];
+    c->prim_light[p] = -1;
+    if (m->emissive[0] > 0.0f || m->emissive[1] > 0.0f || m->emissive[2] > 0.0f) nl++;
+  }
+  c->lights = (light_t*)malloc(sizeof(light_t) * (nl ? nl : 1)); c->cdf = (float*)malloc(4u * (nl ? nl : 1));
+  nl = 0; float total = 0.0f;
+  for (uint32_t p = 0; p < n; ++p) {
+    const material_t* m = &c->mats[c->tri_mat[p]];
+    if (!(m->emissive[0] > 0.0f || m->emissive[1] > 0.0f || m->emissive[2] > 0.0f)) continue;
+    const float* a = c->wv[c->widx[p * 3 + 0]].position; const float* bb = c->wv[c->widx[p * 3 + 1]].position; const float* d = c->wv[c->widx[p * 3 + 2]].position;
+    light_t L; L.v0 = V3(a[0], a[1], a[2]);
+    L.e1 = V3(bb[0] - a[0], bb[1] - a[1], bb[2] - a[2]); L.e2 = V3(d[0] - a[0], d[1] - a[1], d[2] - a[2]);
+    v3 cr = cross3(L.e1, L.e2); float len = sqrtf(dot3(cr, cr));
+    L.area = 0.5f * len; L.Le = V3(m->emissive[0], m->emissive[1], m->emissive[2]);
+    float wgt = L.area * luminance(L.Le);
+    if (!(wgt > 0.0f)) continue;
+    L.ng = vscale(cr, 1.0f / len); L.pmf = wgt; L.prim = p;
+    c->prim_light[p] = (int32_t)nl; c->lights[nl++] = L; total += wgt;
+  }
+  c->n_lights = nl;
+  float run = 0.0f;
+  for (uint32_t i = 0; i < nl; ++i) { run += c->lights[i].pmf; c->cdf[i] = run / total; c->lights[i].pmf = c->lights[i].pmf / total; }
+  if (nl) c->cdf[nl - 1] = 1.0f;
+}
+/* R2/R3/R4: instances in insertion order, triangles in index order -> world-space vertices (c->wv, c->wbt), indices, materials.
+ * (Re)allocates the arrays; ora_scene_refit runs it again after the instances' matrices changed. */
+static int flatten(ora_ctx* c) {
+  free(c->wv); free(c->wbt); free(c->widx); free(c->tri_mat);
+  c->wv = NULL; c->wbt = NULL; c->widx = NULL; c->tri_mat = NULL;
   /* R2/R3/R4 flatten: instances in insertion order, triangles in index order. */
   uint64_t nv = 0, nt = 0;
   for (int i = 0; i < c->n_insts; ++i) { nv += c->meshes[c->insts[i].mesh].nv; nt += c->meshes[c->insts[i].mesh].ni / 3; }
@@ -790,23 +865,19 @@ int ora_scene_commit(ora_ctx* c) {
     }
     vb += m->nv; tb += m->ni / 3;
   }
-  uint32_t n = c->n_tris;
   for (uint32_t i = 0; i < c->n_wv; ++i) for (int k = 0; k < 3; ++k)
     if (!isfinite(c->wv[i].position[k])) return fail(c, "scene_commit: non-finite vertex position after the instance transform");
-  /* triangle boxes, scene bounds */
+  return 0;
+}
+
+int ora_scene_commit(ora_ctx* c) {
+  free_committed(c);
+  if (!c->have_cam) return fail(c, "scene_commit: no camera");
+  if (c->n_insts == 0) return fail(c, "scene_commit: no instances");
+  { int rf = flatten(c); if (rf) return rf; }
+  uint32_t n = c->n_tris;
   float* tlo = (float*)malloc(12u * n); float* thi = (float*)malloc(12u * n);
-  for (int k = 0; k < 3; ++k) { c->scene_lo[k] = INFINITY; c->scene_hi[k] = -INFINITY; }
-  for (uint32_t p = 0; p < n; ++p) {
-    for (int k = 0; k < 3; ++k) {
-      float a = c->wv[c->widx[p * 3 + 0]].position[k], b = c->wv[c->widx[p * 3 + 1]].position[k], d = c->wv[c->widx[p * 3 + 2]].position[k];
-      float lo = fmin2(fmin2(a, b), d), hi = fmax2(fmax2(a, b), d);
-      tlo[p * 3 + k] = lo; thi[p * 3 + k] = hi;
-      c->scene_lo[k] = fmin2(c->scene_lo[k], lo); c->scene_hi[k] = fmax2(c->scene_hi[k], hi);
-    }
-  }
-  float diag = fmax2(fmax2(c->scene_hi[0] - c->scene_lo[0], c->scene_hi[1] - c->scene_lo[1]), c->scene_hi[2] - c->scene_lo[2]);
-  c->ray_eps = 1e-4f * fmax2(diag, 1e-6f);
-  for (int k = 0; k < 3; ++k) { float st = (c->scene_hi[k] - c->scene_lo[k]) / 65535.0f; c->grid_step[k] = st > 0.0f ? st : 1.0f; }
+  triangle_boxes_and_bounds(c, tlo, thi);
   c->order = (uint32_t*)malloc(4u * n);
   for (uint32_t i = 0; i < n; ++i) c->order[i] = i;      /* initial order: original primitive order */
   uint64_t* codes = c->bvh_builder == 1 ? morton_order(c, tlo, thi, n) : NULL;
@@ -821,14 +892,7 @@ int ora_scene_commit(ora_ctx* c) {
     build_node(&b, 0, n - 1, 0);
   }
   c->n_nodes = b.next; c->max_depth = b.depth_max;
-  c->tv0 = (v3*)malloc(sizeof(v3) * n); c->te1 = (v3*)malloc(sizeof(v3) * n); c->te2 = (v3*)malloc(sizeof(v3) * n);
-  for (uint32_t i = 0; i < n; ++i) {
-    uint32_t p = c->order[i];
-    const float* a = c->wv[c->widx[p * 3 + 0]].position; const float* bq = c->wv[c->widx[p * 3 + 1]].position; const float* d = c->wv[c->widx[p * 3 + 2]].position;
-    c->tv0[i] = V3(a[0], a[1], a[2]);
-    c->te1[i] = V3(bq[0] - a[0], bq[1] - a[1], bq[2] - a[2]);
-    c->te2[i] = V3(d[0] - a[0], d[1] - a[1], d[2] - a[2]);
-  }
+  sorted_triangles(c);
   c->wnodes = (wnode_t*)calloc(c->n_nodes, sizeof(wnode_t));
   {
     dp_t* dp = (dp_t*)calloc(c->n_nodes, sizeof(dp_t));
@@ -839,35 +903,72 @@ int ora_scene_commit(ora_ctx* c) {
     free(dp);
   }
   free(tlo); free(thi); free(codes);
-  /* P7: emitter table in original primitive order, power pmf/cdf */
-  c->prim_light = (int32_t*)malloc(4u * n);
-  uint32_t nl = 0;
-  for (uint32_t p = 0; p < n; ++p) {
-    const material_t* m = &c->mats[c->tri_mat[p]];
-    c->prim_light[p] = -1;
-    if (m->emissive[0] > 0.0f || m->emissive[1] > 0.0f || m->emissive[2] > 0.0f) nl++;
-  }
-  c->lights = (light_t*)malloc(sizeof(light_t) * (nl ? nl : 1)); c->cdf = (float*)malloc(4u * (nl ? nl : 1));
-  nl = 0; float total = 0.0f;
-  for (uint32_t p = 0; p < n; ++p) {
-    const material_t* m = &c->mats[c->tri_mat[p]];
-    if (!(m->emissive[0] > 0.0f || m->emissive[1] > 0.0f || m->emissive[2] > 0.0f)) continue;
-    const float* a = c->wv[c->widx[p * 3 + 0]].position; const float* bb = c->wv[c->widx[p * 3 + 1]].position; const float* d = c->wv[c->widx[p * 3 + 2]].position;
-    light_t L; L.v0 = V3(a[0], a[1], a[2]);
-    L.e1 = V3(bb[0] - a[0], bb[1] - a[1], bb[2] - a[2]); L.e2 = V3(d[0] - a[0], d[1] - a[1], d[2] - a[2]);
-    v3 cr = cross3(L.e1, L.e2); float len = sqrtf(dot3(cr, cr));
-    L.area = 0.5f * len; L.Le = V3(m->emissive[0], m->emissive[1], m->emissive[2]);
-    float wgt = L.area * luminance(L.Le);
-    if (!(wgt > 0.0f)) continue;
-    L.ng = vscale(cr, 1.0f / len); L.pmf = wgt; L.prim = p;
-    c->prim_light[p] = (int32_t)nl; c->lights[nl++] = L; total += wgt;
-  }
-  c->n_lights = nl;
-  float run = 0.0f;
-  for (uint32_t i = 0; i < nl; ++i) { run += c->lights[i].pmf; c->cdf[i] = run / total; c->lights[i].pmf = c->lights[i].pmf / total; }
-  if (nl) c->cdf[nl - 1] = 1.0f;
+  emitter_table(c);
+  uint32_t nl = c->n_lights;
   memset(&c->stats, 0, sizeof c->stats);
   c->stats.n_triangles = n; c->stats.n_bvh_nodes = c->n_wnodes; c->stats.n_emitters = nl; c->stats.bvh_max_depth = c->wdepth;
+  c->committed = 1;
+  return 0;
+}
+
+/* ---- scene dynamics: new transforms for committed instances, then a REFIT of the committed tree (ptc.h: ptc_update_instance,
+ * ptc_scene_refit).  Same order of the triangles, same binary tree, same wide nodes and slots; what follows the vertices is recomputed
+ * with the arithmetic of the commit: flatten, triangle boxes, scene box (ray offset, origin grid), the exact box of every child of every
+ * wide node (bottom-up: a leaf child's box is that of its triangles, an interior child's the union of ITS children's boxes — the box of
+ * the binary subtree it stands for), quantised planes, sorted triangles, emitters. */
+int ora_update_instance_matrix(ora_ctx* c, int instance, const float m[16]) {
+  if (!m) return fail(c, "update_instance_matrix: null pointer");
+  if (instance < 0 || instance >= c->n_insts) return fail(c, "update_instance: instance out of range");
+  memcpy(c->insts[instance].m, m, 64);
+  return 0;
+}
+int ora_update_instance(ora_ctx* c, int instance, const float t[3], const float q[4], const float s[3]) {
+  if (!t || !q || !s) return fail(c, "update_instance: null pointer");
+  if (instance < 0 || instance >= c->n_insts) return fail(c, "update_instance: instance out of range");
+  float N[9];
+  make_model(t, q, s, c->insts[instance].m, N);
+  return 0;
+}
+int ora_scene_refit(ora_ctx* c) {
+  if (!c->committed) return fail(c, "scene_refit: scene not committed");
+  const uint32_t n_before = c->n_tris, nv_before = c->n_wv;
+  c->committed = 0;
+  { int rf = flatten(c); if (rf) return rf; }
+  if (c->n_tris != n_before || c->n_wv != nv_before) return fail(c, "scene_refit: the scene's meshes or instances changed since the commit (only transforms may)");
+  uint32_t n = c->n_tris;
+  float* tlo = (float*)malloc(12u * n); float* thi = (float*)malloc(12u * n);
+  triangle_boxes_and_bounds(c, tlo, thi);
+  sorted_triangles(c);
+  /* exact child boxes, bottom-up: widen numbers a node before its children, so a child's index is larger than its parent's */
+  float (*xlo)[ORA_W][3] = malloc(sizeof(float[ORA_W][3]) * c->n_wnodes);
+  float (*xhi)[ORA_W][3] = malloc(sizeof(float[ORA_W][3]) * c->n_wnodes);
+  for (uint32_t i = c->n_wnodes; i-- > 0;) {
+    wnode_t* w = &c->wnodes[i];
+    int used[ORA_W];
+    for (int sl = 0; sl < ORA_W; ++sl) {
+      used[sl] = w->code[sl] != ORA_EMPTY;
+      if (!used[sl]) continue;
+      float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+      if (w->code[sl] < 0) {
+        uint32_t code = (uint32_t)~w->code[sl], first = code & 0x0fffffffu, count = (code >> 28) + 1u;
+        for (uint32_t t = first; t < first + count; ++t) {
+          uint32_t p = c->order[t];
+          for (int k = 0; k < 3; ++k) { lo[k] = fmin2(lo[k], tlo[p * 3 + k]); hi[k] = fmax2(hi[k], thi[p * 3 + k]); }
+        }
+      } else {
+        const wnode_t* ch = &c->wnodes[w->code[sl]];
+        for (int s2 = 0; s2 < ORA_W; ++s2) {
+          if (ch->code[s2] == ORA_EMPTY) continue;
+          for (int k = 0; k < 3; ++k) { lo[k] = fmin2(lo[k], xlo[w->code[sl]][s2][k]); hi[k] = fmax2(hi[k], xhi[w->code[sl]][s2][k]); }
+        }
+      }
+      memcpy(xlo[i][sl], lo, 12); memcpy(xhi[i][sl], hi, 12);
+    }
+    quantise_wnode(c, w, xlo[i], xhi[i], used);
+  }
+  free(xlo); free(xhi); free(tlo); free(thi);
+  emitter_table(c);
+  c->stats.n_emitters = c->n_lights;
   c->committed = 1;
   return 0;
 }

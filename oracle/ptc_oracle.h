@@ -43,6 +43,11 @@ int ora_set_env_latlong_rgb32f(ora_ctx*, const float* rgb, int w, int h);   /* N
 int ora_set_texture_filter(ora_ctx*, int mode);                              /* 0 nearest (default, the reference's), 1 bilinear */
 int ora_set_bvh_builder(ora_ctx*, int mode);                                 /* 0 binned SAH (default), 1 Morton-order LBVH; reset by scene_begin */
 int ora_scene_commit(ora_ctx*);
+/* new transform for a committed instance (the id ora_add_instance* returned), then a refit of the committed tree: same topology and slots,
+ * every box, record and emitter recomputed from the moved vertices (mirrors ptc_update_instance / ptc_scene_refit) */
+int ora_update_instance(ora_ctx*, int instance, const float t[3], const float q_wxyz[4], const float s[3]);
+int ora_update_instance_matrix(ora_ctx*, int instance, const float model16[16]);
+int ora_scene_refit(ora_ctx*);
 
 /* Renders into out_rgba (w*h*4 floats, y-down).  Pixels not owned by (tile_rank, tile_count)
  * stay 0.  n_threads <= 0 means "all online cores".  integrator: 0 path tracer, 1 raster-compat (the reference's

@@ -926,21 +926,33 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(const De
       }
       if (!nonempty) break;
     }
-    // ---- take a batch: 64 slots of one class, or what is left of a class at the end of the segment ----
-    const uint32_t c = (uint32_t)__builtin_ctz(ready ? ready : nonempty);
-    const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)fillv, (int)c);
-    const uint32_t take = f < 64u ? f : 64u, rest = f - take;
+    // ---- take a batch: 64 slots of one class; at the end of the segment what is left in ALL rings goes out in mixed batches (the shading
+    // code does not need a uniform class, it is merely faster with one), so that a segment ends with one partial batch, not one per class ----
+    bool valid; uint32_t item = 0u;
     wave_lds_sync();
-    const bool valid = lane < take;
-    const uint32_t item = valid ? ring[c * SHADE_RING + lane] : 0u;
-    if (rest) {
-      const uint32_t mv = lane < rest ? ring[c * SHADE_RING + 64u + lane] : 0u;
-      wave_lds_sync();
-      if (lane < rest) ring[c * SHADE_RING + lane] = mv;
+    if (ready) {
+      const uint32_t c = (uint32_t)__builtin_ctz(ready);
+      const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)fillv, (int)c);     // 64 <= f <= 127
+      const uint32_t rest = f - 64u;
+      valid = true;
+      item = ring[c * SHADE_RING + rest + lane];                                      // the 64 youngest: nothing has to move
+      if (lane == c) fillv = rest;
+      ready &= ~(1u << c);
+      if (!rest) nonempty &= ~(1u << c);
+    } else {
+      uint32_t off = 0, left = nonempty;
+      valid = false;
+      while (left && off < 64u) {
+        const uint32_t c = (uint32_t)__builtin_ctz(left);
+        const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)fillv, (int)c);   // 1 <= f <= 63
+        const uint32_t take = f < 64u - off ? f : 64u - off;
+        if (lane >= off && lane < off + take) { item = ring[c * SHADE_RING + f - take + (lane - off)]; valid = true; }
+        if (lane == c) fillv = f - take;
+        if (f == take) nonempty &= ~(1u << c);
+        left &= ~(1u << c);
+        off += take;
+      }
     }
-    if (lane == c) fillv = rest;
-    ready &= ~(1u << c);
-    if (!rest) nonempty &= ~(1u << c);
     const uint32_t slot = base + item;
     SSTAMP(t_front);
 

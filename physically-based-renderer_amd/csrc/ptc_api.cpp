@@ -575,6 +575,61 @@ int ptc_add_instance_matrix(ptc_ctx* c, int mesh, const float model[16]) {
   return (int)c->insts.size() - 1;
 }
 
+namespace { int commit_upload(ptc_ctx* c, std::chrono::steady_clock::time_point t0); }
+
+int ptc_update_instance_matrix(ptc_ctx* c, int instance, const float model[16]) {
+  if (!c) return PTC_E_ARG;
+  if (!model) return fail(c, PTC_E_ARG, "update_instance_matrix: null pointer");
+  if (instance < 0 || instance >= (int)c->insts.size()) return fail(c, PTC_E_ARG, "update_instance: instance out of range");
+  std::memcpy(c->insts[(size_t)instance].m, model, 64);
+  return PTC_OK;
+}
+
+int ptc_update_instance(ptc_ctx* c, int instance, const float t[3], const float q_wxyz[4], const float s[3]) {
+  if (!c) return PTC_E_ARG;
+  if (!t || !q_wxyz || !s) return fail(c, PTC_E_ARG, "update_instance: null pointer");
+  if (instance < 0 || instance >= (int)c->insts.size()) return fail(c, PTC_E_ARG, "update_instance: instance out of range");
+  ptc_trs_to_matrix(t, q_wxyz, s, c->insts[(size_t)instance].m);
+  return PTC_OK;
+}
+
+int ptc_scene_refit(ptc_ctx* c) {
+  if (!c) return PTC_E_ARG;
+  if (!c->committed) return fail(c, PTC_E_STATE, "scene_refit: scene not committed");
+  if (c->device >= 0) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    { int rf = flush(c); if (rf) return rf; }
+    { int rs = sync_all_lanes(c); if (rs) return rs; }
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  if (c->built.use_count() > 1) c->built = std::make_shared<HostBuilt>(*c->built);      // a group shares one build: this context now gets its own
+  HostBuilt& B = *c->built;
+  const size_t n_recs = B.recs.size(), n_shade = B.shade.size(), n_lights = B.lights.size(), n_cdf = B.cdf.size();
+  const std::string e = ptc_refit_scene(c->mats, c->meshes, c->insts, c->texs, c->env, B);
+  if (!e.empty()) return fail(c, PTC_E_STATE, e);
+  c->in_frame = false; c->pending = 0;
+  if (c->device >= 0) {
+    if (B.recs.size() != n_recs || B.shade.size() != n_shade || B.lights.size() != n_lights || B.cdf.size() != n_cdf) {
+      int rc = commit_upload(c, t0);                   // an emitter appeared or vanished (degenerate scale): the tables change size, upload everything
+      if (rc) return rc;
+    } else {
+      // same sizes: overwrite in place what depends on the vertex positions; textures, environment and materials stay where they are
+      HIP_TRY(c, hipMemcpy((void*)c->dsc.recs, B.recs.data(), B.recs.size() * 4, hipMemcpyHostToDevice));
+      HIP_TRY(c, hipMemcpy((void*)c->dsc.shade, B.shade.data(), B.shade.size() * 4, hipMemcpyHostToDevice));
+      HIP_TRY(c, hipMemcpy((void*)c->dsc.lights, B.lights.data(), B.lights.size() * 4, hipMemcpyHostToDevice));
+      HIP_TRY(c, hipMemcpy((void*)c->dsc.cdf, B.cdf.data(), B.cdf.size() * 4, hipMemcpyHostToDevice));
+      c->dsc.ray_eps = B.ray_eps; c->dsc.n_lights = B.n_lights;
+      for (int k = 0; k < 3; ++k) { c->dsc.grid_lo[k] = B.grid_lo[k]; c->dsc.grid_step[k] = B.grid_step[k]; }
+      for (int l = 0; l < c->n_lanes; ++l) {
+        const DevScene ds = lane_scene(c, l);
+        HIP_TRY(c, hipMemcpy(c->lanes[(size_t)l].d_scene, &ds, sizeof ds, hipMemcpyHostToDevice));
+      }
+    }
+  }
+  c->stats.seconds_refit = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return PTC_OK;
+}
+
 int ptc_set_camera(ptc_ctx* c, const float pos[3], const float target[3], float fov_y, float aspect) {
   if (!c) return PTC_E_ARG;
   if (!pos || !target) return fail(c, PTC_E_ARG, "set_camera: null pointer");
@@ -725,7 +780,7 @@ int ptc_frame_begin(ptc_ctx* c, int w, int h, int spp_total, uint64_t seed, int 
   collect_times(c, true);      // all lanes are idle: every span is complete; the previous frame's times are dropped below
   ptc_stats keep = c->stats;
   std::memset(&c->stats, 0, sizeof c->stats);
-  c->stats.seconds_commit = keep.seconds_commit; c->stats.n_triangles = keep.n_triangles; c->stats.n_bvh_nodes = keep.n_bvh_nodes;
+  c->stats.seconds_commit = keep.seconds_commit; c->stats.seconds_refit = keep.seconds_refit; c->stats.n_triangles = keep.n_triangles; c->stats.n_bvh_nodes = keep.n_bvh_nodes;
   c->stats.n_emitters = keep.n_emitters; c->stats.bvh_max_depth = keep.bvh_max_depth;
   c->in_frame = true;
   return PTC_OK;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -154,12 +155,16 @@ struct HostBuilt {
   std::vector<float> cdf;
   uint32_t n_nodes = 0, n_tris = 0, n_tri_records = 0, n_lights = 0, max_depth = 0, n_units = 0, n_lds_units = 0;
   float ray_eps = 0.0f;
+  std::shared_ptr<void> topology;   // what ptc_refit_scene keeps of the build (ptc_scene.cpp: Topology)
 };
 
 // returns empty string on success, else the error text
 std::string ptc_build_scene(const std::vector<HostMaterial>&, const std::vector<HostMesh>&, const std::vector<HostInstance>&,
                             const std::vector<HostTexture>&, const HostEnv&, uint32_t toplet_budget, int bvh_builder /* PTC_BVH_* */,
                             HostBuilt& out);
+// the instances' matrices changed since ptc_build_scene filled `out`: same tree, new boxes / records (ptc_scene.cpp)
+std::string ptc_refit_scene(const std::vector<HostMaterial>&, const std::vector<HostMesh>&, const std::vector<HostInstance>&,
+                            const std::vector<HostTexture>&, const HostEnv&, HostBuilt& out);
 void ptc_trs_to_matrix(const float t[3], const float q_wxyz[4], const float s[3], float m16[16]);
 void ptc_make_camera(const float pos[3], const float target[3], float fov, float aspect, DevCamera& cam);
 // pixels owned by (rank,count) in tile-Morton order

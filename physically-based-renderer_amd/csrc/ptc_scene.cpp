@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <memory>
 
 namespace {
 
@@ -223,6 +224,24 @@ void build_split_tree(const std::vector<Box>& tbox, std::vector<uint32_t>& ord, 
 
 inline int32_t leaf_code(uint32_t first, uint32_t count) { return (int32_t) ~(first | ((count - 1u) << 28)); }
 
+// ---- what a refit keeps (HostBuilt::topology): the order of the triangles, the binary tree they were split into, which of its
+// subtrees the 8-wide nodes took as children and in which slots, and where every node and children block lies in the unit array.
+// ptc_refit_scene recomputes everything that depends on vertex positions — boxes, quantised planes, triangle and shading records, emitters —
+// and leaves these alone: the tree keeps its shape and its layout, so the new unit array has the size of the old one.
+struct WChild { bool leaf; uint32_t lo, hi; int32_t radix; Box box; };
+struct Wide { WChild slot[kWide]; bool used[kWide]; int n; };
+struct Slot { int32_t radix; uint32_t depth; };
+struct Topology {
+  std::vector<uint32_t> ord;
+  std::vector<SplitNode> radix;
+  std::vector<Slot> order;
+  std::vector<Wide> wide;
+  std::vector<uint32_t> child_base, block_order, node_addr, block_addr;
+  uint64_t next_unit = 4;
+  uint32_t n_tri_records = 0, toplet_budget = 0;
+  std::vector<float> wbt;            // world bitangent per vertex
+};
+
 }  // namespace
 
 // =================================================================================================
@@ -280,16 +299,27 @@ void ptc_owned_pixels(int w, int h, int tile_rank, int tile_count, std::vector<u
   }
 }
 
-std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::vector<HostMesh>& meshes,
-                            const std::vector<HostInstance>& insts, const std::vector<HostTexture>& texs, const HostEnv& env,
-                            uint32_t toplet_budget, int bvh_builder, HostBuilt& B) {
+namespace {
+std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vector<HostMesh>& meshes,
+                           const std::vector<HostInstance>& insts, const std::vector<HostTexture>& texs, const HostEnv& env,
+                           uint32_t toplet_budget, int bvh_builder, HostBuilt& B, bool refit) {
   if (insts.empty()) return "scene_commit: no instances";
   uint64_t nv = 0, nt = 0;
   for (const auto& in : insts) { nv += meshes[(size_t)in.mesh].v.size(); nt += meshes[(size_t)in.mesh].idx.size() / 3; }
   if (nt >= (1u << 28)) return "scene_commit: too many triangles";
-  B = HostBuilt();
+  std::shared_ptr<Topology> topo;
+  if (refit) {
+    topo = std::static_pointer_cast<Topology>(B.topology);
+    if (!topo || B.n_tris != nt || B.wverts.size() != nv) return "scene_refit: the scene's meshes or instances changed since the commit (only transforms may)";
+    toplet_budget = topo->toplet_budget;
+  } else {
+    B = HostBuilt();
+    topo = std::make_shared<Topology>();
+    topo->toplet_budget = toplet_budget;
+  }
   B.wverts.resize(nv);
-  std::vector<float> wbt(nv * 3);   // world bitangent per vertex (vertex.glsl:35)
+  std::vector<float>& wbt = topo->wbt;   // world bitangent per vertex (vertex.glsl:35)
+  wbt.resize(nv * 3);
   B.widx.resize(nt * 3);
   B.tri_mat.resize(nt);
   // ---- flatten ----------------------------------------------------------------------------------
@@ -348,8 +378,8 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
   if (sb.hi[1] - sb.lo[1] > diag) diag = sb.hi[1] - sb.lo[1];
   if (sb.hi[2] - sb.lo[2] > diag) diag = sb.hi[2] - sb.lo[2];
   B.ray_eps = 1e-4f * (diag > 1e-6f ? diag : 1e-6f);
-  std::vector<uint32_t> ord(n);        // position in BVH order → original primitive id (partitioned by the build)
-  for (uint32_t p = 0; p < n; ++p) ord[p] = p;
+  std::vector<uint32_t>& ord = topo->ord;        // position in BVH order → original primitive id (partitioned by the build)
+  if (!refit) { ord.resize(n); for (uint32_t p = 0; p < n; ++p) ord[p] = p; }
   // ---- texture sets and material classes ------------------------------------------------------------------------------------
   // A texture SET is a distinct (colour, normal, metal-rough) triple of texture ids among the materials that have a texture, numbered in
   // material order.  The material CLASS travels in the triangle record and the hit word and is what k_shade sorts by (a wave shades 64
@@ -409,15 +439,13 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
   // cost of four unrelated 16-byte gathers: tools/gather_bench.hip).
   // Layout: blocks breadth-first until `toplet_budget` 64-byte records exist (the trace kernels stage that prefix in LDS),
   // then depth-first.
-  struct WChild { bool leaf; uint32_t lo, hi; int32_t radix; Box box; };
-  std::vector<SplitNode> radix;
+  std::vector<SplitNode>& radix = topo->radix;
   std::vector<Box> radix_box;
   struct Dp { float c[8]; uint8_t leaf1, same[8], k[9]; };   // c[i], same[i]: i = 1..7; k[j]: j = 2..8
   std::vector<Dp> dp;
   auto link_box = [&](int32_t link) { return link < 0 ? tbox[ord[(size_t)~link]] : radix_box[(size_t)link]; };
   auto dp_cost = [&](int32_t link, int i) { return link < 0 ? box_half_area(link_box(link)) * 1.0f * kCostPrim : dp[(size_t)link].c[i]; };
   auto min7 = [](int k) { return k > 7 ? 7 : k; };
-  struct Wide { WChild slot[kWide]; bool used[kWide]; int n; };
   auto assign_slots = [&](const WChild* kid, int n, int* slot_of) {
     Box nb = empty_box();
     for (int i = 0; i < n; ++i) grow(nb, kid[i].box);
@@ -506,33 +534,42 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
     }
     e_out = e;
   };
-  struct Slot { int32_t radix; uint32_t depth; };
-  std::vector<Slot> order;          // node index → radix node (or -1 for the single-triangle special case)
-  std::vector<Wide> wide;           // node index → its children
-  std::vector<uint32_t> child_base; // node index → index of its first interior child
-  std::vector<uint32_t> block_order; // node indices in the order their children blocks were allocated
-  if (n == 1) {   // a single triangle: two identical leaf children (mirrors the binary special case)
+  std::vector<Slot>& order = topo->order;              // node index → radix node (or -1 for the single-triangle special case)
+  std::vector<Wide>& wide = topo->wide;                // node index → its children
+  std::vector<uint32_t>& child_base = topo->child_base; // node index → index of its first interior child
+  std::vector<uint32_t>& block_order = topo->block_order; // node indices in the order their children blocks were allocated
+  // boxes of all radix nodes, bottom-up (iterative post-order)
+  auto compute_radix_boxes = [&]() {
+    radix_box.assign(radix.size(), empty_box());
+    if (radix.empty()) return;
+    std::vector<std::pair<int32_t, int>> stk{{0, 0}};
+    while (!stk.empty()) {
+      auto& top = stk.back();
+      const SplitNode& r = radix[(size_t)top.first];
+      if (top.second == 0) { top.second = 1; if (r.left >= 0) { stk.push_back({r.left, 0}); continue; } }
+      if (top.second == 1) { top.second = 2; if (r.right >= 0) { stk.push_back({r.right, 0}); continue; } }
+      Box b = r.left < 0 ? tbox[ord[(size_t)~r.left]] : radix_box[(size_t)r.left];
+      grow(b, r.right < 0 ? tbox[ord[(size_t)~r.right]] : radix_box[(size_t)r.right]);
+      radix_box[(size_t)top.first] = b;
+      stk.pop_back();
+    }
+  };
+  if (refit) {    // same tree, same slots: only the boxes of the children follow the moved triangles
+    compute_radix_boxes();
+    for (Wide& w : wide)
+      for (int sl = 0; sl < kWide; ++sl) {
+        if (!w.used[sl]) continue;
+        WChild& ch = w.slot[sl];
+        ch.box = ch.radix >= 0 ? radix_box[(size_t)ch.radix] : tbox[ord[ch.lo]];
+      }
+  } else if (n == 1) {   // a single triangle: two identical leaf children (mirrors the binary special case)
     WChild kid[2];
     for (int k = 0; k < 2; ++k) { kid[k].leaf = true; kid[k].lo = kid[k].hi = 0; kid[k].radix = -1; kid[k].box = tbox[0]; }
     const Wide w = make_wide(kid, 2);
     order.push_back({-1, 0}); wide.push_back(w); child_base.push_back(1); block_order.push_back(0);
   } else {
     build_split_tree(tbox, ord, radix, bvh_builder == 1);
-    // boxes of all radix nodes, bottom-up (iterative post-order)
-    radix_box.assign(radix.size(), empty_box());
-    {
-      std::vector<std::pair<int32_t, int>> stk{{0, 0}};
-      while (!stk.empty()) {
-        auto& top = stk.back();
-        const SplitNode& r = radix[(size_t)top.first];
-        if (top.second == 0) { top.second = 1; if (r.left >= 0) { stk.push_back({r.left, 0}); continue; } }
-        if (top.second == 1) { top.second = 2; if (r.right >= 0) { stk.push_back({r.right, 0}); continue; } }
-        Box b = r.left < 0 ? tbox[ord[(size_t)~r.left]] : radix_box[(size_t)r.left];
-        grow(b, r.right < 0 ? tbox[ord[(size_t)~r.right]] : radix_box[(size_t)r.right]);
-        radix_box[(size_t)top.first] = b;
-        stk.pop_back();
-      }
-    }
+    compute_radix_boxes();
     // cost tables, bottom-up: radix nodes are numbered parents-first, so descending index order is a valid post-order
     dp.assign(radix.size(), Dp());
     for (size_t idx = radix.size(); idx-- > 0;) {
@@ -590,10 +627,13 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
   }
   // ---- unit addresses: root at 0, then the children blocks in allocation order, each on a 64-byte boundary ---------------
   B.n_nodes = (uint32_t)order.size();
-  std::vector<uint32_t> node_addr(B.n_nodes, 0u), block_addr(B.n_nodes, 0u);
-  uint64_t next_unit = 4;
-  uint32_t n_tri_records = 0;
+  std::vector<uint32_t>& node_addr = topo->node_addr;
+  std::vector<uint32_t>& block_addr = topo->block_addr;
+  uint64_t& next_unit = topo->next_unit;
+  uint32_t& n_tri_records = topo->n_tri_records;
+  if (!refit) { node_addr.assign(B.n_nodes, 0u); block_addr.assign(B.n_nodes, 0u); next_unit = 4; n_tri_records = 0; }
   for (const uint32_t idx : block_order) {
+    if (refit) break;
     const Wide& w = wide[idx];
     uint32_t ni = 0, nt = 0;
     for (int sl = 0; sl < kWide; ++sl) {
@@ -674,6 +714,7 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
   }
   // ---- emitters (original primitive order), power pmf / cdf ----------------------------------------------
   B.prim_light.assign(n, -1);
+  B.lights.clear(); B.cdf.clear();
   std::vector<float> weight;
   for (uint32_t p = 0; p < n; ++p) {
     const HostMaterial& m = mats[(size_t)B.tri_mat[p]];
@@ -733,6 +774,7 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
       }
     }
   }
+  if (!refit) {      // textures and the environment do not depend on the instances' transforms
   for (const auto& t : texs) {
     const int32_t info[4] = {(int32_t)B.texels.size(), t.w, t.h, 0};
     B.tex_info.insert(B.tex_info.end(), info, info + 4);
@@ -824,8 +866,25 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
     if (B.env_marg_guide.empty()) B.env_marg_guide.assign(PTC_ENV_GUIDE + 1, 0);
     if (B.env_cond_guide.empty()) B.env_cond_guide.assign(PTC_ENV_GUIDE + 1, 0);
   }
+  }
   if (!B.cdf.empty()) B.cdf.back() = 1.0f;
   if (B.cdf.empty()) B.cdf.push_back(1.0f);
   if (B.lights.empty()) B.lights.assign(20, 0.0f);
+  B.topology = topo;
   return std::string();
+}
+}  // namespace
+
+std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::vector<HostMesh>& meshes,
+                            const std::vector<HostInstance>& insts, const std::vector<HostTexture>& texs, const HostEnv& env,
+                            uint32_t toplet_budget, int bvh_builder, HostBuilt& B) {
+  return build_or_refit(mats, meshes, insts, texs, env, toplet_budget, bvh_builder, B, false);
+}
+
+// Refit: the instances' transforms changed (and nothing else).  Vertices are flattened again, every box of the committed tree is
+// recomputed bottom-up and re-quantised (the scene box, hence the origin grid and the ray offset, follow the geometry), triangle records,
+// shading records and the emitter table are rewritten; the tree keeps its topology, its slots and its layout.
+std::string ptc_refit_scene(const std::vector<HostMaterial>& mats, const std::vector<HostMesh>& meshes, const std::vector<HostInstance>& insts,
+                            const std::vector<HostTexture>& texs, const HostEnv& env, HostBuilt& B) {
+  return build_or_refit(mats, meshes, insts, texs, env, 0, 0, B, true);
 }

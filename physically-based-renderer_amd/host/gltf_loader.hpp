@@ -170,6 +170,35 @@ inline std::vector<std::uint8_t> read_file(const std::string& path) {
   const std::string s = ss.str();
   return std::vector<std::uint8_t>(s.begin(), s.end());
 }
+// A relative-reference URI of a buffer or an image (glTF 2.0 §2.8 / RFC 3986): percent-decoded, and resolved against the asset's directory
+// only when it stays inside it — no scheme ("file:", "http:"), no absolute path, no ".." segment that climbs out, no NUL.  An asset is
+// untrusted input: "../../etc/passwd" or "%2e%2e/x" must not turn the loader into a file reader for the rest of the disk.
+inline std::string resolve_uri(const std::string& dir, const std::string& uri) {
+  std::string dec;
+  for (std::size_t i = 0; i < uri.size(); ++i) {
+    if (uri[i] == '%') {
+      auto hex = [](char c) { return c >= '0' && c <= '9' ? c - '0' : c >= 'a' && c <= 'f' ? c - 'a' + 10 : c >= 'A' && c <= 'F' ? c - 'A' + 10 : -1; };
+      if (i + 2 >= uri.size()) throw std::runtime_error("uri: truncated percent escape in " + uri);
+      const int h = hex(uri[i + 1]), l = hex(uri[i + 2]);
+      if (h < 0 || l < 0) throw std::runtime_error("uri: bad percent escape in " + uri);
+      dec.push_back((char)(h * 16 + l));
+      i += 2;
+    } else dec.push_back(uri[i]);
+  }
+  if (dec.empty() || dec.find('\0') != std::string::npos) throw std::runtime_error("uri: empty or contains NUL: " + uri);
+  if (dec[0] == '/' || dec[0] == '\\' || dec.find(':') != std::string::npos) throw std::runtime_error("uri: only relative references inside the asset's directory are read: " + uri);
+  int depth = 0;                                    // segments below the asset's directory
+  std::size_t a = 0;
+  while (a <= dec.size()) {
+    std::size_t b = dec.find_first_of("/\\", a);
+    if (b == std::string::npos) b = dec.size();
+    const std::string seg = dec.substr(a, b - a);
+    if (seg == "..") { if (--depth < 0) throw std::runtime_error("uri: leaves the asset's directory: " + uri); }
+    else if (!seg.empty() && seg != ".") ++depth;
+    a = b + 1;
+  }
+  return dir + dec;
+}
 inline std::vector<std::uint8_t> base64(const std::string& in) {
   std::vector<std::uint8_t> out;
   unsigned acc = 0; int bits = 0;
@@ -328,7 +357,7 @@ inline Doc open(const std::string& path) {
       const size_t k = uri.find("base64,");
       if (k == std::string::npos) throw std::runtime_error("only base64 data: URIs are supported");
       d.buffers.push_back(base64(uri.substr(k + 7)));
-    } else d.buffers.push_back(read_file(dir + uri));
+    } else d.buffers.push_back(read_file(resolve_uri(dir, uri)));
     if (d.buffers.back().size() < (size_t)b.integer("byteLength", 0)) throw std::runtime_error("buffer shorter than its byteLength");
     ++bi;
   }
@@ -371,7 +400,7 @@ inline FlatScene load(const std::string& path, int scene_index = -1, bool compos
         const size_t k = uri.find("base64,");
         if (k == std::string::npos) throw std::runtime_error("only base64 data: URIs are supported");
         owned = base64(uri.substr(k + 7));
-      } else owned = read_file(dir + uri);
+      } else owned = read_file(resolve_uri(dir, uri));
       bytes = owned.data(); nbytes = owned.size();
     }
     Texture t;

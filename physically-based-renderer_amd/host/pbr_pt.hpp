@@ -11,6 +11,7 @@
 #include <ptc.h>
 
 #include <array>
+#include <cmath>
 #include <cstdint>
 #include <memory>
 #include <stdexcept>
@@ -38,6 +39,20 @@ struct MaterialData {
   std::array<float, 4> color{1, 1, 1, 1};
   float metallic = 0.0f, roughness = 1.0f;
   std::array<float, 3> emissive{0, 0, 0};
+};
+
+// The viewer's start-up camera: app::CameraController's defaults (src/gltf_viewer/CameraController.hpp:25-40: position 0, pitch 0,
+// yaw -pi/2, vertical fov pi/2) and its getDirection() / getCameraData() (CameraController.hpp:128-136), in the same float arithmetic.
+struct ViewerCamera {
+  std::array<float, 3> position{0.0f, 0.0f, 0.0f};
+  float pitch = 0.0f, yaw = -1.57079632679489661923f, fov = 1.57079632679489661923f;
+  [[nodiscard]] auto direction() const -> std::array<float, 3> {
+    const float cp = std::cos(pitch);
+    const float x = cp * std::cos(yaw), y = std::sin(pitch), z = cp * std::sin(yaw);
+    const float il = 1.0f / std::sqrt(x * x + y * y + z * z);
+    return {x * il, y * il, z * il};
+  }
+  [[nodiscard]] auto target() const -> std::array<float, 3> { const auto d = direction(); return {position[0] + d[0], position[1] + d[1], position[2] + d[2]}; }
 };
 
 struct PrimitiveSpan { int material; std::uint32_t firstVertex, vertexCount, firstIndex, indexCount; };

@@ -1,5 +1,5 @@
 // ptc_render — dependency-free C++17 offline renderer over the C-ABI (include/ptc.h).
-//   ptc_render (--scene cornell|sphere | --gltf file.glb [--cam-pos x y z --cam-target x y z --fov deg]) --width W --height H
+//   ptc_render (--scene cornell|sphere | --gltf file.glb [--cam-pos x y z --cam-target x y z --fov deg | --viewer-camera]) --width W --height H
 //              --spp N --seed S --bounces B [--raster | --raster16] [--env latlong.pfm | --sky] [--filter nearest|linear] [--bvh sah|lbvh] [--device D] [--gpus N]
 //              --out image.pfm [--png image.png] [--ppm image.ppm] [--half image.f16]
 // --gpus N: devices D..D+N-1 share the frame by 32x32-pixel tiles, one RCCL reduce brings it to device D (ptc_group_*).
@@ -110,6 +110,7 @@ int main(int argc, char** argv) {
   int bvh = -1;                             // -1: the context's default (SAH, or PTC_BVH in the environment)
   float camPos[3] = {0, 0, 0}, camTarget[3] = {0, 0, -1}, fovDeg = 60.0f;
   bool haveCam = false;
+  float viewerFov = 0.0f;                    // --viewer-camera: the reference's fov in radians, passed on without a degree round trip
   int w = 256, h = 256, spp = 64, bounces = 8, device = 0, gpus = 0 /* 0: one plain context; N >= 1: a device group of N */, integrator = PTC_INTEGRATOR_PATH;
   std::string halfPath;
   std::uint64_t seed = 1;
@@ -124,6 +125,12 @@ int main(int argc, char** argv) {
     else if (a == "--env") envPath = next(); else if (a == "--sky") sky = true;
     else if (a == "--filter") { const std::string f = next(); if (f == "linear") filter = PTC_FILTER_LINEAR; else if (f == "nearest") filter = PTC_FILTER_NEAREST; else { std::cerr << "--filter nearest|linear\n"; return 2; } }
     else if (a == "--cam-pos") { for (float& v : camPos) v = (float)std::atof(next()); haveCam = true; }
+    else if (a == "--viewer-camera") {     // the reference viewer's start-up view: CameraController.hpp:25-40 (position 0, looking down -z, fovY pi/2, aspect W/H)
+      const pbr::ViewerCamera vc;
+      const auto tg = vc.target();
+      for (int k = 0; k < 3; ++k) { camPos[k] = vc.position[(std::size_t)k]; camTarget[k] = tg[(std::size_t)k]; }
+      fovDeg = vc.fov * 180.0f / 3.14159265358979323846f; viewerFov = vc.fov; haveCam = true;
+    }
     else if (a == "--cam-target") { for (float& v : camTarget) v = (float)std::atof(next()); }
     else if (a == "--fov") fovDeg = (float)std::atof(next());
     else if (a == "--bvh") { const std::string f = next(); if (f == "lbvh") bvh = PTC_BVH_LBVH; else if (f == "sah") bvh = PTC_BVH_SAH; else { std::cerr << "--bvh sah|lbvh\n"; return 2; } }
@@ -147,7 +154,7 @@ int main(int argc, char** argv) {
         camPos[0] = cx; camPos[1] = cy; camPos[2] = cz + r / std::tan(0.5f * fovDeg * 3.14159265f / 180.0f) + r;
         haveCam = true;
       }
-      rs.setCamera({camPos[0], camPos[1], camPos[2]}, {camTarget[0], camTarget[1], camTarget[2]}, fovDeg * 3.14159265f / 180.0f, (float)w / h);
+      rs.setCamera({camPos[0], camPos[1], camPos[2]}, {camTarget[0], camTarget[1], camTarget[2]}, viewerFov > 0.0f ? viewerFov : fovDeg * 3.14159265f / 180.0f, (float)w / h);
       if (!envPath.empty()) {
         int ew = 0, eh = 0;
         std::vector<float> env = pbr::image::read_pfm(envPath, ew, eh);

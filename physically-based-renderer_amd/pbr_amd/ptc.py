@@ -30,7 +30,7 @@ ABI_VERSION = 3
 # every symbol include/ptc.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "ptc_create", "ptc_destroy", "ptc_last_error", "ptc_abi_version", "ptc_build_info", "ptc_scene_begin", "ptc_add_material",
-    "ptc_add_texture_rgba8", "ptc_add_mesh", "ptc_add_instance", "ptc_add_instance_matrix", "ptc_set_camera", "ptc_set_env_latlong_rgb32f", "ptc_set_texture_filter", "ptc_set_bvh_builder", "ptc_scene_commit", "ptc_render",
+    "ptc_add_texture_rgba8", "ptc_add_mesh", "ptc_add_instance", "ptc_add_instance_matrix", "ptc_update_instance", "ptc_update_instance_matrix", "ptc_scene_refit", "ptc_set_camera", "ptc_set_env_latlong_rgb32f", "ptc_set_texture_filter", "ptc_set_bvh_builder", "ptc_scene_commit", "ptc_render",
     "ptc_frame_begin", "ptc_frame_add_samples", "ptc_frame_reserve", "ptc_frame_resolve", "ptc_sync", "ptc_read_radiance_rgba32f",
     "ptc_radiance_device_ptr", "ptc_write_radiance_rgba32f", "ptc_tonemap_rgba8", "ptc_get_stats",
     "ptc_debug_trace_closest", "ptc_debug_trace_any", "ptc_debug_get_flat_scene", "ptc_debug_get_bvh", "ptc_debug_get_counters",
@@ -47,7 +47,7 @@ class PtcStats(C.Structure):
         ("node_visits_closest", C.c_uint64), ("tri_tests_closest", C.c_uint64),
         ("node_visits_any", C.c_uint64), ("tri_tests_any", C.c_uint64), ("algorithmic_bytes", C.c_uint64),
         ("seconds_render", C.c_double), ("seconds_trace_closest", C.c_double), ("seconds_trace_any", C.c_double),
-        ("seconds_shade", C.c_double), ("seconds_commit", C.c_double), ("seconds_reduce", C.c_double),
+        ("seconds_shade", C.c_double), ("seconds_commit", C.c_double), ("seconds_reduce", C.c_double), ("seconds_refit", C.c_double),
         ("launches_trace_closest", C.c_uint32), ("launches_trace_any", C.c_uint32),
         ("n_triangles", C.c_uint32), ("n_bvh_nodes", C.c_uint32), ("n_emitters", C.c_uint32), ("bvh_max_depth", C.c_uint32),
     ]
@@ -88,6 +88,9 @@ def load_library():
     L.ptc_add_mesh.argtypes = [vp, vp, C.c_uint32, u32p, C.c_uint32, C.c_int]
     L.ptc_add_instance.argtypes = [vp, C.c_int, fp, fp, fp]
     L.ptc_add_instance_matrix.argtypes = [vp, C.c_int, fp]
+    L.ptc_update_instance.argtypes = [vp, C.c_int, fp, fp, fp]
+    L.ptc_update_instance_matrix.argtypes = [vp, C.c_int, fp]
+    L.ptc_scene_refit.argtypes = [vp]
     L.ptc_set_camera.argtypes = [vp, fp, fp, C.c_float, C.c_float]
     L.ptc_set_env_latlong_rgb32f.argtypes = [vp, fp, C.c_int, C.c_int]
     L.ptc_set_texture_filter.argtypes = [vp, C.c_int]
@@ -211,6 +214,18 @@ class PathTracer:
 
     def set_camera(self, position, target, fov_y, aspect):
         self._ck(self._L.ptc_set_camera(self._h, _f(position)[1], _f(target)[1], fov_y, aspect))
+
+    def update_instance(self, instance, t=None, q_wxyz=None, s=None, matrix=None):
+        """New transform for a committed instance (ptc_update_instance / ptc_update_instance_matrix); scene_refit() applies it."""
+        if matrix is not None:
+            self._ck(self._L.ptc_update_instance_matrix(self._h, instance, _f(np.asarray(matrix, np.float32).reshape(16))[1]))
+        else:
+            self._ck(self._L.ptc_update_instance(self._h, instance, _f(t)[1], _f(q_wxyz)[1], _f(s)[1]))
+        return self
+
+    def scene_refit(self):
+        self._ck(self._L.ptc_scene_refit(self._h))
+        return self
 
     # ---- rendering --------------------------------------------------------------------------------
     def render(self, w, h, spp, seed=1, max_bounces=8, integrator=INTEGRATOR_PATH):

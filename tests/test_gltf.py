@@ -243,3 +243,33 @@ def test_hostile_accessors_and_json_are_rejected(pbr, tmp_path):
             load(j)
     with pytest.raises(pbr.PtcError, match="nesting"):
         load(b'{"asset":{"version":"2.0"},"x":' + b"[" * 5000 + b"]" * 5000 + b"}")
+
+
+def test_uris_are_percent_decoded_and_kept_inside_the_asset_directory(pbr, tmp_path):
+    """glTF URIs are RFC 3986 relative references: "my%20mesh.bin" names the file "my mesh.bin", sub-directories are fine — and an asset is
+    untrusted input: absolute paths, schemes, and ".." segments that climb out of the asset's directory (percent-encoded or not) are refused,
+    with an error that says so, before any file is opened."""
+    pos = np.array([(0, 0, 0), (1, 0, 0), (0, 1, 0)], "<f4")
+
+    def doc(uri):
+        return {"asset": {"version": "2.0"}, "buffers": [{"uri": uri, "byteLength": 36}], "bufferViews": [{"buffer": 0, "byteLength": 36}],
+                "accessors": [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"}],
+                "meshes": [{"primitives": [{"attributes": {"POSITION": 0}}]}], "nodes": [{"mesh": 0}], "scenes": [{"nodes": [0]}]}
+
+    (tmp_path / "sub dir").mkdir()
+    (tmp_path / "sub dir" / "my mesh.bin").write_bytes(pos.tobytes())
+    p = _write_gltf(tmp_path, doc("sub%20dir/my%20mesh.bin"), [])
+    (v, idx, mats), (n, lo, hi), _ = _flat_glb(pbr, p)
+    assert n == 1 and np.allclose(hi, (1, 1, 0))
+    p = _write_gltf(tmp_path, doc("sub%20dir/../sub%20dir/./my%20mesh.bin"), [])      # ".." that stays inside
+    assert _flat_glb(pbr, p)[1][0] == 1
+    outside = tmp_path.parent / "outside.bin"
+    outside.write_bytes(pos.tobytes())
+    try:
+        for bad, msg in (("../outside.bin", "leaves the asset"), ("%2e%2e/outside.bin", "leaves the asset"), ("sub%20dir/../../outside.bin", "leaves the asset"),
+                         (str(outside), "only relative"), ("file:///etc/passwd", "only relative"), ("a%zz.bin", "percent escape"), ("a%2", "percent escape")):
+            p = _write_gltf(tmp_path, doc(bad), [])
+            with pytest.raises(pbr.PtcError, match=msg):
+                _flat_glb(pbr, p)
+    finally:
+        outside.unlink()

@@ -329,3 +329,15 @@ def test_config5_full_size(gpu, ora):
         pt.frame_resolve()
         acc += pt.read_radiance()
     assert _bits_equal(acc, a)
+
+
+def test_viewer_shim_renders_progressively_and_refits(gpu):
+    """examples/viewer_shim.cpp on the GPU: App::run's loop — one sample per displayed frame into the RGBA16F staging buffer, the node turned half
+    way (ptc_update_instance + ptc_scene_refit), the frame restarted."""
+    import json
+
+    exe = os.path.join(os.path.dirname(gpu.ptc.LIB_PATH), "viewer_shim")
+    r = subprocess.run([exe, "0", "6"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    info = json.loads(r.stdout.strip().splitlines()[0])
+    assert info["rendered"] is True and info["triangles"] == 4 and info["frames"] == 6 and info["staging_sum"] > 0

@@ -552,3 +552,45 @@ def test_camera_change_without_recommit(gpu, ora):
     pt.frame_add_samples(2)
     pt.frame_resolve()
     assert _bits_equal(pt.read_radiance(), g) and not np.array_equal(first, g)
+
+
+@pytest.mark.parametrize("name,kw,w,h,spp,seed,mb", [("sphere10k", {}, 96, 96, 4, 2, 6), ("atrium", {}, 160, 90, 2, 3, 8),
+                                                      ("textured_atrium", {"scale": 0.05, "tex_size": 64, "env_size": (64, 32)}, 120, 68, 4, 5, 6)])
+def test_scene_dynamics_refit(gpu, ora, name, kw, w, h, spp, seed, mb):
+    """The viewer turns its nodes every frame (src/gltf_viewer/App.cpp:306-313).  ptc_update_instance + ptc_scene_refit: the image is, bit for
+    bit, that of a fresh commit of the same transforms (closest hit and occlusion do not depend on the tree) and that of the oracle's refit;
+    the traversal counters are those of the oracle's refitted tree; a second turn refits the refitted tree again."""
+    import copy
+    import math
+    d = gpu.scenes.by_name(name, **kw)
+    pt, o = _pair(gpu, ora, d)
+    pt.render(w, h, 1, seed=seed, max_bounces=mb)                                        # something was rendered before the scene moves
+    d2 = copy.deepcopy(d)
+    for k in (1, 2):
+        for i, it in enumerate(d2.instances):
+            if i % 3 or getattr(it, "matrix", None) is not None:
+                continue
+            a = 0.07 * k + 0.013 * i
+            w1, x1, y1, z1 = math.cos(a / 2), 0.0, math.sin(a / 2), 0.0
+            w2, x2, y2, z2 = d.instances[i].q_wxyz
+            q = (w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2)
+            t = (d.instances[i].t[0], d.instances[i].t[1] + 0.03 * k, d.instances[i].t[2])
+            it.t, it.q_wxyz = t, q
+            pt.update_instance(i, t, q, it.s)
+            o.update_instance(i, t, q, it.s)
+        pt.scene_refit()
+        o.scene_refit()
+        g = pt.render(w, h, spp, seed=seed, max_bounces=mb)
+        c = o.render(w, h, spp, seed=seed, max_bounces=mb)
+        assert _bits_equal(g, c), f"turn {k}: {int((g != c).any(-1).sum())} pixels differ from the oracle's refit"
+        sg, so = pt.stats(), o.stats()
+        for key in COUNTERS:
+            assert sg[key] == so[key], (k, key)
+        fresh = gpu.PathTracer(0).load_scene(d2)
+        f = fresh.render(w, h, spp, seed=seed, max_bounces=mb)
+        assert _bits_equal(g, f), f"turn {k}: {int((g != f).any(-1).sum())} pixels differ from a fresh commit"
+        sf = fresh.stats()
+        assert sf["segments"] == sg["segments"] and sf["shadow_rays"] == sg["shadow_rays"] and sf["hits"] == sg["hits"]
+        assert 0.0 < sg["seconds_refit"]
+    # the refit is cheaper than the commit it replaces (no build), and the numbers are there to be read
+    print(f"{name}: commit {pt.stats()['seconds_commit'] * 1e3:.1f} ms, refit {pt.stats()['seconds_refit'] * 1e3:.1f} ms")

@@ -287,3 +287,70 @@ def test_material_classes_follow_the_texture_sets(ora, pbr):
     assert len(prim) == len(tri_mat)
     for p, c in zip(prim, cls):
         assert c == want[int(tri_mat[p])], (p, tri_mat[p], c)
+
+
+def _rotated(desc, k):
+    """The viewer's App::update turns its nodes a little every frame (src/gltf_viewer/App.cpp:306-313): here every third instance gets
+    a yaw of 0.05*k rad about its own origin and a small lift, the rest stay."""
+    import copy
+    import math
+    out = []
+    for i, it in enumerate(desc.instances):
+        if i % 3 or getattr(it, "matrix", None) is not None:
+            out.append(None)
+            continue
+        a = 0.05 * k + 0.01 * i
+        q = (math.cos(a / 2), 0.0, math.sin(a / 2), 0.0)
+        # compose with the instance's own rotation: q_new = q * q_old
+        w1, x1, y1, z1 = q
+        w2, x2, y2, z2 = it.q_wxyz
+        qn = (w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2)
+        out.append(((it.t[0], it.t[1] + 0.02 * k, it.t[2]), qn, it.s))
+    return out
+
+
+@pytest.mark.parametrize("name,kw", [("sphere10k", {}), ("atrium", {"scale": 0.05}), ("textured_objects", {})])
+def test_refit_equals_oracle_and_keeps_the_topology(ora, pbr, name, kw):
+    """ptc_update_instance + ptc_scene_refit against the oracle's: the refitted trees are identical bit for bit (same topology and slots as
+    the committed tree, boxes and records from the moved vertices); a refit without any change reproduces the committed tree; the flattened
+    scene after the refit is the one a fresh commit of the same transforms flattens to."""
+    d = pbr.scenes.by_name(name, **kw)
+    pt = pbr.PathTracer(pbr.DEVICE_NONE).load_scene(d)
+    o = ora.Oracle().load_scene(d)
+    units0, nn0, nt0, grid0 = pt.bvh()
+    pt.scene_refit()
+    units1, nn1, nt1, grid1 = pt.bvh()
+    assert nn0 == nn1 and np.array_equal(units0.view(np.uint32), units1.view(np.uint32)) and np.array_equal(np.asarray(grid0), np.asarray(grid1))
+    n0, t0 = o.bvh()
+    o.scene_refit()
+    n1, t1 = o.bvh()
+    assert np.array_equal(n0.view(np.uint32), n1.view(np.uint32)) and np.array_equal(t0.view(np.uint32), t1.view(np.uint32))
+    for k in (1, 2):
+        moved = _rotated(d, k)
+        import copy
+        d2 = copy.deepcopy(d)
+        for i, m in enumerate(moved):
+            if m is None:
+                continue
+            pt.update_instance(i, *m)
+            o.update_instance(i, *m)
+            d2.instances[i].t, d2.instances[i].q_wxyz, d2.instances[i].s = m
+        pt.scene_refit()
+        o.scene_refit()
+        units, nn, nt, grid = pt.bvh()
+        n2, t2 = o.bvh()
+        assert nn == nn0 == n2.shape[0]
+        assert np.array_equal(_canon(_decode_product(units, nn, nt, grid)), _canon(_decode_oracle(n2, t2)))
+        # the topology stayed: child codes of the oracle's nodes are those of the commit
+        assert np.array_equal(n2.view(np.uint32)[:, -8:], n0.view(np.uint32)[:, -8:])
+        fresh = pbr.PathTracer(pbr.DEVICE_NONE).load_scene(d2)
+        v1, i1, m1 = pt.flat_scene()
+        v2, i2, m2 = fresh.flat_scene()
+        assert np.array_equal(v1.view(np.uint32), v2.view(np.uint32)) and np.array_equal(i1, i2) and np.array_equal(m1, m2)
+        v3, _, _ = o.flat_scene()
+        assert np.array_equal(v1.view(np.uint32), v3.view(np.uint32))
+        assert pt.stats()["seconds_refit"] > 0.0
+    with pytest.raises(pbr.PtcError):
+        pt.update_instance(10 ** 6, (0, 0, 0), (1, 0, 0, 0), (1, 1, 1))
+    with pytest.raises(pbr.PtcError):
+        pbr.PathTracer(pbr.DEVICE_NONE).scene_refit()                  # nothing committed
