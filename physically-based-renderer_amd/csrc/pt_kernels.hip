@@ -848,12 +848,13 @@ PT_DEV void wave_lds_sync() {     // LDS written by some lanes of this wave is r
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+template <bool SORT>
 __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(const DevScene* __restrict__ scp, DevFrame fr, DevQueues q, int qi, uint32_t b) {
   // small scene-wide tables staged once per block: emitter records + power cdf, materials
   __shared__ float4 s_light[SHADE_LDS_LIGHTS * 5];
   __shared__ float s_cdf[SHADE_LDS_LIGHTS];
   __shared__ float4 s_mat[SHADE_LDS_MATS * 4];
-  __shared__ uint32_t s_ring[SHADE_WAVES][PTC_MATERIAL_CLASSES][SHADE_RING];
+  __shared__ uint32_t s_ring[SORT ? SHADE_WAVES : 1][PTC_MATERIAL_CLASSES][SORT ? SHADE_RING : 1];
   __shared__ float s_marg[SHADE_LDS_ENV_ROWS];                   // the environment's row cdf and its guide, when the map is at most this high
   __shared__ uint16_t s_marg_guide[PTC_ENV_GUIDE + 2];
   const DevScene& sc = *scp;
@@ -886,7 +887,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(const De
   const uint32_t base = seg * q.seg_len;                       // first slot of the segment, in every queue array
   const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.seg_ray[qi][seg]);
   typedef __attribute__((address_space(3))) volatile uint32_t lds_u32;
-  lds_u32* ring = (lds_u32*)&s_ring[wave][0][0];
+  lds_u32* ring = (lds_u32*)&s_ring[SORT ? wave : 0][0][0];
 #ifdef PT_STAMP_SHADE   // wave-cycles per phase (tools/stamp_shade.py)
   unsigned long long t_front = 0, t_load = 0, t_math = 0, t_back = 0, t_mark = __builtin_amdgcn_s_memtime();
 #define SSTAMP(acc) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - t_mark; t_mark = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -899,8 +900,14 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(const De
   uint32_t fillv = 0;                     // lane c holds the number of slots waiting in ring c
   uint32_t ready = 0, nonempty = 0;       // class masks: ring holds >= 64 / > 0 slots
   uint32_t i0 = 0;
-  int w_pref = lane < n ? __float_as_int(q.hit[base + lane].y) : -1;    // class word of the group to be sorted next
+  int w_pref = SORT && lane < n ? __float_as_int(q.hit[base + lane].y) : -1;    // class word of the group to be sorted next
   for (;;) {
+    bool valid; uint32_t item = 0u;
+    if (!SORT) {          // a batch is the next 64 slots of the segment, whatever their materials
+      if (i0 >= n) break;
+      valid = i0 + lane < n; item = i0 + lane;
+      i0 += 64u;
+    } else {
     if (!ready) {
       if (i0 < n) {
         // ---- P9 front end: sort the next 64 slots into the class rings ----
@@ -927,8 +934,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(const De
       if (!nonempty) break;
     }
     // ---- take a batch: 64 slots of one class; at the end of the segment what is left in ALL rings goes out in mixed batches (the shading
-    // code does not need a uniform class, it is merely faster with one), so that a segment ends with one partial batch, not one per class ----
-    bool valid; uint32_t item = 0u;
+    // code does not need a uniform class), so that a segment ends with one partial batch, not one per class ----
     wave_lds_sync();
     if (ready) {
       const uint32_t c = (uint32_t)__builtin_ctz(ready);
@@ -953,6 +959,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(const De
         off += take;
       }
     }
+    }   // SORT
     const uint32_t slot = base + item;
     SSTAMP(t_front);
 
@@ -967,12 +974,14 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(const De
       const uint32_t path = __float_as_uint(Cq.z), key = __float_as_uint(Cq.w);
       const float ht = H.x, hu = H.z, hv = H.w;
       if (__float_as_int(H.y) < 0) {                                   // miss: environment radiance, MIS against env NEE
+        if (SORT || has_env) {                                          // (the sort has dropped the misses of a scene without environment already)
         v3 Le; float pe; env_lookup(sc, d, Le, pe);
         float wgt = 1.0f;
         if (b > 0u) { const float pl = pe * p_env; const float pb2 = prev_pdf * prev_pdf; wgt = pb2 / pt_fma(pl, pl, pb2); }
         float4 L = q.lpath[path];
         L.x = pt_fma(T.x * Le.x, wgt, L.x); L.y = pt_fma(T.y * Le.y, wgt, L.y); L.z = pt_fma(T.z * Le.z, wgt, L.z);
         q.lpath[path] = L;
+        }
       } else {
       const uint32_t prim = (uint32_t)__float_as_int(H.y) & ((1u << HIT_CLASS_SHIFT) - 1u);
       // ---- P5 surface reconstruction from the primitive's shading record (five 16-byte loads) ----
@@ -1297,8 +1306,9 @@ void pt_launch_trace_any(hipStream_t s, const LaunchCfg& cfg, const DevScene& sc
 }
 
 void pt_launch_shade(hipStream_t s, const LaunchCfg& cfg, const DevScene* sc, const DevFrame& fr, const DevQueues& q, int qi, uint32_t bounce) {
-  (void)cfg;
-  hipLaunchKernelGGL(k_shade, dim3((q.n_seg + SHADE_WAVES - 1u) / SHADE_WAVES), dim3(SHADE_BLOCK), 0, s, sc, fr, q, qi, bounce);   // one wave per segment
+  const dim3 grid((q.n_seg + SHADE_WAVES - 1u) / SHADE_WAVES);      // one wave per segment
+  if (cfg.shade_sort) hipLaunchKernelGGL(k_shade<true>, grid, dim3(SHADE_BLOCK), 0, s, sc, fr, q, qi, bounce);
+  else hipLaunchKernelGGL(k_shade<false>, grid, dim3(SHADE_BLOCK), 0, s, sc, fr, q, qi, bounce);
 }
 void pt_launch_accumulate(hipStream_t s, const DevFrame& fr, const DevQueues& q, float4* accum, uint32_t n_samples) {
   hipLaunchKernelGGL(k_accumulate, dim3((fr.n_owned + 255u) / 256u), dim3(256), 0, s, fr, (const float4*)q.lpath, accum, n_samples);

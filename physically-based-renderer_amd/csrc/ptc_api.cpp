@@ -457,6 +457,10 @@ ptc_ctx* ptc_create(int device_id) {
     uint32_t n = (uint32_t)(c->cfg.n_cu * per_cu);
     c->cfg.shade_waves = (int)(n > PTC_MAX_SEGMENTS ? PTC_MAX_SEGMENTS : n);
   }
+  // P9's material sort is built and bit-exact either way, and OFF by default: k_shade runs at the rate of the CUs' memory path, so class-uniform
+  // waves buy nothing, while the sort reads the hit words a second time and turns the ray loads into gathers: -11 % k_shade time without it on the
+  // atrium, -5 % on the textured atrium (profiles/r03_shade_variants.txt).  Output compaction (ballot + mbcnt prefix) is always on.
+  if (const char* s = std::getenv("PTC_SHADE_SORT")) c->cfg.shade_sort = std::atoi(s) != 0 ? 1 : 0;
   if (const char* s = std::getenv("PTC_NODELETS")) c->toplet_budget = (uint32_t)std::strtoul(s, nullptr, 10);
   if (const char* s = std::getenv("PTC_BATCH_PATHS")) { size_t v = std::strtoull(s, nullptr, 10); if (v >= 1024) c->max_batch_paths = v; }
   if (const char* s = std::getenv("PTC_TIMING")) c->timing = std::atoi(s) != 0;

@@ -107,7 +107,8 @@ inline void ptc_seg_layout(uint32_t n, uint32_t max_seg, uint32_t& n_seg, uint32
 }
 inline size_t ptc_seg_slots(uint32_t cap, uint32_t max_seg) { return (size_t)cap + 64u * (size_t)max_seg + 64u; }
 
-struct LaunchCfg { int n_cu; int trace_blocks_per_cu; int stack_lds; /* stack entries kept in LDS per lane */ int shade_waves; /* waves of k_shade's grid = upper bound of n_seg */ };
+struct LaunchCfg { int n_cu; int trace_blocks_per_cu; int stack_lds; /* stack entries kept in LDS per lane */ int shade_waves; /* waves of k_shade's grid = upper bound of n_seg */
+                   int shade_sort; /* 1: k_shade sorts its slots by material class before shading (PTC_SHADE_SORT=1); 0: it takes them in queue order */ };
 
 // ---- kernel launchers (pt_kernels.hip) ------------------------------------------------------------
 int pt_trace_block_threads();   // threads per block of the trace kernels (compile-time constant of pt_kernels.hip)

@@ -594,3 +594,24 @@ def test_scene_dynamics_refit(gpu, ora, name, kw, w, h, spp, seed, mb):
         assert 0.0 < sg["seconds_refit"]
     # the refit is cheaper than the commit it replaces (no build), and the numbers are there to be read
     print(f"{name}: commit {pt.stats()['seconds_commit'] * 1e3:.1f} ms, refit {pt.stats()['seconds_refit'] * 1e3:.1f} ms")
+
+
+@pytest.mark.parametrize("name,kw,w,h,spp,seed,mb", [("atrium", {"scale": 0.05}, 160, 90, 4, 3, 8), ("textured_atrium", {"scale": 0.05, "tex_size": 64, "env_size": (64, 32)}, 120, 68, 4, 5, 6),
+                                                      ("two_tris_sphere", {}, 64, 64, 2, 5, 3)])
+def test_material_sort_is_an_option_that_changes_nothing_but_time(gpu, ora, name, kw, w, h, spp, seed, mb):
+    """P9's per-wave material sort (PTC_SHADE_SORT=1: class rings in LDS by ballot + mbcnt, class-uniform batches of 64) is off by default — k_shade is
+    bound by the CUs' memory path, the sort costs 11 % of its time — and either way the image and every counter are the oracle's, bit for bit."""
+    d = gpu.scenes.by_name(name, **kw)
+    c = ora.Oracle().load_scene(d).render(w, h, spp, seed=seed, max_bounces=mb)
+    imgs = []
+    for sort in ("1", "0"):
+        os.environ["PTC_SHADE_SORT"] = sort
+        try:
+            pt = gpu.PathTracer(0).load_scene(d)
+        finally:
+            del os.environ["PTC_SHADE_SORT"]
+        g = pt.render(w, h, spp, seed=seed, max_bounces=mb)
+        assert _bits_equal(g, c), f"sort={sort}: {int((g != c).any(-1).sum())} pixels differ"
+        imgs.append((g, pt.stats()))
+    for k in COUNTERS:
+        assert imgs[0][1][k] == imgs[1][1][k], k
