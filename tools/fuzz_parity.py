@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Differential fuzzing of GPU vs oracle on random scenes (the generator of tests/test_gpu_parity.py).  usage: python tools/fuzz_parity.py [n] [seed]"""
+"""Differential fuzzing of GPU vs oracle on random scenes (the generator of tests/test_gpu_parity.py): image bits and all traversal counters; every third
+scene through the LBVH builder, every other scene moved and refitted afterwards (ptc_update_instance + ptc_scene_refit against the oracle's).
+usage: python tools/fuzz_parity.py [n] [seed]"""
 import importlib.util, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,5 +24,27 @@ for k in range(n):
     if not ok:
         bad += 1
         print("MISMATCH scene", k, d.bvh_builder, "pixels", int((g != c).any(-1).sum()), flush=True)
+    if k % 2 == 0:          # every other scene is then moved (random new transforms for a third of its instances) and refitted on both sides
+        moved = False
+        for i, it in enumerate(d.instances):
+            if rng.random() > 0.34:
+                continue
+            if getattr(it, "matrix", None) is not None:
+                m = np.asarray(it.matrix, np.float32).reshape(16).copy()
+                m[12:15] += rng.normal(0, 0.3, 3).astype(np.float32)
+                pt.update_instance(i, matrix=m); o.update_instance(i, matrix=m)
+            else:
+                q = rng.normal(0, 1, 4); q /= np.linalg.norm(q)
+                t = tuple(float(x) for x in np.asarray(it.t) + rng.normal(0, 0.3, 3))
+                sc = tuple(float(x) for x in np.asarray(it.s) * rng.uniform(0.7, 1.4, 3))
+                pt.update_instance(i, t, tuple(float(x) for x in q), sc); o.update_instance(i, t, tuple(float(x) for x in q), sc)
+            moved = True
+        if moved:
+            pt.scene_refit(); o.scene_refit()
+            g, c = pt.render(w, h, spp, seed=s, max_bounces=mb), o.render(w, h, spp, seed=s, max_bounces=mb)
+            ok = np.array_equal(g.view(np.uint32), c.view(np.uint32)) and all(pt.stats()[x] == o.stats()[x] for x in tg.COUNTERS)
+            if not ok:
+                bad += 1
+                print("MISMATCH after refit, scene", k, d.bvh_builder, "pixels", int((g != c).any(-1).sum()), flush=True)
 print(f"{n} scenes, {bad} mismatches")
 sys.exit(1 if bad else 0)
