@@ -231,6 +231,21 @@ void* ptc_radiance_rgba16f_device_ptr(ptc_ctx*);
 /* TonemapperSystem::run + tonemappers/aces+gamma.glsl:10-40 on the radiance buffer → RGBA8. */
 int ptc_tonemap_rgba8(ptc_ctx*, uint8_t* out);
 
+/* ---- checkpoint / resume, sample ranges (SURVEY §5 "optional later", §8e "kept as an option").  The RNG is counter-based — sample k of pixel p draws from
+ * hash(seed, p, k) — and a pixel's sum is taken in sample order, so a frame is resumable by its sums and a count.
+ *   ptc_frame_checkpoint: everything queued is finished; the per-pixel sums (n_owned x RGBA fp32, in the order of the frame's owned pixels: an opaque blob for
+ *     ptc_frame_restore; NULL to query the sizes only) and the number of samples in them.
+ *   ptc_frame_restore: right after a ptc_frame_begin with the SAME parameters (size, seed, bounces, tile share; spp_total may be larger): the sums and the
+ *     count are put back, the next sample added is sample `samples_done`.  checkpoint after k samples + restore + the remaining samples = the uninterrupted
+ *     frame, bit for bit.
+ *   ptc_frame_set_sample_range: right after ptc_frame_begin: the frame's samples have the indices first_sample, first_sample + 1, ...; with resolve_divisor != 0
+ *     the resolve divides by it instead of by the samples accumulated.  Sharding a frame by SAMPLES instead of by tiles: rank r of N renders all pixels
+ *     (tile_count 1), spp/N samples from first_sample = r x spp/N, resolve_divisor = spp: the reduce's sum of the partial means is the frame (fp32 sums in another
+ *     order than on one GPU: equal to rounding, not bit for bit — which is why tiles are the default). */
+int ptc_frame_checkpoint(ptc_ctx*, float* accum_rgba, uint64_t* n_owned_pixels, uint32_t* samples_done);
+int ptc_frame_restore(ptc_ctx*, const float* accum_rgba, uint64_t n_owned_pixels, uint32_t samples_done);
+int ptc_frame_set_sample_range(ptc_ctx*, uint32_t first_sample, uint32_t resolve_divisor);
+
 int ptc_get_stats(ptc_ctx*, ptc_stats* out);
 
 /* ---- multi-GPU: tiles shard over devices, one RCCL reduce brings the framebuffer to the root -----------

@@ -116,6 +116,8 @@ struct ptc_ctx {
   DevFrame fr{};
   int spp_total = 0, integrator = 0;
   uint32_t samples_done = 0;        // samples issued to the device
+  uint32_t sample_base = 0;         // index of the frame's first sample (ptc_frame_set_sample_range / ptc_frame_restore): sample k of the frame has index sample_base + k
+  uint32_t resolve_divisor = 0;     // 0: the resolve divides by the samples accumulated; else by this (sample-range sharding: partial means that sum to the mean)
   uint32_t pending = 0;             // samples accepted by frame_add_samples and not yet issued (deferred batching)
   uint32_t per_batch = 1;           // samples of one full batch = max_batch_paths / owned pixels / lanes
   DevBuf<uint32_t> owned;
@@ -349,7 +351,7 @@ int issue(ptc_ctx* c, uint32_t k) {
   const uint64_t cap = (uint64_t)c->fr.n_owned * k;
   int rc = ensure_lane_queues(c, (uint32_t)cap);
   if (rc) return rc;
-  if ((rc = run_batch(c, (int)(c->batches_issued % (uint64_t)c->n_lanes), c->samples_done, k))) return rc;
+  if ((rc = run_batch(c, (int)(c->batches_issued % (uint64_t)c->n_lanes), c->sample_base + c->samples_done, k))) return rc;
   c->samples_done += k;
   c->stats.paths += cap;
   return PTC_OK;
@@ -760,7 +762,7 @@ int ptc_frame_begin(ptc_ctx* c, int w, int h, int spp_total, uint64_t seed, int 
     c->fr.seed_hash = pcg((uint32_t)seed + pcg((uint32_t)(seed >> 32)));
   }
   c->spp_total = is_raster(integrator) ? 1 : spp_total;
-  c->integrator = integrator; c->samples_done = 0;
+  c->integrator = integrator; c->samples_done = 0; c->sample_base = 0; c->resolve_divisor = 0;
   // samples of one full batch: as many as fit max_batch_paths split over the lanes.  The queues themselves are sized by the
   // batches actually issued (frame_add_samples), not by spp_total: a progressive loop adding one sample at a time needs
   // queues for one sample per pixel only.
@@ -776,7 +778,11 @@ int ptc_frame_begin(ptc_ctx* c, int w, int h, int spp_total, uint64_t seed, int 
   size_t per = owned.empty() ? 1 : batch_paths / owned.size() / (size_t)c->n_lanes;
   if (per < 1) per = 1;
   if (per > 0x7fffffffu) per = 0x7fffffffu;
-  if (!owned.empty() && (uint64_t)owned.size() * per > 0xfffffff0ull) per = 0xfffffff0ull / owned.size();
+  {   // slot indices are 32 bits, and the segmented layout pads a batch by up to 64 slots per segment
+    const uint64_t max_slots = 0xfffffff0ull - 64ull * (uint64_t)c->cfg.shade_waves - 64ull;
+    if (!owned.empty() && (uint64_t)owned.size() * per > max_slots) per = max_slots / owned.size();
+    if (per < 1) per = 1;
+  }
   c->per_batch = (uint32_t)per;
   for (auto& ln : c->lanes) HIP_TRY(c, hipMemsetAsync(ln.q.stats, 0, ST_N * sizeof(unsigned long long), ln.stream));
   { int rs = sync_all_lanes(c); if (rs) return rs; }     // accum/radiance/statistics are cleared before any lane starts
@@ -823,8 +829,44 @@ int ptc_frame_resolve(ptc_ctx* c) {
   { int rj = join_lanes_on_stream0(c); if (rj) return rj; }
   // divisor: the samples accumulated so far, so a progressive viewer sees a correctly exposed image after every call
   if (c->fr.n_owned && c->samples_done)
-    pt_launch_resolve(c->lanes[0].stream, c->fr, c->accum.p, c->radiance.p, (float)c->samples_done, is_raster(c->integrator));
+    pt_launch_resolve(c->lanes[0].stream, c->fr, c->accum.p, c->radiance.p, (float)(c->resolve_divisor ? c->resolve_divisor : c->samples_done), is_raster(c->integrator));
   HIP_TRY(c, hipGetLastError());
+  return PTC_OK;
+}
+
+int ptc_frame_set_sample_range(ptc_ctx* c, uint32_t first_sample, uint32_t resolve_divisor) {
+  { int rd = need_device(c); if (rd) return rd; }
+  if (!c->in_frame) return fail(c, PTC_E_STATE, "frame_set_sample_range: no frame");
+  if (c->samples_done || c->pending) return fail(c, PTC_E_STATE, "frame_set_sample_range: call it right after ptc_frame_begin, before any sample");
+  if (is_raster(c->integrator)) return fail(c, PTC_E_ARG, "frame_set_sample_range: the raster integrators have one sample");
+  if ((uint64_t)first_sample + (uint64_t)c->spp_total > 0xffffffffull) return fail(c, PTC_E_ARG, "frame_set_sample_range: sample indices exceed 32 bits");
+  c->sample_base = first_sample; c->resolve_divisor = resolve_divisor;
+  return PTC_OK;
+}
+
+int ptc_frame_checkpoint(ptc_ctx* c, float* accum_rgba, uint64_t* n_owned_pixels, uint32_t* samples_done) {
+  { int rd = need_device(c); if (rd) return rd; }
+  if (!c->in_frame) return fail(c, PTC_E_STATE, "frame_checkpoint: no frame");
+  if (is_raster(c->integrator)) return fail(c, PTC_E_ARG, "frame_checkpoint: the raster integrators have nothing to resume");
+  { int rf = flush(c); if (rf) return rf; }
+  { int rs = sync_all_lanes(c); if (rs) return rs; }
+  if (n_owned_pixels) *n_owned_pixels = c->fr.n_owned;
+  if (samples_done) *samples_done = c->samples_done;
+  if (accum_rgba && c->fr.n_owned) HIP_TRY(c, hipMemcpy(accum_rgba, c->accum.p, (size_t)c->fr.n_owned * sizeof(float4), hipMemcpyDeviceToHost));
+  return PTC_OK;
+}
+
+int ptc_frame_restore(ptc_ctx* c, const float* accum_rgba, uint64_t n_owned_pixels, uint32_t samples_done) {
+  { int rd = need_device(c); if (rd) return rd; }
+  if (!c->in_frame) return fail(c, PTC_E_STATE, "frame_restore: no frame (ptc_frame_begin with the checkpointed frame's parameters first)");
+  if (!accum_rgba) return fail(c, PTC_E_ARG, "frame_restore: null pointer");
+  if (c->samples_done || c->pending) return fail(c, PTC_E_STATE, "frame_restore: call it right after ptc_frame_begin, before any sample");
+  if (is_raster(c->integrator)) return fail(c, PTC_E_ARG, "frame_restore: the raster integrators have nothing to resume");
+  if (n_owned_pixels != c->fr.n_owned) return fail(c, PTC_E_ARG, "frame_restore: the checkpoint is of another frame (size or tile share differ)");
+  if (samples_done > (uint32_t)c->spp_total) return fail(c, PTC_E_ARG, "frame_restore: more samples than this frame's spp_total");
+  { int rs = sync_all_lanes(c); if (rs) return rs; }
+  if (c->fr.n_owned) HIP_TRY(c, hipMemcpy(c->accum.p, accum_rgba, (size_t)c->fr.n_owned * sizeof(float4), hipMemcpyHostToDevice));
+  c->samples_done = samples_done;
   return PTC_OK;
 }
 

@@ -31,7 +31,7 @@ ABI_VERSION = 3
 ABI_SYMBOLS = [
     "ptc_create", "ptc_destroy", "ptc_last_error", "ptc_abi_version", "ptc_build_info", "ptc_scene_begin", "ptc_add_material",
     "ptc_add_texture_rgba8", "ptc_add_mesh", "ptc_add_instance", "ptc_add_instance_matrix", "ptc_update_instance", "ptc_update_instance_matrix", "ptc_scene_refit", "ptc_set_camera", "ptc_set_env_latlong_rgb32f", "ptc_set_texture_filter", "ptc_set_bvh_builder", "ptc_scene_commit", "ptc_render",
-    "ptc_frame_begin", "ptc_frame_add_samples", "ptc_frame_reserve", "ptc_frame_resolve", "ptc_sync", "ptc_read_radiance_rgba32f",
+    "ptc_frame_begin", "ptc_frame_add_samples", "ptc_frame_reserve", "ptc_frame_resolve", "ptc_frame_checkpoint", "ptc_frame_restore", "ptc_frame_set_sample_range", "ptc_sync", "ptc_read_radiance_rgba32f",
     "ptc_radiance_device_ptr", "ptc_write_radiance_rgba32f", "ptc_tonemap_rgba8", "ptc_get_stats",
     "ptc_debug_trace_closest", "ptc_debug_trace_any", "ptc_debug_get_flat_scene", "ptc_debug_get_bvh", "ptc_debug_get_counters",
     "ptc_debug_get_description", "ptc_debug_get_material", "ptc_debug_get_texture", "ptc_debug_get_internals",
@@ -101,6 +101,9 @@ def load_library():
     L.ptc_frame_add_samples.argtypes = [vp, C.c_int]
     L.ptc_frame_resolve.argtypes = [vp]
     L.ptc_frame_reserve.argtypes = [vp]
+    L.ptc_frame_checkpoint.argtypes = [vp, fp, C.POINTER(C.c_uint64), u32p]
+    L.ptc_frame_restore.argtypes = [vp, fp, C.c_uint64, C.c_uint32]
+    L.ptc_frame_set_sample_range.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.ptc_sync.argtypes = [vp]
     L.ptc_read_radiance_rgba32f.argtypes = [vp, fp]
     L.ptc_radiance_device_ptr.argtypes = [vp]
@@ -236,6 +239,21 @@ class PathTracer:
     def frame_begin(self, w, h, spp_total, seed=1, max_bounces=8, integrator=INTEGRATOR_PATH, tile_rank=0, tile_count=1):
         self._ck(self._L.ptc_frame_begin(self._h, w, h, spp_total, seed, max_bounces, integrator, tile_rank, tile_count))
         self._w, self._h_px = w, h
+
+    def frame_checkpoint(self):
+        """(per-pixel sums as an opaque (n_owned, 4) float32 array, samples in them) of the frame in progress (ptc_frame_checkpoint)."""
+        n, k = C.c_uint64(0), C.c_uint32(0)
+        self._ck(self._L.ptc_frame_checkpoint(self._h, None, C.byref(n), C.byref(k)))
+        acc = np.zeros((n.value, 4), np.float32)
+        self._ck(self._L.ptc_frame_checkpoint(self._h, acc.ctypes.data_as(C.POINTER(C.c_float)), C.byref(n), C.byref(k)))
+        return acc, int(k.value)
+
+    def frame_restore(self, accum, samples_done):
+        a = np.ascontiguousarray(accum, np.float32)
+        self._ck(self._L.ptc_frame_restore(self._h, a.ctypes.data_as(C.POINTER(C.c_float)), a.shape[0], samples_done))
+
+    def frame_set_sample_range(self, first_sample, resolve_divisor=0):
+        self._ck(self._L.ptc_frame_set_sample_range(self._h, first_sample, resolve_divisor))
 
     def frame_add_samples(self, n):
         self._ck(self._L.ptc_frame_add_samples(self._h, n))

@@ -341,3 +341,48 @@ def test_viewer_shim_renders_progressively_and_refits(gpu):
     assert r.returncode == 0, r.stdout + r.stderr
     info = json.loads(r.stdout.strip().splitlines()[0])
     assert info["rendered"] is True and info["triangles"] == 4 and info["frames"] == 6 and info["staging_sum"] > 0
+
+
+def test_checkpoint_resume_and_sample_ranges(gpu):
+    """SURVEY §5 / §8e options.  The RNG is counter-based and a pixel's sum is taken in sample order, so: checkpoint after k samples + restore in a NEW
+    context + the remaining samples = the uninterrupted frame, bit for bit; and a frame sharded by SAMPLE ranges (each share a partial mean, resolve_divisor =
+    spp) sums to the frame up to the rounding of fp32 sums taken in another order."""
+    d = gpu.scenes.atrium(0.05)
+    w, h, spp, seed, mb = 128, 72, 12, 11, 6
+    pt = gpu.PathTracer(0).load_scene(d)
+    full = pt.render(w, h, spp, seed=seed, max_bounces=mb)
+    for k in (5, 12, 0):
+        a = gpu.PathTracer(0).load_scene(d)
+        a.frame_begin(w, h, spp, seed, mb, 0)
+        if k:
+            a.frame_add_samples(k)
+        acc, done = a.frame_checkpoint()
+        assert done == k and acc.shape == (w * h, 4)
+        b = gpu.PathTracer(0).load_scene(d)
+        b.frame_begin(w, h, spp, seed, mb, 0)
+        b.frame_restore(acc, done)
+        if spp - k:
+            b.frame_add_samples(spp - k)
+        b.frame_resolve()
+        assert _bits_equal(b.read_radiance(), full), f"resumed after {k} samples"
+        with pytest.raises(gpu.PtcError):
+            b.frame_restore(acc, done)                               # only right after frame_begin
+    with pytest.raises(gpu.PtcError):
+        pt.frame_begin(w // 2, h, spp, seed, mb, 0)
+        pt.frame_restore(acc, done)                                  # another frame's checkpoint
+    # sample-range sharding: three shares of 4 samples each, all pixels, partial means
+    total = np.zeros_like(full)
+    for r in range(3):
+        pt.frame_begin(w, h, 4, seed, mb, 0)
+        pt.frame_set_sample_range(4 * r, spp)
+        pt.frame_add_samples(4)
+        pt.frame_resolve()
+        total += pt.read_radiance()
+    total[..., 3] = 1.0
+    rel = float(np.sqrt(((total[..., :3].astype(np.float64) - full[..., :3]) ** 2).sum()) / np.sqrt((full[..., :3].astype(np.float64) ** 2).sum()))
+    assert rel < 1e-6, rel
+    assert not _bits_equal(total, full) or True                      # equal to rounding, not necessarily bit for bit: why tiles are the default
+    pt.frame_begin(w, h, 4, seed, mb, 0)
+    pt.frame_add_samples(1)
+    with pytest.raises(gpu.PtcError):
+        pt.frame_set_sample_range(4, spp)                            # only before the first sample
