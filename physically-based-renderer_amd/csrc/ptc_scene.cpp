@@ -11,12 +11,135 @@
 #include "ptc_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <chrono>
+#include <pthread.h>
+#include <sched.h>
+#include <unistd.h>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <cstdio>
+#include <cstdlib>
 #include <memory>
+#include <new>
+#include <thread>
 
 namespace {
+
+// A parallel loop over [0, n) in chunks for the per-vertex / per-triangle / per-node passes of the flatten, of the emission and of a refit: independent
+// element by element, so the results do not depend on the split.  The workers are a small pool that sleeps between loops (PTC_HOST_THREADS or up to 16
+// threads, the caller included): threads created per loop would not do — a new thread starts on its parent's CPU and is moved to an idle one only at the
+// next scheduler tick, and a chunk of these passes (3 ms) is over before that: eight fresh threads ran one after the other.
+class HostPool {
+public:
+  static HostPool& get() {
+    static HostPool p;
+    static const int once = pthread_atfork(nullptr, nullptr, [] {      // a forked child has none of the workers: it forgets them (never joins them) and loops alone
+      HostPool& q = get();
+      new (&q.workers_) std::vector<std::thread>();
+      new (&q.cv_) std::condition_variable();          // the parent's workers wait on these: pthread_cond_destroy would wait for them to leave, forever
+      new (&q.finished_) std::condition_variable();
+      new (&q.m_) std::mutex();
+      new (&q.run_mutex_) std::mutex();
+      q.n_threads_ = 1;
+    });
+    (void)once;
+    return p;
+  }
+  unsigned size() const { return n_threads_; }
+  // fn(chunk) for chunk in [0, n_chunks), on the pool's threads and the caller
+  template <class F> void run(size_t n_chunks, F&& fn) {
+    if (n_chunks == 0) return;
+    if (n_threads_ <= 1 || n_chunks == 1) { for (size_t i = 0; i < n_chunks; ++i) fn(i); return; }
+    std::unique_lock<std::mutex> one(run_mutex_);          // one loop at a time (contexts on several host threads may commit concurrently)
+    std::function<void(size_t)> job = [&fn](size_t i) { fn(i); };
+    {
+      std::lock_guard<std::mutex> g(m_);
+      job_ = &job; n_chunks_ = n_chunks; next_.store(0); done_ = 0; ++epoch_;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> g(m_);
+    finished_.wait(g, [&] { return done_ == n_chunks_; });
+    job_ = nullptr;
+  }
+private:
+  HostPool() {
+    unsigned t = std::thread::hardware_concurrency();
+    if (const char* e = std::getenv("PTC_HOST_THREADS")) { const int v = std::atoi(e); if (v >= 1) t = (unsigned)v; }
+    n_threads_ = t < 1u ? 1u : (t > 16u ? 16u : t);
+    // A worker first visits a CPU of its own (the i-th of the process's allowed set, rotated by the process id) and then gets the whole set back:
+    // the scheduler wakes a sleeping thread on the CPU it last ran on when that CPU is idle, so the workers start their loops spread over the machine
+    // instead of queued behind the caller (where they sat for a whole 30 ms loop on a VM whose CPUs share no cache domain) — and they are not pinned.
+    cpu_set_t all;
+    CPU_ZERO(&all);
+    const bool have_set = sched_getaffinity(0, sizeof all, &all) == 0;
+    std::vector<int> allowed;
+    if (have_set) for (int c = 0; c < CPU_SETSIZE; ++c) if (CPU_ISSET(c, &all)) allowed.push_back(c);
+    const unsigned rot = (unsigned)getpid();
+    for (unsigned i = 1; i < n_threads_; ++i)
+      workers_.emplace_back([this, i, all, allowed, rot] {
+        if (allowed.size() > 1) {
+          cpu_set_t one;
+          CPU_ZERO(&one);
+          CPU_SET(allowed[(i + rot) % allowed.size()], &one);
+          if (pthread_setaffinity_np(pthread_self(), sizeof one, &one) == 0) { sched_yield(); (void)pthread_setaffinity_np(pthread_self(), sizeof all, &all); }
+        }
+        loop();
+      });
+  }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& w : workers_) w.join();
+  }
+  void work() {
+    size_t mine = 0;
+    for (;;) {
+      const size_t i = next_.fetch_add(1);
+      if (i >= n_chunks_) break;
+      (*job_)(i);
+      ++mine;
+    }
+    if (mine) { std::lock_guard<std::mutex> g(m_); done_ += mine; if (done_ == n_chunks_) finished_.notify_all(); }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [&] { return stop_ || epoch_ != seen; });
+        if (stop_) return;
+        seen = epoch_;
+      }
+      work();
+    }
+  }
+  unsigned n_threads_ = 1;
+  std::vector<std::thread> workers_;
+  std::mutex m_, run_mutex_;
+  std::condition_variable cv_, finished_;
+  const std::function<void(size_t)>* job_ = nullptr;
+  size_t n_chunks_ = 0, done_ = 0;
+  std::atomic<size_t> next_{0};
+  uint64_t epoch_ = 0;
+  bool stop_ = false;
+};
+template <class F> void parallel_for(size_t n, size_t min_chunk, F&& fn) {
+  HostPool& pool = HostPool::get();
+  size_t nc = min_chunk ? n / min_chunk : 1;                  // chunks: a few per thread, so that uneven ones even out
+  if (nc > (size_t)pool.size() * 4) nc = (size_t)pool.size() * 4;
+  if (nc <= 1 || pool.size() <= 1) { fn((size_t)0, n); return; }
+  const size_t per = (n + nc - 1) / nc;
+  pool.run(nc, [&](size_t c) {
+    const size_t lo = c * per, hi = lo + per < n ? lo + per : n;
+    if (lo < hi) fn(lo, hi);
+  });
+}
 
 constexpr int kLeafMax = 2;
 constexpr int kWide = 8;      // child slots per BVH node
@@ -304,6 +427,14 @@ std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vec
                            const std::vector<HostInstance>& insts, const std::vector<HostTexture>& texs, const HostEnv& env,
                            uint32_t toplet_budget, int bvh_builder, HostBuilt& B, bool refit) {
   if (insts.empty()) return "scene_commit: no instances";
+  const bool timing = std::getenv("PTC_BUILD_TIMING") != nullptr;      // phase times of the host build / refit on stderr
+  auto tprev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "  %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tprev).count());
+    tprev = now;
+  };
   uint64_t nv = 0, nt = 0;
   for (const auto& in : insts) { nv += meshes[(size_t)in.mesh].v.size(); nt += meshes[(size_t)in.mesh].idx.size() / 3; }
   if (nt >= (1u << 28)) return "scene_commit: too many triangles";
@@ -323,11 +454,30 @@ std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vec
   B.widx.resize(nt * 3);
   B.tri_mat.resize(nt);
   // ---- flatten ----------------------------------------------------------------------------------
-  uint32_t vb = 0, tb = 0;
-  for (const auto& in : insts) {
+  std::vector<uint32_t> inst_vb(insts.size()), inst_tb(insts.size());
+  {
+    uint32_t vb = 0, tb = 0;
+    for (size_t i = 0; i < insts.size(); ++i) {
+      inst_vb[i] = vb; inst_tb[i] = tb;
+      vb += (uint32_t)meshes[(size_t)insts[i].mesh].v.size(); tb += (uint32_t)(meshes[(size_t)insts[i].mesh].idx.size() / 3);
+    }
+  }
+  // work items: (instance, slice of 4096 of its vertices) and (instance, slice of its triangles), so that one large mesh does not serialise the pass
+  struct Slice { uint32_t inst, lo, hi; };
+  std::vector<Slice> vslices, tslices;
+  for (size_t i = 0; i < insts.size(); ++i) {
+    const HostMesh& m = meshes[(size_t)insts[i].mesh];
+    for (size_t lo = 0; lo < m.v.size(); lo += 4096) vslices.push_back({(uint32_t)i, (uint32_t)lo, (uint32_t)(lo + 4096 < m.v.size() ? lo + 4096 : m.v.size())});
+    const size_t ntm = m.idx.size() / 3;
+    for (size_t lo = 0; lo < ntm; lo += 8192) tslices.push_back({(uint32_t)i, (uint32_t)lo, (uint32_t)(lo + 8192 < ntm ? lo + 8192 : ntm)});
+  }
+  parallel_for(vslices.size(), 1, [&](size_t s0, size_t s1) {
+  for (size_t si = s0; si < s1; ++si) {
+    const HostInstance& in = insts[vslices[si].inst];
     const HostMesh& m = meshes[(size_t)in.mesh];
     const Mat34 M = from_matrix(in.m);
-    for (size_t k = 0; k < m.v.size(); ++k) {
+    const uint32_t vb = inst_vb[vslices[si].inst];
+    for (size_t k = vslices[si].lo; k < vslices[si].hi; ++k) {
       const HostVertex& s = m.v[k];
       HostVertex& d = B.wverts[vb + k];
       for (int r = 0; r < 3; ++r)   // m[0]*x + m[1]*y + m[2]*z + m[3]
@@ -348,14 +498,20 @@ std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vec
       d.texcoord[0] = s.texcoord[0];
       d.texcoord[1] = s.texcoord[1];
     }
-    const size_t ntm = m.idx.size() / 3;
-    for (size_t k = 0; k < ntm; ++k) {
+  }
+  });
+  parallel_for(tslices.size(), 1, [&](size_t s0, size_t s1) {
+  for (size_t si = s0; si < s1; ++si) {
+    const HostInstance& in = insts[tslices[si].inst];
+    const HostMesh& m = meshes[(size_t)in.mesh];
+    const uint32_t vb = inst_vb[tslices[si].inst], tb = inst_tb[tslices[si].inst];
+    for (size_t k = tslices[si].lo; k < tslices[si].hi; ++k) {
       for (int c = 0; c < 3; ++c) B.widx[(tb + k) * 3 + c] = vb + m.idx[k * 3 + c];
       B.tri_mat[tb + k] = m.material;
     }
-    vb += (uint32_t)m.v.size();
-    tb += (uint32_t)ntm;
   }
+  });
+  lap("flatten");
   const uint32_t n = (uint32_t)nt;
   B.n_tris = n;
   // NaN / Inf anywhere in the flattened positions (bad vertices or a bad instance matrix) is an error: the builder
@@ -365,15 +521,25 @@ std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vec
   // ---- triangle boxes, scene bounds ------------------------------------------------------------------
   std::vector<Box> tbox(n);
   Box sb = empty_box();
-  for (uint32_t p = 0; p < n; ++p) {
-    Box b = empty_box();
-    for (int c = 0; c < 3; ++c) {
-      const float* P = B.wverts[B.widx[p * 3 + c]].position;
-      for (int k = 0; k < 3; ++k) { b.lo[k] = P[k] < b.lo[k] ? P[k] : b.lo[k]; b.hi[k] = P[k] > b.hi[k] ? P[k] : b.hi[k]; }
-    }
-    tbox[p] = b;
-    grow(sb, b);
+  {
+    std::vector<Box> part(64, empty_box());          // min / max are exact and order-independent: the merge gives the sequential scene box
+    std::atomic<unsigned> next_part{0};
+    parallel_for(n, 16384, [&](size_t p0, size_t p1) {
+      Box mine = empty_box();
+      for (size_t p = p0; p < p1; ++p) {
+        Box b = empty_box();
+        for (int c = 0; c < 3; ++c) {
+          const float* P = B.wverts[B.widx[p * 3 + c]].position;
+          for (int k = 0; k < 3; ++k) { b.lo[k] = P[k] < b.lo[k] ? P[k] : b.lo[k]; b.hi[k] = P[k] > b.hi[k] ? P[k] : b.hi[k]; }
+        }
+        tbox[p] = b;
+        grow(mine, b);
+      }
+      part[next_part.fetch_add(1) % 64u] = mine;
+    });
+    for (const Box& b : part) if (b.lo[0] <= b.hi[0]) grow(sb, b);
   }
+  lap("triangle boxes");
   float diag = sb.hi[0] - sb.lo[0];
   if (sb.hi[1] - sb.lo[1] > diag) diag = sb.hi[1] - sb.lo[1];
   if (sb.hi[2] - sb.lo[2] > diag) diag = sb.hi[2] - sb.lo[2];
@@ -539,29 +705,25 @@ std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vec
   std::vector<uint32_t>& child_base = topo->child_base; // node index → index of its first interior child
   std::vector<uint32_t>& block_order = topo->block_order; // node indices in the order their children blocks were allocated
   // boxes of all radix nodes, bottom-up (iterative post-order)
-  auto compute_radix_boxes = [&]() {
+  auto compute_radix_boxes = [&]() {      // radix nodes are numbered parents-first: descending index order is a valid post-order
     radix_box.assign(radix.size(), empty_box());
-    if (radix.empty()) return;
-    std::vector<std::pair<int32_t, int>> stk{{0, 0}};
-    while (!stk.empty()) {
-      auto& top = stk.back();
-      const SplitNode& r = radix[(size_t)top.first];
-      if (top.second == 0) { top.second = 1; if (r.left >= 0) { stk.push_back({r.left, 0}); continue; } }
-      if (top.second == 1) { top.second = 2; if (r.right >= 0) { stk.push_back({r.right, 0}); continue; } }
+    for (size_t idx = radix.size(); idx-- > 0;) {
+      const SplitNode& r = radix[idx];
       Box b = r.left < 0 ? tbox[ord[(size_t)~r.left]] : radix_box[(size_t)r.left];
       grow(b, r.right < 0 ? tbox[ord[(size_t)~r.right]] : radix_box[(size_t)r.right]);
-      radix_box[(size_t)top.first] = b;
-      stk.pop_back();
+      radix_box[idx] = b;
     }
   };
   if (refit) {    // same tree, same slots: only the boxes of the children follow the moved triangles
     compute_radix_boxes();
-    for (Wide& w : wide)
-      for (int sl = 0; sl < kWide; ++sl) {
-        if (!w.used[sl]) continue;
-        WChild& ch = w.slot[sl];
-        ch.box = ch.radix >= 0 ? radix_box[(size_t)ch.radix] : tbox[ord[ch.lo]];
-      }
+    parallel_for(wide.size(), 2048, [&](size_t i0, size_t i1) {
+      for (size_t i = i0; i < i1; ++i)
+        for (int sl = 0; sl < kWide; ++sl) {
+          if (!wide[i].used[sl]) continue;
+          WChild& ch = wide[i].slot[sl];
+          ch.box = ch.radix >= 0 ? radix_box[(size_t)ch.radix] : tbox[ord[ch.lo]];
+        }
+    });
   } else if (n == 1) {   // a single triangle: two identical leaf children (mirrors the binary special case)
     WChild kid[2];
     for (int k = 0; k < 2; ++k) { kid[k].leaf = true; kid[k].lo = kid[k].hi = 0; kid[k].radix = -1; kid[k].box = tbox[0]; }
@@ -625,6 +787,7 @@ std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vec
       }
     }
   }
+  lap(refit ? "refit boxes" : "tree build + collapse");
   // ---- unit addresses: root at 0, then the children blocks in allocation order, each on a 64-byte boundary ---------------
   B.n_nodes = (uint32_t)order.size();
   std::vector<uint32_t>& node_addr = topo->node_addr;
@@ -647,13 +810,14 @@ std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vec
     if (next_unit >= (1ull << 31)) return "scene_commit: BVH too large";
   }
   // ---- emit nodes and triangles -----------------------------------------------------------------------------------------
-  B.recs.assign((size_t)next_unit * 4, 0.0f);
+  if (!refit) B.recs.assign((size_t)next_unit * 4, 0.0f);      // a refit rewrites every node and triangle record in place; the padding between blocks stays zero
   B.n_units = (uint32_t)next_unit;
   float grid_step[3];
   for (int k = 0; k < 3; ++k) { const float st = (sb.hi[k] - sb.lo[k]) / 65535.0f; grid_step[k] = st > 0.0f ? st : 1.0f; B.grid_lo[k] = sb.lo[k]; B.grid_step[k] = grid_step[k]; }
   uint32_t maxd = 0;
-  for (uint32_t idx = 0; idx < B.n_nodes; ++idx) {
-    if (order[idx].depth > maxd) maxd = order[idx].depth;
+  for (uint32_t idx = 0; idx < B.n_nodes; ++idx) if (order[idx].depth > maxd) maxd = order[idx].depth;
+  parallel_for(B.n_nodes, 1024, [&](size_t n0, size_t n1) {
+  for (uint32_t idx = (uint32_t)n0; idx < (uint32_t)n1; ++idx) {
     const Wide& w = wide[idx];
     uint32_t word[kNodeWords] = {0};
     uint32_t e[3], oq[3], qlo[3][kWide], qhi[3][kWide];
@@ -699,6 +863,8 @@ std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vec
     }
     std::memcpy(&B.recs[(size_t)node_addr[idx] * 4], word, sizeof word);
   }
+  });
+  lap("emit nodes + triangles");
   B.max_depth = maxd;
   B.n_tri_records = n_tri_records;
   B.n_lds_units = B.n_units < toplet_budget * 4u ? B.n_units : toplet_budget * 4u;
@@ -747,6 +913,7 @@ std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vec
     B.cdf[i] = run / total;
     B.lights[i * 20 + 7] = weight[i] / total;
   }
+  lap("materials + emitters");
   // ---- per-primitive shading records: positions + normals of the three vertices, material, emitter index; with a textured material in
   // the scene also uv / tangent / bitangent of the three vertices (units 5..10) and a unit of padding
   bool any_tex = false;
@@ -754,7 +921,8 @@ std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vec
   B.shade_stride = any_tex ? 12u : 5u;
   const size_t fl = (size_t)B.shade_stride * 4;
   B.shade.assign((size_t)n * fl, 0.0f);
-  for (uint32_t p = 0; p < n; ++p) {
+  parallel_for(n, 8192, [&](size_t p0, size_t p1) {
+  for (uint32_t p = (uint32_t)p0; p < (uint32_t)p1; ++p) {
     const HostVertex& a = B.wverts[B.widx[p * 3 + 0]];
     const HostVertex& b = B.wverts[B.widx[p * 3 + 1]];
     const HostVertex& c = B.wverts[B.widx[p * 3 + 2]];
@@ -774,6 +942,8 @@ std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vec
       }
     }
   }
+  });
+  lap("shading records");
   if (!refit) {      // textures and the environment do not depend on the instances' transforms
   for (const auto& t : texs) {
     const int32_t info[4] = {(int32_t)B.texels.size(), t.w, t.h, 0};
@@ -870,6 +1040,7 @@ std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vec
   if (!B.cdf.empty()) B.cdf.back() = 1.0f;
   if (B.cdf.empty()) B.cdf.push_back(1.0f);
   if (B.lights.empty()) B.lights.assign(20, 0.0f);
+  lap("textures + environment");
   B.topology = topo;
   return std::string();
 }

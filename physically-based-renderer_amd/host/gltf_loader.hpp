@@ -24,6 +24,7 @@
 #include <cstdint>
 #include <cstring>
 #include <fstream>
+#include <map>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -254,11 +255,73 @@ struct Doc {
     throw std::runtime_error("unsupported accessor type " + t);
   }
   struct View { const std::uint8_t* base; size_t stride, count; long ct; int ncomp; bool normalized; };
+  mutable std::map<long, std::vector<std::uint8_t>> dense;     // sparse accessors, materialised (tightly packed) on first use
+  // `n` bytes at byteOffset `off` of bufferView `bv`, bounds-checked (sparse indices / values: tightly packed, no stride)
+  const std::uint8_t* view_bytes(long bv, long off, size_t n) const {
+    const auto& bvs = root.array("bufferViews");
+    if (bv < 0 || (size_t)bv >= bvs.size() || off < 0) throw std::runtime_error("sparse accessor: bufferView index or offset out of range");
+    const JValue& v = bvs[(size_t)bv];
+    const long buf = v.integer("buffer", -1), off_v = v.integer("byteOffset", 0), len_v = v.integer("byteLength", 0);
+    if (buf < 0 || (size_t)buf >= buffers.size() || off_v < 0 || len_v < 0) throw std::runtime_error("buffer index out of range");
+    const auto& data = buffers[(size_t)buf];
+    const size_t o = (size_t)off_v + (size_t)off;
+    if ((size_t)off > (size_t)len_v || n > (size_t)len_v - (size_t)off || o > data.size() || n > data.size() - o) throw std::runtime_error("sparse accessor exceeds its bufferView");
+    return data.data() + o;
+  }
+  // glTF 2.0 §3.6.2.3: a sparse accessor is its bufferView's elements (zeros without one) with `sparse.count` of them replaced: element
+  // indices[i] (strictly increasing, < count) takes values[i]
+  View sparse_view(long accessor, const JValue& a) const {
+    View r;
+    r.ct = a.integer("componentType", 0);
+    r.ncomp = type_count(a.string("type"));
+    const long count = a.integer("count", 0);
+    if (count < 0) throw std::runtime_error("accessor with a negative count, stride or offset");
+    r.count = (size_t)count;
+    r.normalized = a.get("normalized") && a.get("normalized")->b;
+    const size_t elem = comp_size(r.ct) * (size_t)r.ncomp;
+    r.stride = elem;
+    auto it = dense.find(accessor);
+    if (it == dense.end()) {
+      if (r.count > (size_t)1 << 28) throw std::runtime_error("sparse accessor: too many elements");
+      std::vector<std::uint8_t> d(r.count * elem, 0);
+      if (a.integer("bufferView", -1) >= 0) {
+        JValue base = a;                              // the same accessor without its sparse part
+        for (size_t k = 0; k < base.obj.size(); ++k) if (base.obj[k].first == "sparse") { base.obj.erase(base.obj.begin() + (long)k); break; }
+        const View b = view_of(accessor, base);
+        for (size_t i = 0; i < r.count; ++i) std::memcpy(&d[i * elem], b.base + i * b.stride, elem);
+      }
+      const JValue& sp = *a.get("sparse");
+      const long n = sp.integer("count", 0);
+      const JValue* ind = sp.get("indices"); const JValue* val = sp.get("values");
+      if (n < 0 || !ind || !val) throw std::runtime_error("sparse accessor: bad count, or indices / values missing");
+      const long ict = ind->integer("componentType", 0);
+      if (ict != 5121 && ict != 5123 && ict != 5125) throw std::runtime_error("sparse accessor: indices must be UNSIGNED_BYTE / SHORT / INT");
+      const size_t isz = comp_size(ict);
+      if ((size_t)n > r.count) throw std::runtime_error("sparse accessor: more replacements than elements");
+      const std::uint8_t* ip = view_bytes(ind->integer("bufferView", -1), ind->integer("byteOffset", 0), (size_t)n * isz);
+      const std::uint8_t* vp = view_bytes(val->integer("bufferView", -1), val->integer("byteOffset", 0), (size_t)n * elem);
+      long prev = -1;
+      for (long i = 0; i < n; ++i) {
+        std::uint32_t k = 0;
+        if (isz == 1) k = ip[i]; else if (isz == 2) { std::uint16_t u; std::memcpy(&u, ip + 2 * i, 2); k = u; } else std::memcpy(&k, ip + 4 * i, 4);
+        if ((long)k <= prev || k >= r.count) throw std::runtime_error("sparse accessor: indices must be strictly increasing and below count");
+        prev = (long)k;
+        std::memcpy(&d[(size_t)k * elem], vp + (size_t)i * elem, elem);
+      }
+      it = dense.emplace(accessor, std::move(d)).first;
+    }
+    r.base = it->second.data();
+    return r;
+  }
   View view(long accessor) const {
     const auto& accs = root.array("accessors");
     if (accessor < 0 || (size_t)accessor >= accs.size()) throw std::runtime_error("accessor index out of range");
     const JValue& a = accs[(size_t)accessor];
-    if (a.get("sparse")) throw std::runtime_error("sparse accessors are not supported");
+    if (a.get("sparse")) return sparse_view(accessor, a);
+    return view_of(accessor, a);
+  }
+  View view_of(long accessor, const JValue& a) const {
+    (void)accessor;
     const long bv = a.integer("bufferView", -1);
     if (bv < 0) throw std::runtime_error("accessor without bufferView");
     const auto& bvs = root.array("bufferViews");

@@ -381,6 +381,9 @@ def test_bench_two_rank_rehearsal(gpu):
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 2       # the default: the frame is fixed, ranks split its pixels
     assert d["config"]["paths"] == 256 * 192 * 2 * 2 and d["value"] > 0              # 2 spp per step, 2 steps, whole frame
     assert d["per_path"]["segments"] > 1.0 and "torch.distributed.reduce" in d["config"]["sharding"]
+    pr = d["per_rank"]                                                             # what makes a scaling point readable: per-rank kernel sums, wall, paths
+    assert len(pr["wall"]["ranks"]) == 2 and 0 < pr["wall"]["min"] <= pr["wall"]["max"] and sum(pr["paths"]["ranks"]) == d["config"]["paths"]
+    assert pr["seconds_trace_closest"]["min"] > 0 and "reduce_ms" in pr and "written from the generator by rank 0" in d["config"]["scene_source"]
     r = run_torchrun(2, args + ["--scaling", "weak"], cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
