@@ -138,3 +138,53 @@ def test_oracle_argument_errors(ora, pbr):
     for bad in [dict(w=0, h=8, spp=1), dict(w=8, h=8, spp=0), dict(w=8, h=8, spp=1, integrator=7), dict(w=8, h=8, spp=1, tile_rank=2, tile_count=2)]:
         with pytest.raises(RuntimeError):
             o.render(**bad)
+
+
+def test_refitted_tree_answers_like_brute_force_and_like_a_fresh_build(ora, pbr):
+    """ora_scene_refit (the specification of ptc_scene_refit): after the instances move, the refitted tree gives, for fixed rays, exactly the hit records
+    of a FRESH build of the moved scene (closest hit and occlusion are properties of the triangles, not of the tree) — and those agree with a brute-force
+    test of every triangle in float64.  Two turns: the second refits a refitted tree."""
+    import copy
+    import math
+
+    from golden.make_golden import fixed_rays
+
+    d = pbr.scenes.sphere_scene()
+    o = ora.Oracle().load_scene(d)
+    org, dirs, tmax = fixed_rays(d)
+    d2 = copy.deepcopy(d)
+    for turn in (1, 2):
+        for i, it in enumerate(d2.instances):
+            a = 0.4 * turn + 0.3 * i
+            q = (math.cos(a / 2), math.sin(a / 2) * 0.6, math.sin(a / 2) * 0.8, 0.0)
+            t = (d.instances[i].t[0] + 0.1 * turn, d.instances[i].t[1] - 0.05 * i, d.instances[i].t[2])
+            s = tuple(x * (1.0 + 0.1 * turn) for x in d.instances[i].s)
+            it.t, it.q_wxyz, it.s = t, q, s
+            o.update_instance(i, t, q, s)
+        o.scene_refit()
+        t1, p1, uv1 = o.trace_closest(org, dirs)
+        occ1 = o.trace_any(org, dirs, tmax)
+        fresh = ora.Oracle().load_scene(d2)
+        t2, p2, uv2 = fresh.trace_closest(org, dirs)
+        assert np.array_equal(t1.view(np.uint32), t2.view(np.uint32)) and np.array_equal(p1, p2) and np.array_equal(uv1.view(np.uint32), uv2.view(np.uint32))
+        assert np.array_equal(occ1, fresh.trace_any(org, dirs, tmax))
+        assert o.stats()["node_visits_closest"] != fresh.stats()["node_visits_closest"] or turn == 0      # another tree: other counters, same answers
+        verts, idx, _ = o.flat_scene()
+        P = verts[:, :3].astype(np.float64)
+        a_, b_, c_ = P[idx[:, 0]], P[idx[:, 1]], P[idx[:, 2]]
+        e1, e2 = b_ - a_, c_ - a_
+        for k in range(0, 4096, 211):
+            oo, dd = org[k].astype(np.float64), dirs[k].astype(np.float64)
+            pv = np.cross(dd, e2)
+            det = (e1 * pv).sum(1)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                inv = 1.0 / det
+                tv = oo - a_
+                u = (tv * pv).sum(1) * inv
+                v = (np.cross(tv, e1) * dd).sum(1) * inv
+                tt = (e2 * np.cross(tv, e1)).sum(1) * inv
+            ok = (det != 0) & (u >= 0) & (u <= 1) & (v >= 0) & (u + v <= 1) & (tt > 0)
+            if not ok.any():
+                assert p1[k] == -1
+            else:
+                assert p1[k] >= 0 and abs(t1[k] - tt[ok].min()) <= 1e-4 * max(1.0, tt[ok].min())
