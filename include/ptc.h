@@ -275,6 +275,8 @@ int ptc_group_size(const ptc_group*);
  * builds the BVH once on the host (unless device 0 has committed it already: that build is then used) and uploads that one build to
  * every device (N contexts committing on their own would each repeat the build, one after the other on the calling thread). */
 int ptc_group_scene_commit(ptc_group*);
+/* Scene dynamics for a group: ptc_update_instance* on ptc_group_ctx(g, 0), then ONE refit on the host whose arrays go to every device. */
+int ptc_group_scene_refit(ptc_group*);
 ptc_ctx* ptc_group_ctx(ptc_group*, int i);
 int ptc_group_render(ptc_group*, int w, int h, int spp, uint64_t seed, int max_bounces, int integrator);
 const char* ptc_group_last_error(const ptc_group*);

@@ -581,7 +581,26 @@ int ptc_add_instance_matrix(ptc_ctx* c, int mesh, const float model[16]) {
   return (int)c->insts.size() - 1;
 }
 
-namespace { int commit_upload(ptc_ctx* c, std::chrono::steady_clock::time_point t0); }
+namespace {
+int commit_upload(ptc_ctx* c, std::chrono::steady_clock::time_point t0);
+// Device half of a refit: c->built holds the refitted arrays.  same_sizes: overwrite in place what depends on the vertex positions (textures,
+// environment and materials stay where they are); else (an emitter appeared or vanished under a degenerate scale) upload everything.
+int refit_upload(ptc_ctx* c, bool same_sizes, std::chrono::steady_clock::time_point t0) {
+  const HostBuilt& B = *c->built;
+  if (!same_sizes) return commit_upload(c, t0);
+  HIP_TRY(c, hipMemcpy((void*)c->dsc.recs, B.recs.data(), B.recs.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy((void*)c->dsc.shade, B.shade.data(), B.shade.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy((void*)c->dsc.lights, B.lights.data(), B.lights.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy((void*)c->dsc.cdf, B.cdf.data(), B.cdf.size() * 4, hipMemcpyHostToDevice));
+  c->dsc.ray_eps = B.ray_eps; c->dsc.n_lights = B.n_lights;
+  for (int k = 0; k < 3; ++k) { c->dsc.grid_lo[k] = B.grid_lo[k]; c->dsc.grid_step[k] = B.grid_step[k]; }
+  for (int l = 0; l < c->n_lanes; ++l) {
+    const DevScene ds = lane_scene(c, l);
+    HIP_TRY(c, hipMemcpy(c->lanes[(size_t)l].d_scene, &ds, sizeof ds, hipMemcpyHostToDevice));
+  }
+  return PTC_OK;
+}
+}  // namespace
 
 int ptc_update_instance_matrix(ptc_ctx* c, int instance, const float model[16]) {
   if (!c) return PTC_E_ARG;
@@ -615,22 +634,8 @@ int ptc_scene_refit(ptc_ctx* c) {
   if (!e.empty()) return fail(c, PTC_E_STATE, e);
   c->in_frame = false; c->pending = 0;
   if (c->device >= 0) {
-    if (B.recs.size() != n_recs || B.shade.size() != n_shade || B.lights.size() != n_lights || B.cdf.size() != n_cdf) {
-      int rc = commit_upload(c, t0);                   // an emitter appeared or vanished (degenerate scale): the tables change size, upload everything
-      if (rc) return rc;
-    } else {
-      // same sizes: overwrite in place what depends on the vertex positions; textures, environment and materials stay where they are
-      HIP_TRY(c, hipMemcpy((void*)c->dsc.recs, B.recs.data(), B.recs.size() * 4, hipMemcpyHostToDevice));
-      HIP_TRY(c, hipMemcpy((void*)c->dsc.shade, B.shade.data(), B.shade.size() * 4, hipMemcpyHostToDevice));
-      HIP_TRY(c, hipMemcpy((void*)c->dsc.lights, B.lights.data(), B.lights.size() * 4, hipMemcpyHostToDevice));
-      HIP_TRY(c, hipMemcpy((void*)c->dsc.cdf, B.cdf.data(), B.cdf.size() * 4, hipMemcpyHostToDevice));
-      c->dsc.ray_eps = B.ray_eps; c->dsc.n_lights = B.n_lights;
-      for (int k = 0; k < 3; ++k) { c->dsc.grid_lo[k] = B.grid_lo[k]; c->dsc.grid_step[k] = B.grid_step[k]; }
-      for (int l = 0; l < c->n_lanes; ++l) {
-        const DevScene ds = lane_scene(c, l);
-        HIP_TRY(c, hipMemcpy(c->lanes[(size_t)l].d_scene, &ds, sizeof ds, hipMemcpyHostToDevice));
-      }
-    }
+    int rc = refit_upload(c, B.recs.size() == n_recs && B.shade.size() == n_shade && B.lights.size() == n_lights && B.cdf.size() == n_cdf, t0);
+    if (rc) return rc;
   }
   c->stats.seconds_refit = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return PTC_OK;
@@ -1041,6 +1046,35 @@ int ptc_group_scene_commit(ptc_group* g) {
 }
 ptc_ctx* ptc_group_ctx(ptc_group* g, int i) { return (g && i >= 0 && (size_t)i < g->ctx.size()) ? g->ctx[(size_t)i] : nullptr; }
 const char* ptc_group_last_error(const ptc_group* g) { return g ? g->err.c_str() : g_create_error.c_str(); }
+
+int ptc_group_scene_refit(ptc_group* g) {
+  if (!g || g->ctx.empty()) return PTC_E_ARG;
+  ptc_ctx* c0 = g->ctx[0];
+  if (!c0->committed) { g->err = "ptc_group_scene_refit: the group's scene is not committed"; return PTC_E_STATE; }
+  // device 0's instances carry the new transforms (ptc_update_instance* on ptc_group_ctx(g, 0)): one refit on the host, the arrays go to every device
+  for (ptc_ctx* c : g->ctx) {
+    if (hipSetDevice(c->device) != hipSuccess) { g->err = "ptc_group_scene_refit: hipSetDevice failed"; return PTC_E_DEVICE; }
+    int rc = flush(c); if (!rc) rc = sync_all_lanes(c);
+    if (rc) { g->err = std::string("ptc_group_scene_refit: ") + ptc_last_error(c); return rc; }
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  auto built = std::make_shared<HostBuilt>(*c0->built);                 // the devices keep rendering from the old arrays until theirs are overwritten
+  const size_t n_recs = built->recs.size(), n_shade = built->shade.size(), n_lights = built->lights.size(), n_cdf = built->cdf.size();
+  const std::string e = ptc_refit_scene(c0->mats, c0->meshes, c0->insts, c0->texs, c0->env, *built);
+  if (!e.empty()) { g->err = e; return PTC_E_STATE; }
+  const bool same = built->recs.size() == n_recs && built->shade.size() == n_shade && built->lights.size() == n_lights && built->cdf.size() == n_cdf;
+  for (size_t i = 0; i < g->ctx.size(); ++i) {
+    ptc_ctx* c = g->ctx[i];
+    if (hipSetDevice(c->device) != hipSuccess) { g->err = "ptc_group_scene_refit: hipSetDevice failed"; return PTC_E_DEVICE; }
+    if (i) c->insts = c0->insts;
+    c->built = built;
+    c->in_frame = false; c->pending = 0;
+    const int rc = refit_upload(c, same, t0);
+    if (rc) { g->err = "device " + std::to_string(i) + ": " + ptc_last_error(c); return rc; }
+    c->stats.seconds_refit = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  return PTC_OK;
+}
 
 int ptc_group_render(ptc_group* g, int w, int h, int spp, uint64_t seed, int max_bounces, int integrator) {
   if (!g || g->ctx.empty()) return PTC_E_ARG;

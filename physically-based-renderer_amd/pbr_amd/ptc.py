@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     "ptc_debug_get_description", "ptc_debug_get_material", "ptc_debug_get_texture", "ptc_debug_get_internals",
     "ptc_read_radiance_rgba16f", "ptc_radiance_rgba16f_device_ptr",
     "ptc_comm_unique_id", "ptc_comm_init", "ptc_comm_reduce_radiance", "ptc_comm_destroy",
-    "ptc_group_create", "ptc_group_size", "ptc_group_scene_commit", "ptc_group_ctx", "ptc_group_render", "ptc_group_last_error", "ptc_group_destroy",
+    "ptc_group_create", "ptc_group_size", "ptc_group_scene_commit", "ptc_group_scene_refit", "ptc_group_ctx", "ptc_group_render", "ptc_group_last_error", "ptc_group_destroy",
 ]
 
 
@@ -131,6 +131,7 @@ def load_library():
     L.ptc_group_create.restype = vp
     L.ptc_group_size.argtypes = [vp]
     L.ptc_group_scene_commit.argtypes = [vp]
+    L.ptc_group_scene_refit.argtypes = [vp]
     L.ptc_group_ctx.argtypes = [vp, C.c_int]
     L.ptc_group_ctx.restype = vp
     L.ptc_group_render.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int]
@@ -405,6 +406,13 @@ class Group:
         """Describe the scene on device 0 and commit it to every device with ONE host build (ptc_group_scene_commit)."""
         self._ctx[0].load_scene(desc)
         rc = self._L.ptc_group_scene_commit(self._g)
+        if rc < 0:
+            raise PtcError(f"ptc error {rc}: {self._L.ptc_group_last_error(self._g).decode()}")
+        return self
+
+    def scene_refit(self):
+        """After ctx(0).update_instance(...): one host refit, uploaded to every device (ptc_group_scene_refit)."""
+        rc = self._L.ptc_group_scene_refit(self._g)
         if rc < 0:
             raise PtcError(f"ptc error {rc}: {self._L.ptc_group_last_error(self._g).decode()}")
         return self

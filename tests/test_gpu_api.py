@@ -220,6 +220,13 @@ def test_rccl_through_the_c_abi_single_rank(gpu):
     pt.comm_destroy()
     g = gpu.Group([0]).load_scene(gpu.scenes.cornell_box())        # ptc_group_scene_commit: described on device 0, one host build for the group
     assert g.ctx(0).stats()["n_triangles"] == 12
+    g.ctx(0).update_instance(0, (0.0, 0.05, 0.0), (1.0, 0.0, 0.0, 0.0), (1.0, 1.0, 1.0))       # dynamics for a group: one host refit for all devices
+    g.scene_refit()
+    moved = gpu.scenes.cornell_box()
+    moved.instances[0].t = (0.0, 0.05, 0.0)
+    assert _bits_equal(g.render(96, 64, 4, seed=6), gpu.PathTracer(0).load_scene(moved).render(96, 64, 4, seed=6))
+    g.ctx(0).update_instance(0, (0.0, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
+    g.scene_refit()
     assert len(g) == 1 and _bits_equal(g.render(96, 64, 4, seed=6), ref)
     g.close()
     with pytest.raises(gpu.PtcError):
