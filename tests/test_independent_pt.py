@@ -12,18 +12,21 @@ import pytest
 
 
 def _independent_cornell(pbr, w, h, spp, max_bounces, seed):
-    d = pbr.scenes.cornell_box()
-    tris, alb, emi = [], [], []
+    return _independent(pbr.scenes.cornell_box(), w, h, spp, max_bounces, seed)
+
+
+def _independent(d, w, h, spp, max_bounces, seed):
+    tris, alb, emi, met, rough = [], [], [], [], []
     for inst in d.instances:                                            # identity transforms in this scene: positions are world positions
         m = d.meshes[inst.mesh]
         P = np.asarray(m.vertices["position"], np.float64)
         I = np.asarray(m.indices, np.int64).reshape(-1, 3)
         mat = d.materials[m.material]
         for a, b, c in I:
-            tris.append((P[a], P[b], P[c])); alb.append(mat.base_color[:3]); emi.append(mat.emissive)
+            tris.append((P[a], P[b], P[c])); alb.append(mat.base_color[:3]); emi.append(mat.emissive); met.append(mat.metallic); rough.append(mat.roughness)
     A = np.array([t[0] for t in tris]); E1 = np.array([t[1] - t[0] for t in tris]); E2 = np.array([t[2] - t[0] for t in tris])
     NG = np.cross(E1, E2); NG /= np.linalg.norm(NG, axis=1, keepdims=True)
-    alb, emi = np.asarray(alb, np.float64), np.asarray(emi, np.float64)
+    alb, emi, met, rough = np.asarray(alb, np.float64), np.asarray(emi, np.float64), np.asarray(met, np.float64), np.asarray(rough, np.float64)
     cam = d.camera
     eye, tgt = np.asarray(cam.position, np.float64), np.asarray(cam.target, np.float64)
     f = (tgt - eye) / np.linalg.norm(tgt - eye)                         # glm::lookAtRH(eye, target, up = (0,-1,0)): CameraData.hpp:22-32
@@ -36,7 +39,7 @@ def _independent_cornell(pbr, w, h, spp, max_bounces, seed):
     px, py = px.reshape(-1).astype(np.float64), py.reshape(-1).astype(np.float64)
     n = px.size
     for _ in range(spp):
-        x = (2 * (px + rng.random(n)) / w - 1) * th * 1.0               # aspect 1
+        x = (2 * (px + rng.random(n)) / w - 1) * th * cam.aspect
         y = (2 * (py + rng.random(n)) / h - 1) * th
         dirs = x[:, None] * s + y[:, None] * u + f
         dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
@@ -74,7 +77,26 @@ def _independent_cornell(pbr, w, h, spp, max_bounces, seed):
             t1 = np.cross(a_, nn); t1 /= np.linalg.norm(t1, axis=1, keepdims=True)
             t2 = np.cross(nn, t1)
             wi = t1 * (r * np.cos(phi))[:, None] + t2 * (r * np.sin(phi))[:, None] + nn * z[:, None]
-            T = T * alb[k] * (2 * z)[:, None]
+            # BRDF from its definition: Lambert base(1-m)/pi + Cook-Torrance D G F / (4 n.v n.l), GGX D, separable Smith G1,
+            # Schlick F, alpha = max(r^2, 1e-3), F0 = 0.04 (1-m) + base m; materials with metallic 0 and roughness >= 1 are Lambert only
+            m_, r_ = met[k][:, None], rough[k]
+            cd = alb[k] * (1 - m_)
+            fr = cd / math.pi
+            ggx = ~((met[k] == 0) & (r_ >= 1))
+            if ggx.any():
+                wo = -dirs
+                nv = np.maximum((nn * wo).sum(1), 1e-4)
+                hv = wo + wi
+                hv /= np.maximum(np.linalg.norm(hv, axis=1, keepdims=True), 1e-30)
+                nh, vh = (nn * hv).sum(1), (wo * hv).sum(1)
+                al = np.maximum(r_ * r_, 1e-3); a2 = al * al
+                D = a2 / (math.pi * (nh * nh * (a2 - 1) + 1) ** 2)
+                g1 = lambda x: 2 * x / (x + np.sqrt(a2 + (1 - a2) * x * x))
+                F0 = 0.04 * (1 - m_) + alb[k] * m_
+                F = F0 + (1 - F0) * (np.maximum(1 - vh, 0.0) ** 5)[:, None]
+                spec = (D * g1(nv) * g1(np.maximum(z, 1e-9)) / (4 * nv * np.maximum(z, 1e-9)))[:, None] * F
+                fr = fr + np.where(ggx[:, None], spec, 0.0)
+            T = T * fr * (2 * math.pi * z)[:, None]                      # f cos / pdf, pdf = 1 / (2 pi)
             org, dirs = P, wi
             alive &= T.max(1) > 0
             T = np.where(alive[:, None], T, 0.0)
@@ -110,3 +132,35 @@ def test_an_independent_estimator_agrees_with_the_oracle_on_the_cornell_box(ora,
     for im in (ref, ind):
         assert im[:, :3, 1].mean() > 2 * im[:, :3, 0].mean() and im[:, -3:, 0].mean() > 2 * im[:, -3:, 1].mean()
         assert im[:4].mean() > im[-4:].mean() * 0.5
+
+
+def test_an_independent_estimator_agrees_on_a_ggx_surface(ora, pbr):
+    """The same cross-check where the oracle's path is at its most intricate: a rough metal-dielectric GGX floor (VNDF sampling, lobe selection, Fresnel, MIS
+    between BSDF sampling and light sampling) under an emissive quad, seen at a grazing-ish angle.  The independent estimator evaluates the BRDF from its
+    definition and samples the hemisphere uniformly."""
+    sc = pbr.scene
+    quad = pbr.scenes._quad
+    mats = [sc.Material((0.8, 0.6, 0.4, 1.0), 0.3, 0.5), sc.Material((0.0, 0.0, 0.0, 1.0), 0.0, 1.0, (6.0, 6.0, 6.0)), sc.Material((0.5, 0.5, 0.7, 1.0), 0.0, 1.0)]
+    q = [(quad((-2, 0, 2), (2, 0, 2), (2, 0, -2), (-2, 0, -2)), 0),                     # floor, normal +y: GGX
+         (quad((-0.8, 1.5, -0.8), (0.8, 1.5, -0.8), (0.8, 1.5, 0.8), (-0.8, 1.5, 0.8)), 1),   # light, normal -y
+         (quad((-2, 0, -2), (2, 0, -2), (2, 2.5, -2), (-2, 2.5, -2)), 2)]               # back wall, normal +z: Lambert
+    meshes = [sc.MeshDesc(v, i, m) for (v, i), m in q]
+    inst = [sc.InstanceDesc(k, (0.0, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0), (1.0, 1.0, 1.0)) for k in range(3)]
+    d = sc.SceneDesc(mats, meshes, inst, sc.CameraDesc((0.0, 0.9, 3.2), (0.0, 0.2, 0.0), math.radians(50.0), 1.0), "ggx_floor")
+    w = h = 16
+    mb = 3
+    ind, var = _independent(d, w, h, 3000, mb, seed=4052)
+    o = ora.Oracle().load_scene(d)
+    r1 = o.render(w, h, 512, seed=5, max_bounces=mb)[..., :3].astype(np.float64)
+    r2 = o.render(w, h, 512, seed=6, max_bounces=mb)[..., :3].astype(np.float64)
+    ref, ovar = 0.5 * (r1 + r2), ((r1 - r2) ** 2) / 4
+    se = math.sqrt(var.sum() + ovar.sum()) / var.size
+    assert ref.mean() > 0.05
+    assert abs(ind.mean() - ref.mean()) <= 4 * se + 0.015 * ref.mean(), (ind.mean(), ref.mean(), se)
+    B = 4
+    for c in range(3):
+        a = ind[..., c].reshape(h // B, B, w // B, B).mean((1, 3))
+        b = ref[..., c].reshape(h // B, B, w // B, B).mean((1, 3))
+        s = np.sqrt((var[..., c] + ovar[..., c]).reshape(h // B, B, w // B, B).sum((1, 3))) / (B * B)
+        bad = np.abs(a - b) > 4 * s + 0.04 * np.maximum(b, 0.02)
+        assert not bad.any(), (c, a[bad], b[bad], s[bad])
