@@ -64,6 +64,14 @@ def _independent(d, w, h, spp, max_bounces, seed):
             ng = NG[k]
             front = (ng * -dirs).sum(1) > 0
             L += np.where((hit & front)[:, None], T * emi[k], 0.0)       # one-sided emission
+            env = getattr(d, "env", None)
+            if env is not None:                                          # a ray that leaves the scene sees the lat-long environment: row 0 = +y,
+                miss = alive & ~np.isfinite(th_)                         # u = atan2(d.z, d.x) / 2 pi + 1/2, v = acos(d.y) / pi, piecewise-constant texels
+                eh, ew = env.shape[:2]
+                uu_ = np.arctan2(dirs[:, 2], dirs[:, 0]) / (2 * math.pi) + 0.5
+                vv_ = np.arccos(np.clip(dirs[:, 1], -1.0, 1.0)) / math.pi
+                ex = np.clip((uu_ * ew).astype(np.int64), 0, ew - 1); ey = np.clip((vv_ * eh).astype(np.int64), 0, eh - 1)
+                L += np.where(miss[:, None], T * np.asarray(env, np.float64)[ey, ex], 0.0)
             alive = hit
             if b == max_bounces:
                 break
@@ -153,6 +161,42 @@ def test_an_independent_estimator_agrees_on_a_ggx_surface(ora, pbr):
     o = ora.Oracle().load_scene(d)
     r1 = o.render(w, h, 512, seed=5, max_bounces=mb)[..., :3].astype(np.float64)
     r2 = o.render(w, h, 512, seed=6, max_bounces=mb)[..., :3].astype(np.float64)
+    ref, ovar = 0.5 * (r1 + r2), ((r1 - r2) ** 2) / 4
+    se = math.sqrt(var.sum() + ovar.sum()) / var.size
+    assert ref.mean() > 0.05
+    assert abs(ind.mean() - ref.mean()) <= 4 * se + 0.015 * ref.mean(), (ind.mean(), ref.mean(), se)
+    B = 4
+    for c in range(3):
+        a = ind[..., c].reshape(h // B, B, w // B, B).mean((1, 3))
+        b = ref[..., c].reshape(h // B, B, w // B, B).mean((1, 3))
+        s = np.sqrt((var[..., c] + ovar[..., c]).reshape(h // B, B, w // B, B).sum((1, 3))) / (B * B)
+        bad = np.abs(a - b) > 4 * s + 0.04 * np.maximum(b, 0.02)
+        assert not bad.any(), (c, a[bad], b[bad], s[bad])
+
+
+def test_an_independent_estimator_agrees_under_an_environment_light(ora, pbr):
+    """... and with the lat-long environment as the only light: the oracle importance-samples it (row / column cdfs, MIS against BSDF sampling), the independent
+    estimator only looks it up, from the mapping's definition, where a path leaves the scene."""
+    sc = pbr.scene
+    quad = pbr.scenes._quad
+    mats = [sc.Material((0.7, 0.7, 0.6, 1.0), 0.0, 0.6), sc.Material((0.6, 0.3, 0.3, 1.0), 0.0, 1.0)]
+    q = [(quad((-2, 0, 2), (2, 0, 2), (2, 0, -2), (-2, 0, -2)), 0), (quad((-2, 0, -1), (0.5, 0, -1), (0.5, 1.6, -1), (-2, 1.6, -1)), 1)]
+    meshes = [sc.MeshDesc(v, i, m) for (v, i), m in q]
+    inst = [sc.InstanceDesc(k, (0.0, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0), (1.0, 1.0, 1.0)) for k in range(2)]
+    d = sc.SceneDesc(mats, meshes, inst, sc.CameraDesc((0.3, 1.0, 3.0), (0.0, 0.3, 0.0), math.radians(50.0), 1.0), "env_floor")
+    eh, ew = 16, 32
+    yy, xx = np.mgrid[0:eh, 0:ew]
+    env = np.zeros((eh, ew, 3), np.float32)                              # smooth and asymmetric: brighter up and towards +x / +z, tinted
+    env[..., 0] = 0.3 + 1.2 * np.cos(math.pi * (yy + 0.5) / eh / 2) ** 2 + 0.5 * (xx / ew)
+    env[..., 1] = 0.3 + 1.0 * np.cos(math.pi * (yy + 0.5) / eh / 2) ** 2
+    env[..., 2] = 0.4 + 0.8 * np.cos(math.pi * (yy + 0.5) / eh / 2) ** 2 + 0.6 * (1 - xx / ew)
+    d.env = env
+    w = h = 16
+    mb = 3
+    ind, var = _independent(d, w, h, 2000, mb, seed=99)
+    o = ora.Oracle().load_scene(d)
+    r1 = o.render(w, h, 512, seed=15, max_bounces=mb)[..., :3].astype(np.float64)
+    r2 = o.render(w, h, 512, seed=16, max_bounces=mb)[..., :3].astype(np.float64)
     ref, ovar = 0.5 * (r1 + r2), ((r1 - r2) ** 2) / 4
     se = math.sqrt(var.sum() + ovar.sum()) / var.size
     assert ref.mean() > 0.05
