@@ -1,14 +1,16 @@
 // pt_kernels.hip — the wavefront path tracer's kernels for gfx950 (wave64).
 //
-// Stages:  P1 k_raygen · P3 k_trace_closest · P9 material sort + compaction (front and
-// back end of k_shade) · P5–P8 k_shade · P4 k_trace_any · P10 k_accumulate / k_resolve ·
-// R8 k_shade_raster · R9 k_tonemap.
+// Stages:  P1 k_raygen · P3 k_trace_closest · P9 compaction (and, optionally, material sort) inside
+// k_shade · P5–P8 k_shade · P4 k_trace_any · P10 k_accumulate / k_resolve · R8 k_shade_raster · R9 k_tonemap;
+// queue bookkeeping k_set_counts / k_scan.
 //
-// Design rules that came out of the first profile (profiles/r01_v1_*):
+// Design rules that came out of the profiles (profiles/r01_v1_* ... profiles/r03_*):
 //  * a single device word takes ≈88 atomics/µs, so NOTHING does one atomic per wave-iteration: trace
-//    waves pull 512-ray chunks (one atomic per chunk) and refill idle lanes from their private chunk;
-//    the shade kernel sorts and compacts per 512-thread block through LDS and does ONE atomic per
-//    block and output queue;
+//    waves pull chunks of <= 512 rays (their first chunk is static, later ones cost one atomic) and refill idle lanes
+//    from their private chunk; the shade kernel needs no atomic at all: a queue is cut into segments, one wave owns a
+//    segment and compacts its outputs into the same segment of the output arrays (ptc_internal.h, "SEGMENTED queues");
+//  * k_shade runs at the rate of the CUs' vector-memory path: whatever adds loads to it loses, the material sort included
+//    (it stays as k_shade<true>, off by default);
 //  * traversal has poor lane utilisation when a wave waits for its slowest ray, so finished lanes are
 //    refilled in place (persistent while-while with dynamic fetch);
 //  * every queue access is a 16-byte lane (dwordx4); no float atomics anywhere — each per-path /
@@ -831,9 +833,10 @@ PT_DEV v3 env_sample(const DevScene& sc, const float* marg, const uint16_t* marg
 // =================================================================================================
 // P9 + P5–P8 shading.  One WAVE owns one queue segment (ptc_internal.h, "SEGMENTED queues"): no block barrier and no atomic anywhere
 // in the loop, so the four waves a SIMD holds are four independent streams of loads and arithmetic (the round-2 kernel kept the
-// eight waves of a 512-thread block in lockstep at three barriers per window, which left a SIMD two independent streams: 55 % of its
-// wave-cycles waited for memory).
-// P9, material sort per wave: the wave reads the class words of the next 64 slots of its segment, and appends each slot to the ring
+// eight waves of a 512-thread block in lockstep at three barriers per window).  That alone changed nothing: the kernel runs at the rate of
+// the CUs' vector-memory path (two waves per SIMD are 93 % as fast as four), so what pays is fewer bytes and fewer gathers.
+// SORT = false (default): a batch is simply the next 64 slots of the segment, coalesced 64-byte ray + hit records.
+// SORT = true (P9's material sort per wave): the wave reads the class words of the next 64 slots of its segment, and appends each slot to the ring
 // of its class in LDS (ballot + mbcnt prefix per class present); as soon as a ring holds 64 slots they are shaded as ONE batch, so every
 // batch but a segment's last few is uniform in class (Lambert / GGX / environment miss; 8 classes fit the hit word).  Misses without an
 // environment are dropped here.

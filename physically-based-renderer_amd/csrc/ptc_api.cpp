@@ -2,7 +2,7 @@
 //
 // One context = one HIP device + `n_lanes` streams ("lanes").  Everything a frame needs is enqueued without host
 // synchronisation: queue sizes live in device memory and the persistent kernels read them there, so a whole batch
-// (raygen → [trace, shade, shadow, advance] × bounces → accumulate) is a single asynchronous burst.  With PTC_LANES > 1
+// (set_counts → raygen → [closest, shade, scan, any] × bounces → accumulate) is a single asynchronous burst.  With PTC_LANES > 1
 // successive batches of a frame alternate between the lanes, so one batch's launch tails overlap another batch's
 // full-occupancy phases (only the per-pixel accumulation is ordered, in sample order, by events); the default is one lane,
 // which the round-2 kernels make the faster arrangement.  The host blocks only in ptc_sync / read-backs / ptc_get_stats.
