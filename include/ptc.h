@@ -146,9 +146,11 @@ int ptc_add_instance_matrix(ptc_ctx*, int mesh, const float model[16]);
  * triangles live in one world-space tree, so a change is two steps: ptc_update_instance / ptc_update_instance_matrix give instance
  * `instance` (the value ptc_add_instance* returned) a new transform, any number of them; ptc_scene_refit then re-flattens the
  * vertices and REFITS the committed tree — same topology, same slots, same layout; every box re-computed bottom-up and re-quantised,
- * triangle records, shading records and emitters rewritten — and overwrites those arrays on the device in place (textures,
- * environment and materials are not touched).  No re-build: 250 k triangles refit in 7-8 ms, a sixteenth of ptc_scene_commit's time
- * (ptc_stats.seconds_refit beside seconds_commit).  A refitted tree renders the same image as a fresh commit of the same transforms
+ * triangle records, shading records and emitters rewritten — in place in HBM (textures, environment and materials are not
+ * touched).  The refit runs ON THE DEVICE (csrc/pt_refit.hip: the same arithmetic as the host's, element-parallel; 84 bytes per
+ * instance and the emitter table are all that crosses the bus); PTC_REFIT=host in the environment, a description-only context, or
+ * a move that changes which triangles are emitters (a zero-area scale) take the host refit + upload instead — both give the same
+ * bytes (ptc_debug_get_bvh / ptc_debug_get_shading_tables).  No re-build either way (ptc_stats.seconds_refit beside seconds_commit).  A refitted tree renders the same image as a fresh commit of the same transforms
  * (closest hit = minimum of (t, primitive id), whatever the tree); its traversal counters are those of the refitted tree, and the
  * oracle refits the same way.  Meshes, materials or the number of instances cannot change this way: that is a new scene.
  * A frame in progress ends (call ptc_frame_begin again).  PTC_E_STATE before the first ptc_scene_commit. */
@@ -275,7 +277,8 @@ int ptc_group_size(const ptc_group*);
  * builds the BVH once on the host (unless device 0 has committed it already: that build is then used) and uploads that one build to
  * every device (N contexts committing on their own would each repeat the build, one after the other on the calling thread). */
 int ptc_group_scene_commit(ptc_group*);
-/* Scene dynamics for a group: ptc_update_instance* on ptc_group_ctx(g, 0), then ONE refit on the host whose arrays go to every device. */
+/* Scene dynamics for a group: ptc_update_instance* on ptc_group_ctx(g, 0), then every device refits its copy in place (or, on the
+ * host path, ONE refit on the host whose arrays go to every device). */
 int ptc_group_scene_refit(ptc_group*);
 ptc_ctx* ptc_group_ctx(ptc_group*, int i);
 int ptc_group_render(ptc_group*, int w, int h, int spp, uint64_t seed, int max_bounces, int integrator);
@@ -316,8 +319,15 @@ int ptc_debug_get_bvh(ptc_ctx*, uint32_t* n_nodes, uint32_t* n_tris, uint32_t* n
 
 /* Context internals for tests of the host logic: [0] HIP events created so far, [1] timing spans waiting to be
  * collected, [2] queue capacity (paths) of a lane, [3] samples of one full batch, [4] samples accepted but not yet
- * issued, [5] trace blocks per CU, [6] stack entries per lane kept in LDS. */
+ * issued, [5] trace blocks per CU, [6] stack entries per lane kept in LDS, [7] 1 if the last ptc_scene_refit ran on the
+ * device (csrc/pt_refit.hip), 0 if on the host. */
 int ptc_debug_get_internals(ptc_ctx*, uint64_t out[8]);
+
+/* The tables shading reads besides the BVH, as they lie in HBM: the per-primitive shading records (4 * stride floats each,
+ * stride 5 or 12), the emitters (20 floats each) and their power cdf (max(n_lights, 1) floats).  Arrays may be NULL (sizes only).
+ * With ptc_debug_get_bvh this is everything a refit rewrites: the tests hold the refit on the device against the one on the
+ * host and the oracle's through these two calls. */
+int ptc_debug_get_shading_tables(ptc_ctx*, uint32_t* stride, float* shade, uint32_t* n_lights, float* lights, float* cdf);
 
 #ifdef __cplusplus
 }

@@ -10,6 +10,7 @@
 // There is no CPU path in this library: without a usable HIP device ptc_create fails.
 #include "../../include/ptc.h"
 #include "ptc_internal.h"
+#include "pt_refit.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -106,6 +107,14 @@ struct ptc_ctx {
   DevScene dsc{};
   DevCamera cam{};
   std::vector<void*> scene_allocs;
+  // refit on the device (pt_refit.h): the plan is built and uploaded by the first ptc_scene_refit after a commit
+  int refit_on_device = 1;          // PTC_REFIT=host: ptc_scene_refit recomputes on the host and uploads (the round-3a path, kept as the cross-check)
+  bool refit_ready = false;
+  RefitPlan plan;
+  DevRefit drf{};
+  bool host_stale = false;          // the device refitted in place: built's vertex-dependent arrays are those of an earlier state until refresh_host_copy
+  bool last_refit_on_device = false;
+  std::vector<float> xf_live;       // instance transforms of the last refit the device completed (a refused one re-flattens its scratch vertices from these)
   // lanes: lane 0 is the context's primary stream (resolve, tonemap, conversions, the reduce)
   std::vector<Lane> lanes;
   int n_lanes = 1;                  // PTC_LANES: >1 runs successive batches on separate streams.  With the round-2 kernels one lane
@@ -587,6 +596,7 @@ int commit_upload(ptc_ctx* c, std::chrono::steady_clock::time_point t0);
 // environment and materials stay where they are); else (an emitter appeared or vanished under a degenerate scale) upload everything.
 int refit_upload(ptc_ctx* c, bool same_sizes, std::chrono::steady_clock::time_point t0) {
   const HostBuilt& B = *c->built;
+  c->host_stale = false; c->last_refit_on_device = false;
   if (!same_sizes) return commit_upload(c, t0);
   HIP_TRY(c, hipMemcpy((void*)c->dsc.recs, B.recs.data(), B.recs.size() * 4, hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy((void*)c->dsc.shade, B.shade.data(), B.shade.size() * 4, hipMemcpyHostToDevice));
@@ -598,6 +608,93 @@ int refit_upload(ptc_ctx* c, bool same_sizes, std::chrono::steady_clock::time_po
     const DevScene ds = lane_scene(c, l);
     HIP_TRY(c, hipMemcpy(c->lanes[(size_t)l].d_scene, &ds, sizeof ds, hipMemcpyHostToDevice));
   }
+  return PTC_OK;
+}
+
+bool refit_on_device(ptc_ctx* c) {
+  if (const char* s = std::getenv("PTC_REFIT")) return std::strcmp(s, "host") != 0;
+  return c->refit_on_device != 0;
+}
+
+// The plan of the committed scene in HBM + the scratch arrays of the refit kernels; once per commit.
+int ensure_refit_plan(ptc_ctx* c) {
+  if (c->refit_ready) return PTC_OK;
+  const HostBuilt& B = *c->built;
+  ptc_refit_plan(c->mats, c->meshes, c->insts, B, c->plan);
+  const RefitPlan& P = c->plan;
+  DevRefit d{};
+  int rc = dev_upload(c, c->scene_allocs, &d.mesh_verts, P.mesh_verts);
+  if (!rc) rc = dev_upload(c, c->scene_allocs, &d.vert_inst, P.vert_inst);
+  if (!rc) rc = dev_upload(c, c->scene_allocs, &d.inst_first, P.inst_first);
+  if (!rc) rc = dev_upload(c, c->scene_allocs, &d.inst_src, P.inst_src);
+  if (!rc) rc = dev_upload(c, c->scene_allocs, &d.widx, B.widx);
+  if (!rc) rc = dev_upload(c, c->scene_allocs, &d.level_nodes, P.level_nodes);
+  if (!rc) rc = dev_alloc(c, c->scene_allocs, &d.inst_xf, c->insts.size() * 21);
+  if (!rc) rc = dev_alloc(c, c->scene_allocs, &d.wverts, (size_t)P.n_verts);
+  if (!rc) rc = dev_alloc(c, c->scene_allocs, &d.wbt, (size_t)P.n_verts * 3);
+  if (!rc) rc = dev_alloc(c, c->scene_allocs, &d.nbox, (size_t)(B.n_units / 4u + 1u) * 6);
+  if (!rc) rc = dev_alloc(c, c->scene_allocs, &d.bounds, 8);
+  if (rc) return rc;
+  d.recs = const_cast<float4*>(c->dsc.recs); d.shade = const_cast<float4*>(c->dsc.shade);
+  d.n_verts = P.n_verts; d.n_tris = P.n_tris; d.shade_stride = B.shade_stride;
+  c->drf = d;
+  c->refit_ready = true;
+  return PTC_OK;
+}
+
+// Refit on the device.  Returns PTC_OK, an error, or +1: "not this way" (the set of emitters changed) — the caller refits on the host.
+// may_write_built: c->built is this context's own, or a group's fresh copy every member writes the same values to.
+int device_refit(ptc_ctx* c) {
+  { int rc = ensure_refit_plan(c); if (rc) return rc; }
+  std::vector<float> xf, lights, cdf;
+  if (!ptc_refit_instance_transforms(c->insts, xf)) return fail(c, PTC_E_STATE, "scene_commit: non-finite vertex position after the instance transform");
+  if (!ptc_refit_emitters(c->mats, c->meshes, c->insts, c->plan, *c->built, lights, cdf)) return 1;
+  hipStream_t st = c->lanes[0].stream;
+  const DevRefit& d = c->drf;
+  HIP_TRY(c, hipMemcpyAsync(d.inst_xf, xf.data(), xf.size() * 4, hipMemcpyHostToDevice, st));
+  pt_launch_refit_geometry(st, d);
+  uint32_t raw[8];
+  HIP_TRY(c, hipMemcpyAsync(raw, d.bounds, sizeof raw, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipStreamSynchronize(st));
+  float lo[3], hi[3]; bool bad = false;
+  pt_refit_decode_bounds(raw, lo, hi, &bad);
+  if (bad) {     // nothing of the scene was written (k_refit_prims saw the flag); the scratch vertices go back to the state the scene in HBM was made from
+    if (!c->xf_live.empty()) {
+      HIP_TRY(c, hipMemcpyAsync(d.inst_xf, c->xf_live.data(), c->xf_live.size() * 4, hipMemcpyHostToDevice, st));
+      pt_launch_refit_geometry(st, d);
+      HIP_TRY(c, hipStreamSynchronize(st));
+    }
+    return fail(c, PTC_E_STATE, "scene_commit: non-finite vertex position after the instance transform");
+  }
+  HostBuilt& B = *c->built;
+  ptc_refit_grid(lo, hi, B.grid_lo, B.grid_step, &B.ray_eps);
+  pt_launch_refit_nodes(st, d, c->plan.level_first, B.grid_lo, B.grid_step);
+  HIP_TRY(c, hipGetLastError());
+  B.lights = lights; B.cdf = cdf;
+  HIP_TRY(c, hipMemcpyAsync((void*)c->dsc.lights, B.lights.data(), B.lights.size() * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemcpyAsync((void*)c->dsc.cdf, B.cdf.data(), B.cdf.size() * 4, hipMemcpyHostToDevice, st));
+  c->dsc.ray_eps = B.ray_eps;
+  for (int k = 0; k < 3; ++k) { c->dsc.grid_lo[k] = B.grid_lo[k]; c->dsc.grid_step[k] = B.grid_step[k]; }
+  for (int l = 0; l < c->n_lanes; ++l) {
+    const DevScene ds = lane_scene(c, l);
+    HIP_TRY(c, hipMemcpyAsync(c->lanes[(size_t)l].d_scene, &ds, sizeof ds, hipMemcpyHostToDevice, st));
+  }
+  HIP_TRY(c, hipStreamSynchronize(st));
+  c->host_stale = true; c->last_refit_on_device = true;
+  c->xf_live.swap(xf);
+  return PTC_OK;
+}
+
+// The debug getters read the host build: after a refit on the device its vertex-dependent arrays come back from HBM first.
+int refresh_host_copy(ptc_ctx* c) {
+  if (!c->host_stale || c->device < 0) return PTC_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  { int rs = sync_all_lanes(c); if (rs) return rs; }
+  HostBuilt& B = *c->built;
+  HIP_TRY(c, hipMemcpy(B.recs.data(), c->dsc.recs, B.recs.size() * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(B.shade.data(), c->dsc.shade, B.shade.size() * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(B.wverts.data(), c->drf.wverts, B.wverts.size() * sizeof(HostVertex), hipMemcpyDeviceToHost));
+  c->host_stale = false;
   return PTC_OK;
 }
 }  // namespace
@@ -628,6 +725,13 @@ int ptc_scene_refit(ptc_ctx* c) {
   }
   const auto t0 = std::chrono::steady_clock::now();
   if (c->built.use_count() > 1) c->built = std::make_shared<HostBuilt>(*c->built);      // a group shares one build: this context now gets its own
+  if (c->device >= 0 && refit_on_device(c)) {
+    const int rd = device_refit(c);
+    if (rd <= 0) {
+      if (rd == PTC_OK) { c->in_frame = false; c->pending = 0; c->stats.seconds_refit = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+      return rd;
+    }
+  }
   HostBuilt& B = *c->built;
   const size_t n_recs = B.recs.size(), n_shade = B.shade.size(), n_lights = B.lights.size(), n_cdf = B.cdf.size();
   const std::string e = ptc_refit_scene(c->mats, c->meshes, c->insts, c->texs, c->env, B);
@@ -687,6 +791,7 @@ int commit_upload(ptc_ctx* c, std::chrono::steady_clock::time_point t0) {
   }
   c->committed = false;
   free_all(c->scene_allocs);
+  c->refit_ready = false; c->host_stale = false; c->plan = RefitPlan(); c->drf = DevRefit{}; c->xf_live.clear();
   for (auto& ln : c->lanes) ln.stack_ovf = nullptr;
   const HostBuilt& B = *c->built;
   DevScene d{};
@@ -1058,6 +1163,22 @@ int ptc_group_scene_refit(ptc_group* g) {
     if (rc) { g->err = std::string("ptc_group_scene_refit: ") + ptc_last_error(c); return rc; }
   }
   const auto t0 = std::chrono::steady_clock::now();
+  if (refit_on_device(c0)) {       // every device refits its own copy in place: nothing but the 84 bytes per instance and the emitter table cross the bus
+    bool host_way = false;
+    auto mine = std::make_shared<HostBuilt>(*c0->built);
+    for (size_t i = 0; i < g->ctx.size() && !host_way; ++i) {
+      ptc_ctx* c = g->ctx[i];
+      if (hipSetDevice(c->device) != hipSuccess) { g->err = "ptc_group_scene_refit: hipSetDevice failed"; return PTC_E_DEVICE; }
+      if (i) c->insts = c0->insts;
+      c->built = mine;
+      const int rc = device_refit(c);
+      if (rc > 0) { host_way = true; break; }      // decided from the description alone, before any kernel ran: all devices take the host path together
+      if (rc) { g->err = "device " + std::to_string(i) + ": " + ptc_last_error(c); return rc; }
+      c->in_frame = false; c->pending = 0;
+      c->stats.seconds_refit = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    if (!host_way) return PTC_OK;
+  }
   auto built = std::make_shared<HostBuilt>(*c0->built);                 // the devices keep rendering from the old arrays until theirs are overwritten
   const size_t n_recs = built->recs.size(), n_shade = built->shade.size(), n_lights = built->lights.size(), n_cdf = built->cdf.size();
   const std::string e = ptc_refit_scene(c0->mats, c0->meshes, c0->insts, c0->texs, c0->env, *built);
@@ -1162,6 +1283,7 @@ int ptc_debug_trace_any(ptc_ctx* c, const float* origins, const float* dirs, con
 int ptc_debug_get_flat_scene(ptc_ctx* c, uint32_t* n_verts, uint32_t* n_tris, ptc_vertex* verts, uint32_t* indices, int32_t* tri_material) {
   if (!c) return PTC_E_ARG;
   if (!c->committed) return fail(c, PTC_E_STATE, "debug_get_flat_scene: scene not committed");
+  { int rr = refresh_host_copy(c); if (rr) return rr; }
   const HostBuilt& B = *c->built;
   if (n_verts) *n_verts = (uint32_t)B.wverts.size();
   if (n_tris) *n_tris = B.n_tris;
@@ -1211,6 +1333,7 @@ int ptc_debug_get_counters(ptc_ctx* c, uint64_t* out, int n) {
 int ptc_debug_get_bvh(ptc_ctx* c, uint32_t* n_nodes, uint32_t* n_tris, uint32_t* n_units, float* units, float grid[6]) {
   if (!c) return PTC_E_ARG;
   if (!c->committed) return fail(c, PTC_E_STATE, "debug_get_bvh: scene not committed");
+  { int rr = refresh_host_copy(c); if (rr) return rr; }
   const HostBuilt& B = *c->built;
   if (n_nodes) *n_nodes = B.n_nodes;
   if (n_tris) *n_tris = B.n_tri_records;
@@ -1227,7 +1350,22 @@ int ptc_debug_get_internals(ptc_ctx* c, uint64_t out[8]) {
   if (!c || !out) return PTC_E_ARG;
   for (int i = 0; i < 8; ++i) out[i] = 0;
   out[0] = c->events_created; out[1] = c->spans.size(); out[2] = c->lanes.empty() ? 0 : c->lanes[0].q.cap; out[3] = c->per_batch; out[4] = c->pending;
-  out[5] = (uint64_t)c->cfg.trace_blocks_per_cu; out[6] = (uint64_t)c->cfg.stack_lds;
+  out[5] = (uint64_t)c->cfg.trace_blocks_per_cu; out[6] = (uint64_t)c->cfg.stack_lds; out[7] = c->last_refit_on_device ? 1u : 0u;
+  return PTC_OK;
+}
+
+// The tables k_shade reads besides the BVH: shading records (4 * stride floats per primitive), emitters (20 floats each), their power cdf.
+// Sizes come back through the pointers; arrays may be null.
+int ptc_debug_get_shading_tables(ptc_ctx* c, uint32_t* stride, float* shade, uint32_t* n_lights, float* lights, float* cdf) {
+  if (!c) return PTC_E_ARG;
+  if (!c->committed) return fail(c, PTC_E_STATE, "debug_get_shading_tables: scene not committed");
+  { int rr = refresh_host_copy(c); if (rr) return rr; }
+  const HostBuilt& B = *c->built;
+  if (stride) *stride = B.shade_stride;
+  if (n_lights) *n_lights = B.n_lights;
+  if (shade) std::memcpy(shade, B.shade.data(), B.shade.size() * 4);
+  if (lights) std::memcpy(lights, B.lights.data(), B.lights.size() * 4);
+  if (cdf) std::memcpy(cdf, B.cdf.data(), B.cdf.size() * 4);
   return PTC_OK;
 }
 

@@ -9,6 +9,7 @@
 // Everything is plain IEEE binary32 without contraction (this file is compiled -ffp-contract=off),
 // so the flattened scene is reproducible bit for bit.
 #include "ptc_internal.h"
+#include "pt_refit.h"
 
 #include <algorithm>
 #include <atomic>
@@ -1058,4 +1059,108 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
 std::string ptc_refit_scene(const std::vector<HostMaterial>& mats, const std::vector<HostMesh>& meshes, const std::vector<HostInstance>& insts,
                             const std::vector<HostTexture>& texs, const HostEnv& env, HostBuilt& B) {
   return build_or_refit(mats, meshes, insts, texs, env, 0, 0, B, true);
+}
+
+// ---- the host's share of a refit on the device (pt_refit.h) -----------------------------------------------------------------------
+void ptc_refit_plan(const std::vector<HostMaterial>& mats, const std::vector<HostMesh>& meshes, const std::vector<HostInstance>& insts, const HostBuilt& B, RefitPlan& P) {
+  P = RefitPlan();
+  const Topology& topo = *std::static_pointer_cast<Topology>(B.topology);
+  std::vector<uint32_t> mesh_first(meshes.size());
+  for (size_t m = 0; m < meshes.size(); ++m) { mesh_first[m] = (uint32_t)P.mesh_verts.size(); P.mesh_verts.insert(P.mesh_verts.end(), meshes[m].v.begin(), meshes[m].v.end()); }
+  uint32_t vb = 0, tb = 0;
+  for (size_t i = 0; i < insts.size(); ++i) {
+    const HostMesh& m = meshes[(size_t)insts[i].mesh];
+    P.inst_first.push_back(vb);
+    P.inst_src.push_back(mesh_first[(size_t)insts[i].mesh]);
+    P.vert_inst.insert(P.vert_inst.end(), m.v.size(), (uint32_t)i);
+    const HostMaterial& hm = mats[(size_t)m.material];
+    if (hm.emissive[0] > 0.0f || hm.emissive[1] > 0.0f || hm.emissive[2] > 0.0f)
+      for (size_t k = 0; k * 3 < m.idx.size(); ++k) {
+        const int32_t e[5] = {(int32_t)(tb + k), (int32_t)i, (int32_t)m.idx[k * 3], (int32_t)m.idx[k * 3 + 1], (int32_t)m.idx[k * 3 + 2]};
+        P.emit_prims.insert(P.emit_prims.end(), e, e + 5);
+      }
+    vb += (uint32_t)m.v.size(); tb += (uint32_t)(m.idx.size() / 3);
+  }
+  P.n_verts = vb; P.n_tris = tb;
+  uint32_t maxd = 0;
+  for (const Slot& s : topo.order) maxd = s.depth > maxd ? s.depth : maxd;
+  std::vector<uint32_t> count(maxd + 2, 0u);
+  for (const Slot& s : topo.order) ++count[maxd - s.depth + 1];            // level 0 = the deepest nodes
+  for (size_t l = 1; l < count.size(); ++l) count[l] += count[l - 1];
+  P.level_first = count;
+  P.level_nodes.resize(topo.order.size());
+  std::vector<uint32_t> at(count.begin(), count.end() - 1);
+  for (size_t idx = 0; idx < topo.order.size(); ++idx) P.level_nodes[at[maxd - topo.order[idx].depth]++] = topo.node_addr[idx];
+}
+
+bool ptc_refit_instance_transforms(const std::vector<HostInstance>& insts, std::vector<float>& out) {
+  out.resize(insts.size() * 21);
+  bool finite = true;
+  for (size_t i = 0; i < insts.size(); ++i) {
+    const Mat34 M = from_matrix(insts[i].m);
+    float* o = &out[i * 21];
+    for (int c = 0; c < 4; ++c)
+      for (int r = 0; r < 3; ++r) { o[c * 3 + r] = M.m[c * 4 + r]; finite = finite && std::isfinite(M.m[c * 4 + r]); }
+    for (int k = 0; k < 9; ++k) o[12 + k] = M.n[k];
+  }
+  return finite;
+}
+
+void ptc_refit_grid(const float lo[3], const float hi[3], float grid_lo[3], float grid_step[3], float* ray_eps) {
+  float diag = hi[0] - lo[0];
+  if (hi[1] - lo[1] > diag) diag = hi[1] - lo[1];
+  if (hi[2] - lo[2] > diag) diag = hi[2] - lo[2];
+  *ray_eps = 1e-4f * (diag > 1e-6f ? diag : 1e-6f);
+  for (int k = 0; k < 3; ++k) { const float st = (hi[k] - lo[k]) / 65535.0f; grid_step[k] = st > 0.0f ? st : 1.0f; grid_lo[k] = lo[k]; }
+}
+
+bool ptc_refit_emitters(const std::vector<HostMaterial>& mats, const std::vector<HostMesh>& meshes, const std::vector<HostInstance>& insts, const RefitPlan& P,
+                        const HostBuilt& B, std::vector<float>& lights, std::vector<float>& cdf) {
+  lights.clear(); cdf.clear();
+  std::vector<float> weight;
+  int32_t cached_inst = -1;
+  Mat34 M{};
+  for (size_t j = 0; j * 5 < P.emit_prims.size(); ++j) {
+    const int32_t* e = &P.emit_prims[j * 5];
+    const uint32_t p = (uint32_t)e[0];
+    const HostMesh& mesh = meshes[(size_t)insts[(size_t)e[1]].mesh];
+    const HostMaterial& m = mats[(size_t)mesh.material];
+    if (e[1] != cached_inst) { M = from_matrix(insts[(size_t)e[1]].m); cached_inst = e[1]; }
+    float w[3][3];
+    for (int c = 0; c < 3; ++c) {
+      const float* s = mesh.v[(size_t)e[2 + c]].position;
+      for (int r = 0; r < 3; ++r) w[c][r] = M.m[0 + r] * s[0] + M.m[4 + r] * s[1] + M.m[8 + r] * s[2] + M.m[12 + r];
+    }
+    const float *a = w[0], *b = w[1], *c = w[2];
+    const float e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+    float cr[3];
+    fcross(e1, e2, cr);
+    const float len = sqrtf(fdot(cr, cr));
+    const float area = 0.5f * len;
+    const float lum = fmaf(m.emissive[2], 0.0722f, fmaf(m.emissive[1], 0.7152f, m.emissive[0] * 0.2126f));
+    const float wgt = area * lum;
+    const bool is_light = wgt > 0.0f;
+    if (is_light != (B.prim_light[p] >= 0)) return false;
+    if (!is_light) continue;
+    if (B.prim_light[p] != (int32_t)weight.size()) return false;
+    const float il = 1.0f / len;
+    weight.push_back(wgt);
+    const float rec[20] = {a[0], a[1], a[2], area, e1[0], e1[1], e1[2], 0.0f, e2[0], e2[1], e2[2], 0.0f,
+                           cr[0] * il, cr[1] * il, cr[2] * il, 0.0f, m.emissive[0], m.emissive[1], m.emissive[2], 0.0f};
+    lights.insert(lights.end(), rec, rec + 20);
+  }
+  if (weight.size() != B.n_lights) return false;
+  float total = 0.0f;
+  for (float wv : weight) total += wv;
+  float run = 0.0f;
+  cdf.resize(weight.size());
+  for (size_t i = 0; i < weight.size(); ++i) {
+    run += weight[i];
+    cdf[i] = run / total;
+    lights[i * 20 + 7] = weight[i] / total;
+  }
+  if (!cdf.empty()) cdf.back() = 1.0f;
+  if (cdf.empty()) cdf.push_back(1.0f);
+  if (lights.empty()) lights.assign(20, 0.0f);
+  return true;
 }

@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "ptc_frame_begin", "ptc_frame_add_samples", "ptc_frame_reserve", "ptc_frame_resolve", "ptc_frame_checkpoint", "ptc_frame_restore", "ptc_frame_set_sample_range", "ptc_sync", "ptc_read_radiance_rgba32f",
     "ptc_radiance_device_ptr", "ptc_write_radiance_rgba32f", "ptc_tonemap_rgba8", "ptc_get_stats",
     "ptc_debug_trace_closest", "ptc_debug_trace_any", "ptc_debug_get_flat_scene", "ptc_debug_get_bvh", "ptc_debug_get_counters",
-    "ptc_debug_get_description", "ptc_debug_get_material", "ptc_debug_get_texture", "ptc_debug_get_internals",
+    "ptc_debug_get_description", "ptc_debug_get_material", "ptc_debug_get_texture", "ptc_debug_get_internals", "ptc_debug_get_shading_tables",
     "ptc_read_radiance_rgba16f", "ptc_radiance_rgba16f_device_ptr",
     "ptc_comm_unique_id", "ptc_comm_init", "ptc_comm_reduce_radiance", "ptc_comm_destroy",
     "ptc_group_create", "ptc_group_size", "ptc_group_scene_commit", "ptc_group_scene_refit", "ptc_group_ctx", "ptc_group_render", "ptc_group_last_error", "ptc_group_destroy",
@@ -120,6 +120,7 @@ def load_library():
     L.ptc_debug_get_material.argtypes = [vp, C.c_int, fp, C.POINTER(C.c_int)]
     L.ptc_debug_get_texture.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), vp]
     L.ptc_debug_get_internals.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.ptc_debug_get_shading_tables.argtypes = [vp, u32p, fp, u32p, fp, fp]
     L.ptc_read_radiance_rgba16f.argtypes = [vp, C.POINTER(C.c_uint16)]
     L.ptc_radiance_rgba16f_device_ptr.argtypes = [vp]
     L.ptc_radiance_rgba16f_device_ptr.restype = vp
@@ -374,8 +375,21 @@ class PathTracer:
     def internals(self):
         buf = (C.c_uint64 * 8)()
         self._ck(self._L.ptc_debug_get_internals(self._h, buf))
-        keys = ("events_created", "spans_waiting", "queue_cap", "per_batch", "pending", "trace_blocks_per_cu", "stack_lds")
+        keys = ("events_created", "spans_waiting", "queue_cap", "per_batch", "pending", "trace_blocks_per_cu", "stack_lds", "refit_on_device")
         return {k: int(buf[i]) for i, k in enumerate(keys)}
+
+    def shading_tables(self):
+        """(shade, lights, cdf): the per-primitive shading records as (n_tris, 4 * stride) float32, the emitter table (n, 20) and its cdf,
+        as they lie in HBM (after a refit on the device they are read back first)."""
+        stride, nl = C.c_uint32(), C.c_uint32()
+        self._ck(self._L.ptc_debug_get_shading_tables(self._h, C.byref(stride), None, C.byref(nl), None, None))
+        n = self.stats()["n_triangles"]
+        shade = np.zeros((n, 4 * stride.value), np.float32)
+        lights = np.zeros((max(nl.value, 1), 20), np.float32)
+        cdf = np.zeros(max(nl.value, 1), np.float32)
+        f = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        self._ck(self._L.ptc_debug_get_shading_tables(self._h, None, f(shade), None, f(lights), f(cdf)))
+        return shade, lights[:max(nl.value, 1)], cdf
 
     def raw_counters(self):
         buf = (C.c_uint64 * 32)()

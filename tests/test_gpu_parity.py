@@ -599,6 +599,109 @@ def test_scene_dynamics_refit(gpu, ora, name, kw, w, h, spp, seed, mb):
     print(f"{name}: commit {pt.stats()['seconds_commit'] * 1e3:.1f} ms, refit {pt.stats()['seconds_refit'] * 1e3:.1f} ms")
 
 
+def _single_triangle_scene(gpu):
+    sc = gpu.scene
+    d = gpu.scenes.cornell_box()
+    v = d.meshes[5].vertices[:3].copy()
+    return sc.SceneDesc([d.materials[3]], [sc.MeshDesc(v, np.array([0, 1, 2], np.uint32), 0)], [sc.InstanceDesc(0, (0.0, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0), (1.0, 1.0, 1.0))], d.camera, "one")
+
+
+def _scene_bytes(pt):
+    units, nn, nt, grid = pt.bvh()
+    shade, lights, cdf = pt.shading_tables()
+    v, i, m = pt.flat_scene()
+    return {"units": units.view(np.uint32), "grid": np.asarray(grid), "shade": shade.view(np.uint32), "lights": lights.view(np.uint32), "cdf": cdf.view(np.uint32),
+            "verts": v.view(np.uint32), "idx": i, "mat": m, "counts": np.array([nn, nt])}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kw,builder", [("cornell", {}, None), ("sphere10k", {}, None), ("atrium", {"scale": 0.05}, None), ("atrium", {"scale": 0.02}, "lbvh"),
+                                             ("textured_objects", {}, None), ("textured_atrium", {"scale": 0.05, "tex_size": 64, "env_size": (64, 32)}, None),
+                                             ("one", {}, None)])
+def test_refit_on_the_device_writes_the_bytes_of_the_host_refit(gpu, name, kw, builder):
+    """csrc/pt_refit.hip against ptc_refit_scene: after the same moves the BVH units (nodes + triangle records), the origin grid, the shading
+    records, the emitter table and its cdf and the flattened vertices read back from HBM are, byte for byte, what the host refit computes on a
+    description-only context (which tests/test_host_logic.py holds against the oracle's refit) — over SAH and LBVH trees, textured (192-byte)
+    and plain (80-byte) shading records, the single-triangle tree, rotations, translations, non-uniform scales and matrix instances."""
+    import copy
+    d = _single_triangle_scene(gpu) if name == "one" else gpu.scenes.by_name(name, **kw)
+    if builder:
+        d = copy.deepcopy(d)
+        d.bvh_builder = builder
+    dev = gpu.PathTracer(0).load_scene(d)
+    host = gpu.PathTracer(gpu.DEVICE_NONE).load_scene(d)
+    before = _scene_bytes(dev)
+    dev.scene_refit()                                             # nothing moved: the committed bytes come back
+    assert dev.internals()["refit_on_device"] == 1
+    same = _scene_bytes(dev)
+    for key, val in before.items():
+        assert np.array_equal(val, same[key]), f"refit without a move changed {key}"
+    rng = np.random.default_rng(11)
+    for turn in (1, 2, 3):
+        for i, it in enumerate(d.instances):
+            if i % 2 and len(d.instances) > 2:
+                continue
+            a = 0.11 * turn + 0.017 * i
+            ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+            q = (math.cos(a / 2), *(math.sin(a / 2) * ax))
+            if getattr(it, "matrix", None) is not None or turn == 3:       # the third turn moves everything by matrices (shear included)
+                m = np.eye(4, dtype=np.float32)
+                m[:3, :3] += 0.05 * rng.normal(size=(3, 3)).astype(np.float32)
+                m[3, :3] = 0.02 * rng.normal(size=3)                       # column-major: row 3 of the array is the translation column
+                if getattr(it, "matrix", None) is not None:
+                    m = (np.asarray(it.matrix, np.float32).reshape(4, 4) @ m).astype(np.float32)
+                dev.update_instance(i, matrix=m.reshape(16)); host.update_instance(i, matrix=m.reshape(16))
+            else:
+                t = tuple(np.float32(x) + np.float32(0.03 * turn) for x in it.t)
+                s = tuple(np.float32(x) * np.float32(1.0 + 0.1 * k * turn) for k, x in enumerate(it.s))
+                dev.update_instance(i, t, q, s); host.update_instance(i, t, q, s)
+        dev.scene_refit(); host.scene_refit()
+        assert dev.internals()["refit_on_device"] == 1 and host.internals()["refit_on_device"] == 0
+        a, b = _scene_bytes(dev), _scene_bytes(host)
+        for key in a:
+            assert a[key].shape == b[key].shape and np.array_equal(a[key], b[key]), f"turn {turn}: {key} differs in {int((a[key] != b[key]).sum())} words"
+    print(f"{name}: commit {dev.stats()['seconds_commit'] * 1e3:.1f} ms, refit on the device {dev.stats()['seconds_refit'] * 1e3:.2f} ms")
+
+
+@pytest.mark.gpu
+def test_refit_paths_agree_and_fall_back(gpu, ora):
+    """PTC_REFIT=host takes the host refit + upload; a move that changes WHICH triangles are emitters (an emitter scaled to zero area) cannot keep
+    the emitter indices of the shading records and takes the host path by itself; a non-finite matrix is refused and leaves the scene in HBM as
+    it was.  Images: the oracle's, bit for bit, every time."""
+    d = gpu.scenes.by_name("cornell")
+    pt, o = _pair(gpu, ora, d)
+    ref = pt.render(48, 48, 2, seed=4, max_bounces=4)
+    t, q = (0.1, 0.0, 0.05), (math.cos(0.2), 0.0, math.sin(0.2), 0.0)
+    os.environ["PTC_REFIT"] = "host"
+    try:
+        pt.update_instance(0, t, q, (1.0, 1.0, 1.0)); o.update_instance(0, t, q, (1.0, 1.0, 1.0))
+        pt.scene_refit(); o.scene_refit()
+    finally:
+        del os.environ["PTC_REFIT"]
+    assert pt.internals()["refit_on_device"] == 0
+    assert _bits_equal(pt.render(48, 48, 2, seed=4, max_bounces=4), o.render(48, 48, 2, seed=4, max_bounces=4))
+    pt.update_instance(5, (0.0, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0), (0.0, 1.0, 1.0)); o.update_instance(5, (0.0, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0), (0.0, 1.0, 1.0))
+    pt.scene_refit(); o.scene_refit()                      # the light collapsed to a segment: no emitter left
+    assert pt.internals()["refit_on_device"] == 0 and pt.stats()["n_emitters"] == 0
+    assert _bits_equal(pt.render(48, 48, 2, seed=4, max_bounces=4), o.render(48, 48, 2, seed=4, max_bounces=4))
+    pt.update_instance(5, (0.0, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0), (1.0, 1.0, 1.0)); o.update_instance(5, (0.0, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
+    pt.update_instance(0, (0.0, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0), (1.0, 1.0, 1.0)); o.update_instance(0, (0.0, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
+    pt.scene_refit(); o.scene_refit()                      # and back: the emitters return (host path again: the set changed), the image is the first one
+    assert pt.stats()["n_emitters"] == 2
+    back = pt.render(48, 48, 2, seed=4, max_bounces=4)
+    assert _bits_equal(back, ref) and _bits_equal(back, o.render(48, 48, 2, seed=4, max_bounces=4))
+    pt.update_instance(1, (0.0, 0.01, 0.0), (1.0, 0.0, 0.0, 0.0), (1.0, 1.0, 1.0)); o.update_instance(1, (0.0, 0.01, 0.0), (1.0, 0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
+    pt.scene_refit(); o.scene_refit()
+    assert pt.internals()["refit_on_device"] == 1
+    moved = pt.render(48, 48, 2, seed=4, max_bounces=4)
+    assert _bits_equal(moved, o.render(48, 48, 2, seed=4, max_bounces=4))
+    big = np.eye(4, dtype=np.float32); big[0, 0] = 3e38; big[3, 0] = 3e38          # finite entries, positions overflow on the device
+    pt.update_instance(2, matrix=big.reshape(16))
+    with pytest.raises(gpu.PtcError, match="non-finite"):
+        pt.scene_refit()
+    assert _bits_equal(pt.render(48, 48, 2, seed=4, max_bounces=4), moved), "a refused refit must leave the committed scene alone"
+
+
 @pytest.mark.parametrize("name,kw,w,h,spp,seed,mb", [("atrium", {"scale": 0.05}, 160, 90, 4, 3, 8), ("textured_atrium", {"scale": 0.05, "tex_size": 64, "env_size": (64, 32)}, 120, 68, 4, 5, 6),
                                                       ("two_tris_sphere", {}, 64, 64, 2, 5, 3)])
 def test_material_sort_is_an_option_that_changes_nothing_but_time(gpu, ora, name, kw, w, h, spp, seed, mb):
