@@ -145,8 +145,16 @@ def main():
         if td is not None:
             td.cleanup()
     # scene dynamics: what a transform change costs (ptc_scene_refit of the unchanged scene re-computes and re-uploads exactly what a real one does)
+    pt.scene_refit()                                       # the first one also builds and uploads the refit plan
     pt.scene_refit()
     refit_seconds = pt.stats()["seconds_refit"]
+    os.environ["PTC_REFIT"] = "host"                       # the same refit computed on the host and uploaded (the cross-check path)
+    try:
+        pt.scene_refit()
+    finally:
+        del os.environ["PTC_REFIT"]
+    refit_host_seconds = pt.stats()["seconds_refit"]
+    pt.scene_refit()                                       # leave the device-refitted scene (the same bytes) in place
     K, W, S = args.steps, args.warmup, args.spp_per_step * (world if args.scaling == "weak" else 1)
     spp_total = (K + W) * S
     tile_count = world if world > 1 else max(1, args.rehearse_tiles)
@@ -350,7 +358,8 @@ def main():
             "rehearsal": (f"tile rank 0 of {tile_count} on one GPU: value is that rank's share of the frame, not the metric" if tile_count != world else None),
             "whole_path_algorithmic_GBs": tot["algorithmic_bytes"] / dt / 1e9,
             "scene_commit_seconds": s1.get("seconds_commit"),    # flatten + SAH BVH + upload, once per scene, outside the timed region
-            "scene_refit_seconds": refit_seconds,                # ptc_scene_refit: flatten + refit of the committed tree + upload of what moved
+            "scene_refit_seconds": refit_seconds,                # ptc_scene_refit on the device (csrc/pt_refit.hip): flatten + shading records + nodes, in place in HBM
+            "scene_refit_host_seconds": refit_host_seconds,      # PTC_REFIT=host: the same on the host's thread pool + upload
             "seconds": {"wall": dt, "trace_closest": d["seconds_trace_closest"], "trace_any": d["seconds_trace_any"], "shade": d["seconds_shade"],
                         "batches": d.get("seconds_render", 0.0)},
             "per_path": {"segments": tot["segments"] / paths, "shadow_rays": tot["shadow_rays"] / paths,

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Differential fuzzing of GPU vs oracle on random scenes (the generator of tests/test_gpu_parity.py): image bits and all traversal counters; every third
-scene through the LBVH builder, every other scene moved and refitted afterwards (ptc_update_instance + ptc_scene_refit against the oracle's).
+scene through the LBVH builder, every other scene moved and refitted afterwards (ptc_update_instance + ptc_scene_refit against the oracle's; the refit runs on
+the device, csrc/pt_refit.hip, and its BVH units and shading tables are also held byte for byte against a host refit of the same moves on a description-only context).
 usage: python tools/fuzz_parity.py [n] [seed]"""
 import importlib.util, os, sys
 import numpy as np
@@ -12,6 +13,7 @@ spec = importlib.util.spec_from_file_location("tg", os.path.join(ROOT, "tests", 
 n, seed = (int(sys.argv[1]) if len(sys.argv) > 1 else 200), (int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 rng = np.random.default_rng(seed)
 bad = 0
+n_dev_refits = 0
 for k in range(n):
     if k % 50 == 0: print("scene", k, flush=True)
     d = tg._random_scene(pbr.scene, rng, k)
@@ -26,25 +28,32 @@ for k in range(n):
         print("MISMATCH scene", k, d.bvh_builder, "pixels", int((g != c).any(-1).sum()), flush=True)
     if k % 2 == 0:          # every other scene is then moved (random new transforms for a third of its instances) and refitted on both sides
         moved = False
+        host = pbr.PathTracer(pbr.DEVICE_NONE).load_scene(d)
         for i, it in enumerate(d.instances):
             if rng.random() > 0.34:
                 continue
             if getattr(it, "matrix", None) is not None:
                 m = np.asarray(it.matrix, np.float32).reshape(16).copy()
                 m[12:15] += rng.normal(0, 0.3, 3).astype(np.float32)
-                pt.update_instance(i, matrix=m); o.update_instance(i, matrix=m)
+                pt.update_instance(i, matrix=m); o.update_instance(i, matrix=m); host.update_instance(i, matrix=m)
             else:
                 q = rng.normal(0, 1, 4); q /= np.linalg.norm(q)
                 t = tuple(float(x) for x in np.asarray(it.t) + rng.normal(0, 0.3, 3))
                 sc = tuple(float(x) for x in np.asarray(it.s) * rng.uniform(0.7, 1.4, 3))
-                pt.update_instance(i, t, tuple(float(x) for x in q), sc); o.update_instance(i, t, tuple(float(x) for x in q), sc)
+                pt.update_instance(i, t, tuple(float(x) for x in q), sc); o.update_instance(i, t, tuple(float(x) for x in q), sc); host.update_instance(i, t, tuple(float(x) for x in q), sc)
             moved = True
         if moved:
             pt.scene_refit(); o.scene_refit()
+            host.scene_refit()
+            a, b = tg._scene_bytes(pt), tg._scene_bytes(host)
+            n_dev_refits += pt.internals()["refit_on_device"]
+            if not all(np.array_equal(a[x], b[x]) for x in a):
+                bad += 1
+                print("MISMATCH device refit vs host refit, scene", k, [x for x in a if not np.array_equal(a[x], b[x])], flush=True)
             g, c = pt.render(w, h, spp, seed=s, max_bounces=mb), o.render(w, h, spp, seed=s, max_bounces=mb)
             ok = np.array_equal(g.view(np.uint32), c.view(np.uint32)) and all(pt.stats()[x] == o.stats()[x] for x in tg.COUNTERS)
             if not ok:
                 bad += 1
                 print("MISMATCH after refit, scene", k, d.bvh_builder, "pixels", int((g != c).any(-1).sum()), flush=True)
-print(f"{n} scenes, {bad} mismatches")
+print(f"{n} scenes, {n_dev_refits} refits on the device, {bad} mismatches")
 sys.exit(1 if bad else 0)

@@ -10,7 +10,7 @@ PKG=$ROOT/physically-based-renderer_amd; ITERS=${1:-4000}
 CLANG=/opt/rocm/lib/llvm/bin/clang++; RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
 SAN="-fsanitize=address,undefined -fno-omit-frame-pointer -g -O1"
 ( cd $PKG/csrc && /opt/rocm/bin/hipcc $SAN -fno-gpu-sanitize --offload-arch=gfx950 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
-    -fno-fast-math -I$ROOT/include -shared -o $OUT/libptc.so pt_kernels.hip ptc_api.cpp ptc_scene.cpp )
+    -fno-fast-math -I$ROOT/include -shared -o $OUT/libptc.so pt_kernels.hip pt_refit.hip ptc_api.cpp ptc_scene.cpp )
 $CLANG $SAN -std=c++17 -fPIC -ffp-contract=off -I$ROOT/include -I$PKG/host -shared -o $OUT/libptc_gltf.so $PKG/host/ptc_gltf.cpp -L$OUT -lptc -Wl,-rpath,$OUT
 cat > $OUT/run_host.py <<P
 import sys
