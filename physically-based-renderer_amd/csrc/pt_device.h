@@ -200,7 +200,11 @@ struct ray_t { v3 o, d, inv, ood; };
 PT_DEV float safe_dir(float d) { return __builtin_fabsf(d) < 1e-20f ? __builtin_copysignf(1e-20f, d) : d; }
 PT_DEV ray_t make_ray(v3 o, v3 d) {
   ray_t r; r.o = o; r.d = d;
+#ifdef PT_EXP_RCP      // timing experiment only (results differ): what the three IEEE divisions of a refill cost — the upper bound of carrying inv from the producer
+  r.inv = V3(__builtin_amdgcn_rcpf(safe_dir(d.x)), __builtin_amdgcn_rcpf(safe_dir(d.y)), __builtin_amdgcn_rcpf(safe_dir(d.z)));
+#else
   r.inv = V3(1.0f / safe_dir(d.x), 1.0f / safe_dir(d.y), 1.0f / safe_dir(d.z));
+#endif
   r.ood = V3(o.x * r.inv.x, o.y * r.inv.y, o.z * r.inv.z);
   return r;
 }

@@ -312,6 +312,36 @@ PT_DEV uint32_t next_triangle(uint32_t tbase, uint32_t& tmask) {
   return k;
 }
 
+// triangles still pending in a lane's set (after next_triangle took some)
+PT_DEV uint32_t pending_triangles(uint32_t tmask) {
+  const uint32_t lh = tmask & 255u;
+  return (uint32_t)__builtin_popcount(lh) + (uint32_t)__builtin_popcount((tmask >> 16) & lh) - (tmask >> 24);
+}
+#ifndef LEAF_EXTRA
+#define LEAF_EXTRA 1     // triangles a lane may hand to free lanes per leaf pass
+#endif
+// Leaf pass, work distribution: every lane at a leaf tests one triangle itself and hands up to LEAF_EXTRA more to lanes that are not at a leaf.
+// `extra` (0..LEAF_EXTRA) is what the lane would hand out; tasks are numbered by the exclusive prefix of `extra` over the lanes (ballot per bit of
+// `extra` + mbcnt) and the first `ntask` = min(total, free lanes) of them find a helper: task i goes to the i-th free lane.
+struct LeafDeal { uint32_t off, take, ntask, rank_free; bool helper; };
+PT_DEV LeafDeal leaf_deal(uint32_t extra, bool leaf, uint64_t m_leaf) {
+  LeafDeal d;
+  uint32_t off = 0, total = 0;
+#pragma unroll
+  for (int b = 0; (1 << b) <= LEAF_EXTRA; ++b) {
+    const uint64_t m = __ballot(((extra >> b) & 1u) != 0u);
+    off += mbcnt64(m) << b; total += (uint32_t)__popcll(m) << b;
+  }
+  const uint64_t m_free = ~m_leaf;
+  const uint32_t n_free = (uint32_t)__popcll(m_free);
+  d.rank_free = mbcnt64(m_free);
+  d.ntask = total < n_free ? total : n_free;
+  d.helper = !leaf && d.rank_free < d.ntask;
+  d.off = off;
+  d.take = off >= d.ntask ? 0u : (d.ntask - off < extra ? d.ntask - off : extra);
+  return d;
+}
+
 // Wave-private reservoir of input slots: idle lanes are refilled from a chunk of consecutive rays of one queue segment (ballot +
 // mbcnt).  Chunks are numbered over the whole queue (k_scan's prefix of chunks per segment); the first chunk of every wave is static
 // (wave w of the grid owns chunk w), the rest are handed out by one atomic per chunk.  Atomics on one word are served one at a time
@@ -416,8 +446,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_closest(
   const RayQ rq = q.ray[qi];
   unsigned long long nv = 0, nr = 0, nh = 0;   // wave totals, only updated at wave-uniform points: they live in SGPRs
   uint32_t nt = 0;                               // per lane (updated inside the divergent leaf phase)
-  uint32_t d_node = 0, d_tri = 0, d_round = 0;
-  (void)d_node; (void)d_tri; (void)d_round;
+  uint32_t d_node = 0, d_tri = 0, d_round = 0, d_leftpass = 0, d_left = 0;
+  (void)d_node; (void)d_tri; (void)d_round; (void)d_leftpass; (void)d_left;
 #ifdef PT_STAMP
   unsigned long long t_refill = 0, t_node = 0, t_leaf = 0, t_fin = 0, t_mark = __builtin_amdgcn_s_memtime();
 #define STAMP(acc) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - t_mark; t_mark = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -479,6 +509,105 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_closest(
       // one to a lane that is not at a leaf (the k-th such owner to the k-th free lane, through two 64-byte LDS tables; the helper
       // fetches the owner's ray through ds_bpermute and returns its result the same way).  Same tests, same results and counters
       // as one triangle per pass — closest hit is an order-independent minimum — in fewer passes.
+#if LEAF_EXTRA == 0    // no hand-outs: every lane at a leaf tests its own next triangle (no cross-lane traffic at all)
+      {
+        const bool leaf = cur == CUR_LEAF;
+        if (__ballot(leaf)) {
+          DIAG_ITER(d_tri);
+          if (leaf) {
+            const uint32_t k = next_triangle(tbase, tmask);
+            float4 a, b, c;
+            load_triangle(sc, L.top_addr, k, a, b, c);
+            float t, u, v;
+            const bool hit = tri_test<CULL>(r, V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), t, u, v);
+            const int pid = __float_as_int(a.w);
+            ++nt;
+            if (hit && t > tmin && (t < best_t || (t == best_t && pid < best_prim))) {
+              best_t = t; best_u = u; best_v = v; best_prim = pid; best_cls = __float_as_int(b.w); found = true;
+            }
+            if ((tmask & 255u) == 0u) cur = advance<true>(gbase, gmask, st, order_tab, oct);
+          }
+        }
+      }
+#elif LEAF_EXTRA > 1
+      {
+        const bool leaf = cur == CUR_LEAF;
+        const uint64_t m_leaf = __ballot(leaf);
+        if (m_leaf) {
+          DIAG_ITER(d_tri);
+          uint32_t k1 = 0, pend = 0;
+          if (leaf) { k1 = next_triangle(tbase, tmask); pend = pending_triangles(tmask); }
+          const LeafDeal dl = leaf_deal(pend < LEAF_EXTRA ? pend : LEAF_EXTRA, leaf, m_leaf);
+          typedef __attribute__((address_space(3))) volatile uint8_t lds_u8;
+          lds_u8* tab_task = (lds_u8*)s_pair[0][wave];      // task -> owner lane | which of its extras << 6
+          lds_u8* tab_helper = (lds_u8*)s_pair[1][wave];    // task -> helper lane
+          uint32_t kx[LEAF_EXTRA];
+#pragma unroll
+          for (uint32_t j = 0; j < LEAF_EXTRA; ++j) {
+            kx[j] = 0;
+            if (j < dl.take) { kx[j] = next_triangle(tbase, tmask); tab_task[dl.off + j] = (uint8_t)(lane | (j << 6)); }
+          }
+          if (dl.helper) tab_helper[dl.rank_free] = (uint8_t)lane;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const uint32_t task = dl.helper ? (uint32_t)tab_task[dl.rank_free] : lane;
+          const int src = (int)(task & 63u);
+          ray_t rr;
+          rr.o = V3(__shfl(r.o.x, src), __shfl(r.o.y, src), __shfl(r.o.z, src));
+          rr.d = V3(__shfl(r.d.x, src), __shfl(r.d.y, src), __shfl(r.d.z, src));
+          uint32_t k = k1;
+#pragma unroll
+          for (uint32_t j = 0; j < LEAF_EXTRA; ++j) {
+            const uint32_t kj = (uint32_t)__shfl((int)kx[j], src);       // unconditional: a shuffle inside ?: would run with the owners masked off
+            if (dl.helper && (task >> 6) == j) k = kj;
+          }
+          bool hit = false; float t = 0.0f, u = 0.0f, v = 0.0f; int pid = 0, cls = 0;
+          if (leaf || dl.helper) {
+            float4 a, b, c;
+            load_triangle(sc, L.top_addr, k, a, b, c);
+            hit = tri_test<CULL>(rr, V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), t, u, v);
+            pid = __float_as_int(a.w); cls = __float_as_int(b.w);
+          }
+          if (leaf) {
+            ++nt;
+            if (hit && t > tmin && (t < best_t || (t == best_t && pid < best_prim))) {
+              best_t = t; best_u = u; best_v = v; best_prim = pid; best_cls = cls; found = true;
+            }
+          }
+          // results of the handed-out triangles: (t, prim | class) of each, then (u, v) of the best of them only
+          const float tt = hit ? t : -INFINITY;
+          const int pw = pid | (cls << HIT_CLASS_SHIFT);
+          float bt = 0.0f; int bp = 0, bl = (int)lane; bool have = false;
+#pragma unroll
+          for (uint32_t j = 0; j < LEAF_EXTRA; ++j) {
+            const int hl = j < dl.take ? (int)tab_helper[dl.off + j] : (int)lane;
+            const float tj = __shfl(tt, hl);
+            const int pj = __shfl(pw, hl);
+            if (j < dl.take) {
+              ++nt;
+              const int prim_j = pj & ((1 << HIT_CLASS_SHIFT) - 1);
+              if (tj > tmin && (!have || tj < bt || (tj == bt && prim_j < (bp & ((1 << HIT_CLASS_SHIFT) - 1))))) { bt = tj; bp = pj; bl = hl; have = true; }
+            }
+          }
+          const float ub = __shfl(u, bl), vb = __shfl(v, bl);
+          if (have) {
+            const int prim_b = bp & ((1 << HIT_CLASS_SHIFT) - 1);
+            if (bt < best_t || (bt == best_t && prim_b < best_prim)) {
+              best_t = bt; best_u = ub; best_v = vb; best_prim = prim_b; best_cls = (int)((uint32_t)bp >> HIT_CLASS_SHIFT); found = true;
+            }
+          }
+          if (leaf && (tmask & 255u) == 0u) cur = advance<true>(gbase, gmask, st, order_tab, oct);
+#ifdef PT_DIAG
+          {
+            const uint32_t left = (cur == CUR_LEAF) ? pending_triangles(tmask) : 0u;
+            const uint64_t m_left = __ballot(left != 0u);
+            if (m_left) { if ((int)lane == __ffsll((unsigned long long)m_left) - 1) ++d_leftpass; d_left += left; }
+          }
+#endif
+        }
+      }
+#else
       {
         const bool leaf = cur == CUR_LEAF;
         const uint64_t m_leaf = __ballot(leaf);
@@ -529,8 +658,16 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_closest(
             }
           }
           if (leaf && (tmask & 255u) == 0u) cur = advance<true>(gbase, gmask, st, order_tab, oct);
+#ifdef PT_DIAG     // what a pass leaves behind: passes after which some lane still has triangles pending, and how many triangles those are
+          {
+            const uint32_t left = (cur == CUR_LEAF) ? (uint32_t)__builtin_popcount(tmask & 255u) + (uint32_t)__builtin_popcount((tmask >> 16) & tmask & 255u) - (tmask >> 24) : 0u;
+            const uint64_t m_left = __ballot(left != 0u);
+            if (m_left) { if ((int)lane == __ffsll((unsigned long long)m_left) - 1) ++d_leftpass; d_left += left; }
+          }
+#endif
         }
       }
+#endif
       STAMP(t_leaf);
       nh += (unsigned long long)__popcll(__ballot(cur == CUR_FINISHED && found));
       if (cur == CUR_FINISHED) {                                       // this lane's ray is finished: publish in place
@@ -550,8 +687,9 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_closest(
 #endif
 #ifdef PT_DIAG
   {
-    unsigned long long a0 = wave_sum(d_node), a1 = wave_sum(d_tri), a3 = wave_sum(d_round);
-    if (lane == 0) { atomicAdd(&q.stats[ST_DIAG_NODE_ITERS], a0); atomicAdd(&q.stats[ST_DIAG_TRI_ITERS], a1); atomicAdd(&q.stats[ST_DIAG_ROUNDS], a3); }
+    unsigned long long a0 = wave_sum(d_node), a1 = wave_sum(d_tri), a3 = wave_sum(d_round), a4 = wave_sum(d_leftpass), a5 = wave_sum(d_left);
+    if (lane == 0) { atomicAdd(&q.stats[ST_DIAG_NODE_ITERS], a0); atomicAdd(&q.stats[ST_DIAG_TRI_ITERS], a1); atomicAdd(&q.stats[ST_DIAG_ROUNDS], a3);
+                     atomicAdd(&q.stats[ST_DIAG_LEAF_VISITS], a4); atomicAdd(&q.stats[ST_DIAG_REFILLED], a5); }
   }
 #endif
 }
@@ -615,6 +753,76 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_any(DevS
           cur = lhits ? CUR_LEAF : advance<false>(gbase, gmask, st, nullptr, 0u);
         }
       }
+#if LEAF_EXTRA == 0
+      {
+        const bool leaf = cur == CUR_LEAF;
+        if (__ballot(leaf)) {
+          if (leaf) {
+            const uint32_t k = next_triangle(tbase, tmask);
+            float4 a, b, c;
+            load_triangle(sc, L.top_addr, k, a, b, c);
+            float t, u, v;
+            const bool hit = tri_test<false>(r, V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), t, u, v) && t > 0.0f && t < tmax;
+            ++nt;
+            if (hit) { occluded = true; cur = CUR_FINISHED; }
+            else if ((tmask & 255u) == 0u) cur = advance<false>(gbase, gmask, st, nullptr, 0u);
+          }
+        }
+      }
+#elif LEAF_EXTRA > 1
+      {
+        // ---- leaf phase: as in k_trace_closest, up to LEAF_EXTRA more of a lane's pending triangles are tested in the same pass by free lanes.
+        // The counter stays the sequential one: a test is counted (and used) only when all tests before it missed.
+        const bool leaf = cur == CUR_LEAF;
+        const uint64_t m_leaf = __ballot(leaf);
+        if (m_leaf) {
+          uint32_t k1 = 0, pend = 0;
+          if (leaf) { k1 = next_triangle(tbase, tmask); pend = pending_triangles(tmask); }
+          const LeafDeal dl = leaf_deal(pend < LEAF_EXTRA ? pend : LEAF_EXTRA, leaf, m_leaf);
+          typedef __attribute__((address_space(3))) volatile uint8_t lds_u8;
+          lds_u8* tab_task = (lds_u8*)s_pair[0][wave];
+          lds_u8* tab_helper = (lds_u8*)s_pair[1][wave];
+          uint32_t kx[LEAF_EXTRA];
+#pragma unroll
+          for (uint32_t j = 0; j < LEAF_EXTRA; ++j) {
+            kx[j] = 0;
+            if (j < dl.take) { kx[j] = next_triangle(tbase, tmask); tab_task[dl.off + j] = (uint8_t)(lane | (j << 6)); }
+          }
+          if (dl.helper) tab_helper[dl.rank_free] = (uint8_t)lane;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const uint32_t task = dl.helper ? (uint32_t)tab_task[dl.rank_free] : lane;
+          const int src = (int)(task & 63u);
+          ray_t rr;
+          rr.o = V3(__shfl(r.o.x, src), __shfl(r.o.y, src), __shfl(r.o.z, src));
+          rr.d = V3(__shfl(r.d.x, src), __shfl(r.d.y, src), __shfl(r.d.z, src));
+          const float tmax_src = __shfl(tmax, src);
+          uint32_t k = k1;
+#pragma unroll
+          for (uint32_t j = 0; j < LEAF_EXTRA; ++j) {
+            const uint32_t kj = (uint32_t)__shfl((int)kx[j], src);
+            if (dl.helper && (task >> 6) == j) k = kj;
+          }
+          bool hit = false;
+          if (leaf || dl.helper) {
+            float4 a, b, c;
+            load_triangle(sc, L.top_addr, k, a, b, c);
+            float t, u, v;
+            hit = tri_test<false>(rr, V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), t, u, v) && t > 0.0f && t < tmax_src;
+          }
+          bool done = false;
+          if (leaf) { ++nt; if (hit) { occluded = true; cur = CUR_FINISHED; done = true; } }
+#pragma unroll
+          for (uint32_t j = 0; j < LEAF_EXTRA; ++j) {
+            const int hl = j < dl.take ? (int)tab_helper[dl.off + j] : (int)lane;
+            const int hj = __shfl(hit ? 1 : 0, hl);
+            if (j < dl.take && !done) { ++nt; if (hj) { occluded = true; cur = CUR_FINISHED; done = true; } }
+          }
+          if (cur == CUR_LEAF && (tmask & 255u) == 0u) cur = advance<false>(gbase, gmask, st, nullptr, 0u);
+        }
+      }
+#else
       {
         // ---- leaf phase: as in k_trace_closest, a lane's second pending triangle is tested in the same pass by a free lane.  The
         // counter stays the sequential one: the second test is counted (and used) only when the first one missed.
@@ -664,6 +872,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_any(DevS
           }
         }
       }
+#endif
       if (cur == CUR_FINISHED) {
         if (DEBUG_OUT) debug_out[ri] = occluded ? 1 : 0;
         else if (!occluded) {
