@@ -329,6 +329,13 @@ int ptc_debug_get_internals(ptc_ctx*, uint64_t out[8]);
  * host and the oracle's through these two calls. */
 int ptc_debug_get_shading_tables(ptc_ctx*, uint32_t* stride, float* shade, uint32_t* n_lights, float* lights, float* cdf);
 
+/* The HOST's share of a refit on the device, runnable without one (CPU tests, sanitizer builds): the plan of the committed scene (vertex ->
+ * instance, node addresses by level) and the emitter table of the current transforms from the emissive primitives alone, checked against the
+ * host build; call it after ptc_scene_refit on a description-only context.  out: [0] world vertices, [1] primitives, [2] nodes in the level
+ * lists, [3] levels, [4] primitives with an emissive material, [5] 1 if the lists hold every node once with children in earlier levels,
+ * [6] 1 if emitter table and cdf equal the host refit's bit for bit, [7] 1 if every instance transform is finite. */
+int ptc_debug_refit_host_parts(ptc_ctx*, uint64_t out[8]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -737,6 +737,7 @@ int ptc_scene_refit(ptc_ctx* c) {
   const std::string e = ptc_refit_scene(c->mats, c->meshes, c->insts, c->texs, c->env, B);
   if (!e.empty()) return fail(c, PTC_E_STATE, e);
   c->in_frame = false; c->pending = 0;
+  c->stats.n_emitters = B.n_lights;
   if (c->device >= 0) {
     int rc = refit_upload(c, B.recs.size() == n_recs && B.shade.size() == n_shade && B.lights.size() == n_lights && B.cdf.size() == n_cdf, t0);
     if (rc) return rc;
@@ -1351,6 +1352,47 @@ int ptc_debug_get_internals(ptc_ctx* c, uint64_t out[8]) {
   for (int i = 0; i < 8; ++i) out[i] = 0;
   out[0] = c->events_created; out[1] = c->spans.size(); out[2] = c->lanes.empty() ? 0 : c->lanes[0].q.cap; out[3] = c->per_batch; out[4] = c->pending;
   out[5] = (uint64_t)c->cfg.trace_blocks_per_cu; out[6] = (uint64_t)c->cfg.stack_lds; out[7] = c->last_refit_on_device ? 1u : 0u;
+  return PTC_OK;
+}
+
+// The host's share of a refit on the device, run without a device (CPU tests, sanitizer builds): builds the plan of the committed scene and the
+// emitter table of the CURRENT transforms from the emissive primitives alone, and checks them against the host build — call it after
+// ptc_scene_refit on a description-only context.  out: [0] world vertices, [1] primitives, [2] 8-wide nodes in the level lists, [3] levels,
+// [4] emissive-material primitives, [5] 1 if the level lists hold every node address of the tree exactly once with children after parents,
+// [6] 1 if the emitter table and cdf equal the host refit's bit for bit (0 also when the set of emitters changed), [7] 1 if all transforms are finite.
+int ptc_debug_refit_host_parts(ptc_ctx* c, uint64_t out[8]) {
+  if (!c || !out) return PTC_E_ARG;
+  if (!c->committed) return fail(c, PTC_E_STATE, "debug_refit_host_parts: scene not committed");
+  { int rr = refresh_host_copy(c); if (rr) return rr; }
+  const HostBuilt& B = *c->built;
+  RefitPlan P;
+  ptc_refit_plan(c->mats, c->meshes, c->insts, B, P);
+  std::vector<float> xf, lights, cdf;
+  const bool finite = ptc_refit_instance_transforms(c->insts, xf);
+  const bool same_set = ptc_refit_emitters(c->mats, c->meshes, c->insts, P, B, lights, cdf);
+  out[0] = P.n_verts; out[1] = P.n_tris; out[2] = P.level_nodes.size(); out[3] = P.level_first.empty() ? 0 : P.level_first.size() - 1; out[4] = P.emit_prims.size() / 5;
+  // every node once, and a node's children (its block's interior records) in an earlier level than the node itself
+  bool ok = P.level_nodes.size() == B.n_nodes && !P.level_first.empty() && P.level_first.back() == P.level_nodes.size() && P.vert_inst.size() == B.wverts.size();
+  std::vector<int32_t> level_of((size_t)B.n_units / 4 + 1, -1);
+  for (size_t l = 0; ok && l + 1 < P.level_first.size(); ++l)
+    for (uint32_t i = P.level_first[l]; i < P.level_first[l + 1]; ++i) {
+      const uint32_t a = P.level_nodes[i];
+      if ((a & 3u) || a >= B.n_units || level_of[a >> 2] >= 0) { ok = false; break; }
+      level_of[a >> 2] = (int32_t)l;
+    }
+  for (size_t i = 0; ok && i < P.level_nodes.size(); ++i) {
+    const uint32_t a = P.level_nodes[i];
+    uint32_t w2, w3; std::memcpy(&w2, &B.recs[(size_t)a * 4 + 2], 4); std::memcpy(&w3, &B.recs[(size_t)a * 4 + 3], 4);
+    const uint32_t imask = (w2 >> 8) & 255u;
+    for (uint32_t k = 0; k < (uint32_t)__builtin_popcount(imask); ++k) {
+      const uint32_t ch = w3 + 4u * k;
+      if (ch >= B.n_units || level_of[ch >> 2] < 0 || level_of[ch >> 2] >= level_of[a >> 2]) { ok = false; break; }
+    }
+  }
+  out[5] = ok ? 1u : 0u;
+  out[6] = (same_set && lights.size() == B.lights.size() && cdf.size() == B.cdf.size() && std::memcmp(lights.data(), B.lights.data(), lights.size() * 4) == 0 &&
+            std::memcmp(cdf.data(), B.cdf.data(), cdf.size() * 4) == 0) ? 1u : 0u;
+  out[7] = finite ? 1u : 0u;
   return PTC_OK;
 }
 

@@ -309,6 +309,44 @@ def _rotated(desc, k):
     return out
 
 
+@pytest.mark.parametrize("name,kw,builder", [("cornell", {}, None), ("sphere10k", {}, "lbvh"), ("atrium", {"scale": 0.05}, None), ("textured_objects", {}, None)])
+def test_host_share_of_the_device_refit(pbr, name, kw, builder):
+    """csrc/pt_refit.hip's kernels need a GPU; what the host contributes to them does not: the plan of the committed scene (every 8-wide node's
+    address once, children in earlier levels than their parents — the order the node kernel is launched in — and the vertex -> instance map) and
+    the emitter table rebuilt from the emissive primitives alone, which must be the host refit's bit for bit after any move; a move that changes
+    which triangles are emitters is recognised (the device path then hands over to the host refit)."""
+    import copy
+    d = pbr.scenes.by_name(name, **kw)
+    if builder:
+        d = copy.deepcopy(d)
+        d.bvh_builder = builder
+    pt = pbr.PathTracer(pbr.DEVICE_NONE).load_scene(d)
+    st = pt.stats()
+    r = pt.refit_host_parts()
+    assert r["levels_ok"] == 1 and r["emitters_equal"] == 1 and r["transforms_finite"] == 1
+    assert r["n_tris"] == st["n_triangles"] and r["nodes_listed"] == st["n_bvh_nodes"] and r["levels"] == st["bvh_max_depth"] + 1
+    assert r["n_verts"] == pt.flat_scene()[0].shape[0]
+    for k in (1, 2):
+        for i, m in enumerate(_rotated(d, k)):
+            if m is not None:
+                pt.update_instance(i, m[0], m[1], tuple(np.float32(x) * np.float32(1.0 + 0.07 * k) for x in m[2]))
+        pt.scene_refit()
+        r = pt.refit_host_parts()
+        assert r["levels_ok"] == 1 and r["emitters_equal"] == 1, (k, r)
+    emissive = [i for i, it in enumerate(d.instances) if any(x > 0 for x in d.materials[d.meshes[it.mesh].material].emissive)]
+    if emissive:
+        assert r["emissive_prims"] > 0
+        i = emissive[0]
+        pt.update_instance(i, (0.0, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0), (0.0, 0.0, 0.0))      # the emitter collapses to a point: it stops being one
+        assert pt.refit_host_parts()["emitters_equal"] == 0                                # before the refit the committed emitter set is the old one
+        pt.scene_refit()
+        assert pt.stats()["n_emitters"] < st["n_emitters"] and pt.refit_host_parts()["emitters_equal"] == 1
+    bad = np.eye(4, dtype=np.float32).reshape(16)
+    bad[5] = np.inf
+    pt.update_instance(0, matrix=bad)
+    assert pt.refit_host_parts()["transforms_finite"] == 0
+
+
 @pytest.mark.parametrize("name,kw", [("sphere10k", {}), ("atrium", {"scale": 0.05}), ("textured_objects", {})])
 def test_refit_equals_oracle_and_keeps_the_topology(ora, pbr, name, kw):
     """ptc_update_instance + ptc_scene_refit against the oracle's: the refitted trees are identical bit for bit (same topology and slots as
