@@ -894,12 +894,53 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_any(DevS
 // =================================================================================================
 // R7 sampler: NEAREST, REPEAT, no mips (the reference creates its samplers with default create-info, gltf/Asset.cpp:116-117);
 // RGBA8 UNORM texel → float / 255.
-PT_DEV float4 texel_rgba(const DevScene& sc, size_t at) {
+// ---- address spaces of k_shade's scene accesses ---------------------------------------------------------------------------------------
+// k_shade receives the scene through a pointer (DevScene lies in device memory), so the array pointers inside it are values LOADED from memory and
+// the compiler has to treat them as generic: every gather became a FLAT load, which takes a slot in the LDS queue as well as in the vector-memory
+// queue and, because the two return out of order, can only be waited for with vmcnt(0) lgkmcnt(0) — no partial waits, no two chains of loads in
+// flight.  GScene is the same scene with its arrays typed as what they are (global memory); Dual is a table that lies in LDS when it fits and in
+// global memory when it does not, each behind its own address space.  The helpers below are templates over the scene type, so that
+// k_shade_raster (DevScene by value: kernel-argument pointers, known to be global) uses them unchanged.
+typedef float fx4 __attribute__((ext_vector_type(4)));
+typedef uint32_t ux4 __attribute__((ext_vector_type(4)));
+typedef int ix4 __attribute__((ext_vector_type(4)));
+#define AS_GLOBAL __attribute__((address_space(1)))
+#define AS_LDS __attribute__((address_space(3)))
+PT_DEV float4 ld4(const float4* p, size_t i) { return p[i]; }
+PT_DEV float4 ld4(AS_GLOBAL const fx4* p, size_t i) { const fx4 v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
+PT_DEV float4 ld4(AS_LDS const fx4* p, size_t i) { const fx4 v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
+PT_DEV uint4 ldu4(const uint4* p, size_t i) { return p[i]; }
+PT_DEV uint4 ldu4(AS_GLOBAL const ux4* p, size_t i) { const ux4 v = p[i]; return make_uint4(v.x, v.y, v.z, v.w); }
+PT_DEV int4 ldi4(const int4* p, size_t i) { return p[i]; }
+PT_DEV int4 ldi4(AS_GLOBAL const ix4* p, size_t i) { const ix4 v = p[i]; return make_int4(v.x, v.y, v.z, v.w); }
+template <class T> struct Dual {
+  AS_LDS const T* l; AS_GLOBAL const T* g; bool in_lds;
+  PT_DEV T operator[](size_t i) const { return in_lds ? l[i] : g[i]; }
+};
+PT_DEV float4 ld4(const Dual<fx4>& p, size_t i) { const fx4 v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
+struct GScene {
+  AS_GLOBAL const fx4* shade; uint32_t shade_stride;
+  AS_GLOBAL const uint32_t* texels; AS_GLOBAL const ix4* tex_info; AS_GLOBAL const ux4* set_texels; AS_GLOBAL const ix4* set_info; int tex_linear;
+  AS_GLOBAL const fx4* env; AS_GLOBAL const float* env_cond; AS_GLOBAL const uint16_t* env_cond_guide; int env_w, env_h, env_ok;
+  uint32_t n_lights, n_mats; float ray_eps;
+};
+PT_DEV GScene global_view(const DevScene& d) {
+  GScene g;
+  g.shade = (AS_GLOBAL const fx4*)d.shade; g.shade_stride = d.shade_stride;
+  g.texels = (AS_GLOBAL const uint32_t*)d.texels; g.tex_info = (AS_GLOBAL const ix4*)d.tex_info;
+  g.set_texels = (AS_GLOBAL const ux4*)d.set_texels; g.set_info = (AS_GLOBAL const ix4*)d.set_info; g.tex_linear = d.tex_linear;
+  g.env = (AS_GLOBAL const fx4*)d.env; g.env_cond = (AS_GLOBAL const float*)d.env_cond; g.env_cond_guide = (AS_GLOBAL const uint16_t*)d.env_cond_guide;
+  g.env_w = d.env_w; g.env_h = d.env_h; g.env_ok = d.env_ok;
+  g.n_lights = d.n_lights; g.n_mats = d.n_mats; g.ray_eps = d.ray_eps;
+  return g;
+}
+
+template <class S> PT_DEV float4 texel_rgba(const S& sc, size_t at) {
   const uint32_t p = sc.texels[at];
   return make_float4((float)(p & 255u) / 255.0f, (float)((p >> 8) & 255u) / 255.0f, (float)((p >> 16) & 255u) / 255.0f, (float)(p >> 24) / 255.0f);
 }
-PT_DEV float4 tex_fetch(const DevScene& sc, int tex, float u, float v) {
-  const int4 ti = sc.tex_info[tex];
+template <class S> PT_DEV float4 tex_fetch(const S& sc, int tex, float u, float v) {
+  const int4 ti = ldi4(sc.tex_info, (size_t)tex);
   const float fu = u - __builtin_floorf(u), fv = v - __builtin_floorf(v);
   if (!sc.tex_linear) {
     int x = (int)(fu * (float)ti.y), y = (int)(fv * (float)ti.z);
@@ -935,13 +976,13 @@ PT_DEV float4 unorm8x4(uint32_t p) {
 }
 // The three texels (colour, normal, metal-rough) of a texture set at (u, v): ONE 16-byte gather per tap instead of three 4-byte gathers from
 // three textures.  Same arithmetic per texture as tex_fetch (the set's textures share one size, so the tap coordinates are the same).
-PT_DEV void set_fetch(const DevScene& sc, int4 si, float u, float v, float4& c, float4& n, float4& m) {
+template <class S> PT_DEV void set_fetch(const S& sc, int4 si, float u, float v, float4& c, float4& n, float4& m) {
   const float fu = u - __builtin_floorf(u), fv = v - __builtin_floorf(v);
   if (!sc.tex_linear) {
     int x = (int)(fu * (float)si.y), y = (int)(fv * (float)si.z);
     if (x > si.y - 1) x = si.y - 1;
     if (y > si.z - 1) y = si.z - 1;
-    const uint4 t = sc.set_texels[set_texel_at(si, x, y)];
+    const uint4 t = ldu4(sc.set_texels, set_texel_at(si, x, y));
     c = unorm8x4(t.x); n = unorm8x4(t.y); m = unorm8x4(t.z);
     return;
   }
@@ -954,8 +995,8 @@ PT_DEV void set_fetch(const DevScene& sc, int4 si, float u, float v, float4& c, 
   if (y0 < 0) y0 += si.z;
   if (x1 > si.y - 1) x1 -= si.y;
   if (y1 > si.z - 1) y1 -= si.z;
-  const uint4 t00 = sc.set_texels[set_texel_at(si, x0, y0)], t10 = sc.set_texels[set_texel_at(si, x1, y0)],
-              t01 = sc.set_texels[set_texel_at(si, x0, y1)], t11 = sc.set_texels[set_texel_at(si, x1, y1)];
+  const uint4 t00 = ldu4(sc.set_texels, set_texel_at(si, x0, y0)), t10 = ldu4(sc.set_texels, set_texel_at(si, x1, y0)),
+              t01 = ldu4(sc.set_texels, set_texel_at(si, x0, y1)), t11 = ldu4(sc.set_texels, set_texel_at(si, x1, y1));
   auto bil = [&](uint32_t p00, uint32_t p10, uint32_t p01, uint32_t p11) {
     const float4 c00 = unorm8x4(p00), c10 = unorm8x4(p10), c01 = unorm8x4(p01), c11 = unorm8x4(p11);
     const float ax = pt_fma(tx, c10.x - c00.x, c00.x), ay = pt_fma(tx, c10.y - c00.y, c00.y), az = pt_fma(tx, c10.z - c00.z, c00.z), aw = pt_fma(tx, c10.w - c00.w, c00.w);
@@ -969,12 +1010,12 @@ PT_DEV void set_fetch(const DevScene& sc, int4 si, float u, float v, float4& c, 
 // (glTF: G = roughness, B = metallic), tangent-space normal map through the interpolated TBN (fragment.glsl:24-30).
 // ni = interpolated (un-normalised) vertex normal.  Updates base/metallic/roughness/ns in place.  `set` is the material's texture
 // set (M3.x): when the set has an interleaved copy the three texels come with one gather, else one fetch per texture.
-PT_DEV void apply_textures(const DevScene& sc, const float4* tr, float hu, float hv, float hw, float4 M2, int set, v3 ni, float base[4], float& metallic, float& roughness, v3& ns) {
+template <class S> PT_DEV void apply_textures(const S& sc, float4 t0, float4 t1, float4 t2, float4 t3, float4 t4, float4 t5, float hu, float hv, float hw, float4 M2, int set, v3 ni, float base[4],
+                           float& metallic, float& roughness, v3& ns) {
   const int tex_color = __float_as_int(M2.y), tex_normal = __float_as_int(M2.z), tex_mr = __float_as_int(M2.w);
-  const float4 t0 = tr[0], t1 = tr[1];
   const float tu = pt_fma(t1.x, hv, pt_fma(t0.z, hu, t0.x * hw)), tv = pt_fma(t1.y, hv, pt_fma(t0.w, hu, t0.y * hw));
   float4 cc = make_float4(1, 1, 1, 1), cn = make_float4(0.5f, 0.5f, 1.0f, 1.0f), cm = make_float4(1, 1, 1, 1);
-  const int4 si = sc.set_info[set < 0 ? 0 : set];
+  const int4 si = ldi4(sc.set_info, (size_t)(set < 0 ? 0 : set));
   if (set >= 0 && si.x >= 0) set_fetch(sc, si, tu, tv, cc, cn, cm);
   else {
     if (tex_color >= 0) cc = tex_fetch(sc, tex_color, tu, tv);
@@ -985,7 +1026,6 @@ PT_DEV void apply_textures(const DevScene& sc, const float4* tr, float hu, float
   if (tex_mr >= 0) { roughness = roughness * cm.y; metallic = metallic * cm.z; }
   if (tex_normal >= 0) {
     const float nx = 2.0f * cn.x - 1.0f, ny = 2.0f * cn.y - 1.0f, nz = 2.0f * cn.z - 1.0f;
-    const float4 t2 = tr[2], t3 = tr[3], t4 = tr[4], t5 = tr[5];
     // tangents: a = (t1.z, t1.w, t2.x) b = (t2.y, t2.z, t2.w) c = (t3.x, t3.y, t3.z); bitangents: a = (t3.w, t4.x, t4.y) b = (t4.z, t4.w, t5.x) c = (t5.y, t5.z, t5.w)
     const v3 ti = V3(pt_fma(t3.x, hv, pt_fma(t2.y, hu, t1.z * hw)), pt_fma(t3.y, hv, pt_fma(t2.z, hu, t1.w * hw)), pt_fma(t3.z, hv, pt_fma(t2.w, hu, t2.x * hw)));
     const v3 bi = V3(pt_fma(t5.y, hv, pt_fma(t4.z, hu, t3.w * hw)), pt_fma(t5.z, hv, pt_fma(t4.w, hu, t4.x * hw)), pt_fma(t5.w, hv, pt_fma(t5.x, hu, t4.y * hw)));
@@ -994,7 +1034,7 @@ PT_DEV void apply_textures(const DevScene& sc, const float4* tr, float hu, float
 }
 
 // Lat-long environment: radiance and solid-angle pdf of a unit direction (piecewise-constant texels).
-PT_DEV void env_lookup(const DevScene& sc, v3 d, v3& Le, float& pdf) {
+template <class S> PT_DEV void env_lookup(const S& sc, v3 d, v3& Le, float& pdf) {
   const float u = pt_atan2(d.z, d.x) * (0.5f * PT_INV_PI) + 0.5f;
   const float dy = fmin2(fmax2(d.y, -1.0f), 1.0f);
   const float st = pt_sqrt(fmax2(0.0f, 1.0f - dy * dy));
@@ -1004,11 +1044,11 @@ PT_DEV void env_lookup(const DevScene& sc, v3 d, v3& Le, float& pdf) {
   if (x < 0) x = 0;
   if (y > sc.env_h - 1) y = sc.env_h - 1;
   if (y < 0) y = 0;
-  const float4 t = sc.env[(size_t)y * (size_t)sc.env_w + (size_t)x];
+  const float4 t = ld4(sc.env, (size_t)y * (size_t)sc.env_w + (size_t)x);
   Le = V3(t.x, t.y, t.z);
   pdf = sc.env_ok ? (t.w * (float)sc.env_w * (float)sc.env_h) / (2.0f * PT_PI * PT_PI * fmax2(st, 1e-6f)) : 0.0f;
 }
-PT_DEV uint32_t cdf_search(const float* cdf, uint32_t n, float r) {
+template <class P> PT_DEV uint32_t cdf_search(const P& cdf, uint32_t n, float r) {
   uint32_t lo = 0, hi = n - 1u;
   while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cdf[mid] > r) hi = mid; else lo = mid + 1u; }
   return lo;
@@ -1016,18 +1056,18 @@ PT_DEV uint32_t cdf_search(const float* cdf, uint32_t n, float r) {
 // Importance-sample the environment: row by the marginal cdf, column by the row's conditional cdf, uniform inside the texel.
 // cdf_search over [guide[b], guide[b + 1]], b = floor(PTC_ENV_GUIDE r): the same index as the search over the whole table (the answer is monotonic in r
 // and guide[b] is the answer for r = b/64), after 2 + log2(range) instead of log2(n) dependent loads
-PT_DEV uint32_t cdf_search_guided(const float* cdf, const uint16_t* guide, float r) {
+template <class P, class G> PT_DEV uint32_t cdf_search_guided(const P& cdf, const G& guide, float r) {
   const uint32_t b = (uint32_t)(r * (float)PTC_ENV_GUIDE);
   uint32_t lo = guide[b], hi = guide[b + 1u];
   while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cdf[mid] > r) hi = mid; else lo = mid + 1u; }
   return lo;
 }
 // marg / marg_guide: the row cdf and its guide — the scene's arrays, or k_shade's copies in LDS
-PT_DEV v3 env_sample(const DevScene& sc, const float* marg, const uint16_t* marg_guide, float r1, float r2) {
+template <class S, class P, class G> PT_DEV v3 env_sample(const S& sc, const P& marg, const G& marg_guide, float r1, float r2) {
   const uint32_t y = cdf_search_guided(marg, marg_guide, r1);
   const float m0 = y ? marg[y - 1u] : 0.0f, m1 = marg[y];
   float xi_v = m1 > m0 ? (r1 - m0) / (m1 - m0) : 0.5f;
-  const float* cc = sc.env_cond + (size_t)y * (size_t)sc.env_w;
+  const auto cc = sc.env_cond + (size_t)y * (size_t)sc.env_w;
   const uint32_t x = cdf_search_guided(cc, sc.env_cond_guide + (size_t)y * (PTC_ENV_GUIDE + 1u), r2);
   const float c0 = x ? cc[x - 1u] : 0.0f, c1 = cc[x];
   float xi_u = c1 > c0 ? (r2 - c0) / (c1 - c0) : 0.5f;
@@ -1069,29 +1109,30 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(const De
   __shared__ uint32_t s_ring[SORT ? SHADE_WAVES : 1][PTC_MATERIAL_CLASSES][SORT ? SHADE_RING : 1];
   __shared__ float s_marg[SHADE_LDS_ENV_ROWS];                   // the environment's row cdf and its guide, when the map is at most this high
   __shared__ uint16_t s_marg_guide[PTC_ENV_GUIDE + 2];
-  const DevScene& sc = *scp;
+  const DevScene& dsc = *scp;
+  const GScene sc = global_view(dsc);
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
   const bool lds_lights = sc.n_lights <= SHADE_LDS_LIGHTS, lds_mats = sc.n_mats <= SHADE_LDS_MATS;
   if (lds_lights) {
-    for (uint32_t i = threadIdx.x; i < sc.n_lights * 5u; i += SHADE_BLOCK) s_light[i] = sc.lights[i];
-    for (uint32_t i = threadIdx.x; i < sc.n_lights; i += SHADE_BLOCK) s_cdf[i] = sc.cdf[i];
+    for (uint32_t i = threadIdx.x; i < sc.n_lights * 5u; i += SHADE_BLOCK) s_light[i] = dsc.lights[i];
+    for (uint32_t i = threadIdx.x; i < sc.n_lights; i += SHADE_BLOCK) s_cdf[i] = dsc.cdf[i];
   }
   if (lds_mats)
-    for (uint32_t i = threadIdx.x; i < sc.n_mats * 4u; i += SHADE_BLOCK) s_mat[i] = sc.mats[i];
+    for (uint32_t i = threadIdx.x; i < sc.n_mats * 4u; i += SHADE_BLOCK) s_mat[i] = dsc.mats[i];
   const bool lds_marg = sc.env_ok != 0 && sc.env_h <= SHADE_LDS_ENV_ROWS;
   if (lds_marg) {
-    for (uint32_t i = threadIdx.x; i < (uint32_t)sc.env_h; i += SHADE_BLOCK) s_marg[i] = sc.env_marg[i];
-    for (uint32_t i = threadIdx.x; i <= PTC_ENV_GUIDE; i += SHADE_BLOCK) s_marg_guide[i] = sc.env_marg_guide[i];
+    for (uint32_t i = threadIdx.x; i < (uint32_t)sc.env_h; i += SHADE_BLOCK) s_marg[i] = dsc.env_marg[i];
+    for (uint32_t i = threadIdx.x; i <= PTC_ENV_GUIDE; i += SHADE_BLOCK) s_marg_guide[i] = dsc.env_marg_guide[i];
   }
   __syncthreads();
-  const float* env_marg = lds_marg ? s_marg : sc.env_marg;
-  const uint16_t* env_marg_guide = lds_marg ? s_marg_guide : sc.env_marg_guide;
+  const Dual<float> env_marg = {(AS_LDS const float*)s_marg, (AS_GLOBAL const float*)dsc.env_marg, lds_marg};
+  const Dual<uint16_t> env_marg_guide = {(AS_LDS const uint16_t*)s_marg_guide, (AS_GLOBAL const uint16_t*)dsc.env_marg_guide, lds_marg};
   const uint32_t seg = blockIdx.x * SHADE_WAVES + wave;
   if (seg >= q.n_seg) return;
-  const float4* lights = lds_lights ? s_light : sc.lights;
-  const float* cdf = lds_lights ? s_cdf : sc.cdf;
-  const float4* mats = lds_mats ? s_mat : sc.mats;
+  const Dual<fx4> lights = {(AS_LDS const fx4*)s_light, (AS_GLOBAL const fx4*)dsc.lights, lds_lights};
+  const Dual<float> cdf = {(AS_LDS const float*)s_cdf, (AS_GLOBAL const float*)dsc.cdf, lds_lights};
+  const Dual<fx4> mats = {(AS_LDS const fx4*)s_mat, (AS_GLOBAL const fx4*)dsc.mats, lds_mats};
   // light-kind selection probabilities for NEE: environment vs emissive triangles
   const bool has_env = sc.env_w > 0, env_nee = has_env && sc.env_ok != 0;
   const float p_env = env_nee ? (sc.n_lights > 0u ? 0.5f : 1.0f) : 0.0f, p_area = 1.0f - p_env;
@@ -1197,8 +1238,19 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(const De
       } else {
       const uint32_t prim = (uint32_t)__float_as_int(H.y) & ((1u << HIT_CLASS_SHIFT) - 1u);
       // ---- P5 surface reconstruction from the primitive's shading record (five 16-byte loads) ----
-      const float4* rec = sc.shade + (size_t)prim * sc.shade_stride;
-      const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4];
+      const size_t rec = (size_t)prim * sc.shade_stride;
+      const float4 r0 = ld4(sc.shade, rec), r1 = ld4(sc.shade, rec + 1), r2 = ld4(sc.shade, rec + 2), r3 = ld4(sc.shade, rec + 3), r4 = ld4(sc.shade, rec + 4);
+      // a textured class (the hit word says so): the record's other six units leave with the first five, not one round trip later behind the material id
+      const bool tex_cls = ((uint32_t)__float_as_int(H.y) >> HIT_CLASS_SHIFT) >= 2u;
+      float4 x0, x1, x2, x3, x4, x5;
+      x0 = x1 = x2 = x3 = x4 = x5 = make_float4(0, 0, 0, 0);
+      if (tex_cls) { x0 = ld4(sc.shade, rec + 5); x1 = ld4(sc.shade, rec + 6); x2 = ld4(sc.shade, rec + 7); x3 = ld4(sc.shade, rec + 8); x4 = ld4(sc.shade, rec + 9); x5 = ld4(sc.shade, rec + 10); }
+      // P7's environment sample depends on the path's random numbers only: its chain of dependent loads (guide, column cdf) runs while the record gather is in flight
+      const uint32_t rb = b + 1u;
+      bool use_env = false;
+      if ((int)b < fr.max_bounces && env_nee) use_env = sc.n_lights == 0u || rng_f(key, rb, 7) < p_env;
+      v3 wi_env = V3(0, 0, 0);
+      if (use_env) wi_env = env_sample(sc, env_marg, env_marg_guide, rng_f(key, rb, 1), rng_f(key, rb, 2));
       SSTAMP_LOADS(t_load);
       const v3 Pa = V3(r0.x, r0.y, r0.z), Pb = V3(r1.x, r1.y, r1.z), Pc = V3(r2.x, r2.y, r2.z);
       const v3 Na = V3(r2.w, r3.x, r3.y), Nb = V3(r3.z, r3.w, r4.x), Nc = V3(r4.y, r4.z, r4.w);
@@ -1208,12 +1260,12 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(const De
       const v3 ni = V3(pt_fma(Nc.x, hv, pt_fma(Nb.x, hu, Na.x * hw)), pt_fma(Nc.y, hv, pt_fma(Nb.y, hu, Na.y * hw)), pt_fma(Nc.z, hv, pt_fma(Nb.z, hu, Na.z * hw)));
       v3 ns = normalize3(ni);
       const int mat = __float_as_int(r0.w);
-      const float4 M0 = mats[mat * 4 + 0], M1 = mats[mat * 4 + 1], M2 = mats[mat * 4 + 2];
+      const float4 M0 = ld4(mats, (size_t)(mat * 4 + 0)), M1 = ld4(mats, (size_t)(mat * 4 + 1)), M2 = ld4(mats, (size_t)(mat * 4 + 2));
       float base_c[4] = {M0.x, M0.y, M0.z, M2.x};
       float metallic = M0.w, roughness = M1.w;
       const bool lambert = metallic == 0.0f && roughness >= 1.0f && __float_as_int(M2.w) < 0;
       if (__float_as_int(M2.y) >= 0 || __float_as_int(M2.z) >= 0 || __float_as_int(M2.w) >= 0)
-        apply_textures(sc, rec + 5, hu, hv, hw, M2, __float_as_int(mats[mat * 4 + 3].x), ni, base_c, metallic, roughness, ns);
+        apply_textures(sc, x0, x1, x2, x3, x4, x5, hu, hv, hw, M2, __float_as_int(ld4(mats, (size_t)(mat * 4 + 3)).x), ni, base_c, metallic, roughness, ns);
       const v3 wo = -d;
       const bool front = dot3(ng, wo) > 0.0f;
       if (dot3(ns, ng) < 0.0f) ns = -ns;
@@ -1222,7 +1274,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(const De
       // ---- emission (one-sided), MIS against next-event estimation ----
       const int li = __float_as_int(r1.w);
       if (li >= 0 && front) {
-        const float4 l0 = lights[li * 5 + 0], l1 = lights[li * 5 + 1], l4 = lights[li * 5 + 4];
+        const float4 l0 = ld4(lights, (size_t)(li * 5 + 0)), l1 = ld4(lights, (size_t)(li * 5 + 1)), l4 = ld4(lights, (size_t)(li * 5 + 4));
         float wgt = 1.0f;
         if (b > 0u) {
           const float cosl = dot3(ng, wo);
@@ -1240,13 +1292,9 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(const De
         const v3 wol = V3(dot3(tx, wo), dot3(ty, wo), dot3(ns, wo));
         const float ps = spec_prob(bs, fmax2(wol.z, 1e-4f));
         const v3 porg = vfma(ng, sc.ray_eps, P);
-        const uint32_t rb = b + 1u;
         // ---- P7 next-event estimation: one light sample per bounce, environment or emissive triangle ----
-        bool use_env = false;
-        if (env_nee) use_env = sc.n_lights == 0u || rng_f(key, rb, 7) < p_env;
         if (use_env) {
-          const float r1 = rng_f(key, rb, 1), r2 = rng_f(key, rb, 2);
-          const v3 wi = env_sample(sc, env_marg, env_marg_guide, r1, r2);
+          const v3 wi = wi_env;
           const v3 wil = V3(dot3(tx, wi), dot3(ty, wi), dot3(ns, wi));
           if (wil.z > 0.0f && dot3(ng, wi) > 0.0f) {
             v3 Le; float pe; env_lookup(sc, wi, Le, pe);
@@ -1265,7 +1313,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(const De
         } else if (sc.n_lights > 0u) {
           const float u0 = rng_f(key, rb, 0), r1 = rng_f(key, rb, 1), r2 = rng_f(key, rb, 2);
           const uint32_t lo = cdf_search(cdf, sc.n_lights, u0);
-          const float4 l0 = lights[lo * 5 + 0], l1 = lights[lo * 5 + 1], l2 = lights[lo * 5 + 2], l3 = lights[lo * 5 + 3], l4 = lights[lo * 5 + 4];
+          const float4 l0 = ld4(lights, (size_t)(lo * 5 + 0)), l1 = ld4(lights, (size_t)(lo * 5 + 1)), l2 = ld4(lights, (size_t)(lo * 5 + 2)), l3 = ld4(lights, (size_t)(lo * 5 + 3)), l4 = ld4(lights, (size_t)(lo * 5 + 4));
           const float su = pt_sqrt(r1);
           const float bu = su * (1.0f - r2), bv = su * r2;
           const v3 y = vfma(V3(l2.x, l2.y, l2.z), bv, vfma(V3(l1.x, l1.y, l1.z), bu, V3(l0.x, l0.y, l0.z)));
@@ -1403,7 +1451,7 @@ __global__ __launch_bounds__(256) void k_shade_raster(DevScene sc, DevCamera cam
     float base[4] = {M0.x, M0.y, M0.z, M2.x};
     float metallic = M0.w, roughness = M1.w;
     if (__float_as_int(M2.y) >= 0 || __float_as_int(M2.z) >= 0 || __float_as_int(M2.w) >= 0)
-      apply_textures(sc, rec + 5, hu, hv, hw, M2, __float_as_int(sc.mats[mat * 4 + 3].x), ni, base, metallic, roughness, N);
+      apply_textures(sc, rec[5], rec[6], rec[7], rec[8], rec[9], rec[10], hu, hv, hw, M2, __float_as_int(sc.mats[mat * 4 + 3].x), ni, base, metallic, roughness, N);
     if (GBUF16) {
       P = V3(round_f16(P.x), round_f16(P.y), round_f16(P.z));
       N = V3(round_f16(N.x), round_f16(N.y), round_f16(N.z));

@@ -732,7 +732,9 @@ std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vec
     order.push_back({-1, 0}); wide.push_back(w); child_base.push_back(1); block_order.push_back(0);
   } else {
     build_split_tree(tbox, ord, radix, bvh_builder == 1);
+    lap("  binary tree");
     compute_radix_boxes();
+    lap("  binary boxes");
     // cost tables, bottom-up: radix nodes are numbered parents-first, so descending index order is a valid post-order
     dp.assign(radix.size(), Dp());
     for (size_t idx = radix.size(); idx-- > 0;) {
@@ -756,6 +758,7 @@ std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vec
         if (dist[i] < d.c[i - 1]) { d.c[i] = dist[i]; d.same[i] = 0; } else { d.c[i] = d.c[i - 1]; d.same[i] = 1; }
       }
     }
+    lap("  collapse cost tables");
     auto number = [&](int32_t r, uint32_t depth) {
       order.push_back({r, depth});
       wide.push_back(expand(r));
