@@ -460,10 +460,11 @@ ptc_ctx* ptc_create(int device_id) {
   c->cfg.n_cu = prop.multiProcessorCount;
   c->cfg.trace_blocks_per_cu = 4;
   c->cfg.stack_lds = 6;
-  {   // segments of a queue = waves of k_shade's grid.  16 per CU are resident at 4 waves per SIMD; 32 (two rounds, the tail of one under the
-      // start of the next) is 3 % faster, 64 the same, 8 (two waves per SIMD) only 7 % slower and 4 62 %: k_shade runs at the rate of the CUs'
-      // memory path, not at the latency of its loads (profiles/r03_shade_variants.txt)
-    int per_cu = 32;
+  {   // segments of a queue = waves of k_shade's grid; a CU holds 16 of them at a time (4 waves per SIMD).  Whole multiples of 16 only: 8 / 12 / 20 / 24 leave a
+      // partial round and cost 4-20 %.  With the round-3b kernel (global instead of FLAT gathers) 16 / 32 / 48 / 64 per CU give k_shade 0.1296 / 0.1296 / 0.1245 / 0.1236 s
+      // per 6 steps on the atrium and 0.1768 / 0.1973 / 0.1902 / 0.1851 on the textured atrium (profiles/r03_shade_segments.txt): four short rounds beat two,
+      // one round is best where every segment costs the same and worst where they do not.  64 = PTC_MAX_SEGMENTS / 256 CUs.
+    int per_cu = 64;
     if (const char* s = std::getenv("PTC_SEGMENTS_PER_CU")) { int v = std::atoi(s); if (v >= 1 && v <= 64) per_cu = v; }
     uint32_t n = (uint32_t)(c->cfg.n_cu * per_cu);
     c->cfg.shade_waves = (int)(n > PTC_MAX_SEGMENTS ? PTC_MAX_SEGMENTS : n);
