@@ -913,11 +913,12 @@ PT_DEV uint4 ldu4(const uint4* p, size_t i) { return p[i]; }
 PT_DEV uint4 ldu4(AS_GLOBAL const ux4* p, size_t i) { const ux4 v = p[i]; return make_uint4(v.x, v.y, v.z, v.w); }
 PT_DEV int4 ldi4(const int4* p, size_t i) { return p[i]; }
 PT_DEV int4 ldi4(AS_GLOBAL const ix4* p, size_t i) { const ix4 v = p[i]; return make_int4(v.x, v.y, v.z, v.w); }
-template <class T> struct Dual {
+// LDS_ONLY: the table is known (on the host, at launch) to lie in LDS — no fallback pointer to keep in scalar registers, no uniform branch per access
+template <class T, bool LDS_ONLY> struct Dual {
   AS_LDS const T* l; AS_GLOBAL const T* g; bool in_lds;
-  PT_DEV T operator[](size_t i) const { return in_lds ? l[i] : g[i]; }
+  PT_DEV T operator[](size_t i) const { return (LDS_ONLY || in_lds) ? l[i] : g[i]; }
 };
-PT_DEV float4 ld4(const Dual<fx4>& p, size_t i) { const fx4 v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
+template <bool LDS_ONLY> PT_DEV float4 ld4(const Dual<fx4, LDS_ONLY>& p, size_t i) { const fx4 v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
 struct GScene {
   AS_GLOBAL const fx4* shade; uint32_t shade_stride;
   AS_GLOBAL const uint32_t* texels; AS_GLOBAL const ix4* tex_info; AS_GLOBAL const ux4* set_texels; AS_GLOBAL const ix4* set_info; int tex_linear;
@@ -1100,7 +1101,7 @@ PT_DEV void wave_lds_sync() {     // LDS written by some lanes of this wave is r
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-template <bool SORT>
+template <bool SORT, bool TABLES_LDS>
 __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(const DevScene* __restrict__ scp, DevFrame fr, DevQueues q, int qi, uint32_t b) {
   // small scene-wide tables staged once per block: emitter records + power cdf, materials
   __shared__ float4 s_light[SHADE_LDS_LIGHTS * 5];
@@ -1113,26 +1114,26 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(const De
   const GScene sc = global_view(dsc);
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
-  const bool lds_lights = sc.n_lights <= SHADE_LDS_LIGHTS, lds_mats = sc.n_mats <= SHADE_LDS_MATS;
+  const bool lds_lights = TABLES_LDS || sc.n_lights <= SHADE_LDS_LIGHTS, lds_mats = TABLES_LDS || sc.n_mats <= SHADE_LDS_MATS;
   if (lds_lights) {
     for (uint32_t i = threadIdx.x; i < sc.n_lights * 5u; i += SHADE_BLOCK) s_light[i] = dsc.lights[i];
     for (uint32_t i = threadIdx.x; i < sc.n_lights; i += SHADE_BLOCK) s_cdf[i] = dsc.cdf[i];
   }
   if (lds_mats)
     for (uint32_t i = threadIdx.x; i < sc.n_mats * 4u; i += SHADE_BLOCK) s_mat[i] = dsc.mats[i];
-  const bool lds_marg = sc.env_ok != 0 && sc.env_h <= SHADE_LDS_ENV_ROWS;
+  const bool lds_marg = sc.env_ok != 0 && (TABLES_LDS || sc.env_h <= SHADE_LDS_ENV_ROWS);
   if (lds_marg) {
     for (uint32_t i = threadIdx.x; i < (uint32_t)sc.env_h; i += SHADE_BLOCK) s_marg[i] = dsc.env_marg[i];
     for (uint32_t i = threadIdx.x; i <= PTC_ENV_GUIDE; i += SHADE_BLOCK) s_marg_guide[i] = dsc.env_marg_guide[i];
   }
   __syncthreads();
-  const Dual<float> env_marg = {(AS_LDS const float*)s_marg, (AS_GLOBAL const float*)dsc.env_marg, lds_marg};
-  const Dual<uint16_t> env_marg_guide = {(AS_LDS const uint16_t*)s_marg_guide, (AS_GLOBAL const uint16_t*)dsc.env_marg_guide, lds_marg};
+  const Dual<float, TABLES_LDS> env_marg = {(AS_LDS const float*)s_marg, (AS_GLOBAL const float*)dsc.env_marg, lds_marg};
+  const Dual<uint16_t, TABLES_LDS> env_marg_guide = {(AS_LDS const uint16_t*)s_marg_guide, (AS_GLOBAL const uint16_t*)dsc.env_marg_guide, lds_marg};
   const uint32_t seg = blockIdx.x * SHADE_WAVES + wave;
   if (seg >= q.n_seg) return;
-  const Dual<fx4> lights = {(AS_LDS const fx4*)s_light, (AS_GLOBAL const fx4*)dsc.lights, lds_lights};
-  const Dual<float> cdf = {(AS_LDS const float*)s_cdf, (AS_GLOBAL const float*)dsc.cdf, lds_lights};
-  const Dual<fx4> mats = {(AS_LDS const fx4*)s_mat, (AS_GLOBAL const fx4*)dsc.mats, lds_mats};
+  const Dual<fx4, TABLES_LDS> lights = {(AS_LDS const fx4*)s_light, (AS_GLOBAL const fx4*)dsc.lights, lds_lights};
+  const Dual<float, TABLES_LDS> cdf = {(AS_LDS const float*)s_cdf, (AS_GLOBAL const float*)dsc.cdf, lds_lights};
+  const Dual<fx4, TABLES_LDS> mats = {(AS_LDS const fx4*)s_mat, (AS_GLOBAL const fx4*)dsc.mats, lds_mats};
   // light-kind selection probabilities for NEE: environment vs emissive triangles
   const bool has_env = sc.env_w > 0, env_nee = has_env && sc.env_ok != 0;
   const float p_env = env_nee ? (sc.n_lights > 0u ? 0.5f : 1.0f) : 0.0f, p_area = 1.0f - p_env;
@@ -1567,8 +1568,13 @@ void pt_launch_trace_any(hipStream_t s, const LaunchCfg& cfg, const DevScene& sc
 
 void pt_launch_shade(hipStream_t s, const LaunchCfg& cfg, const DevScene* sc, const DevFrame& fr, const DevQueues& q, int qi, uint32_t bounce) {
   const dim3 grid((q.n_seg + SHADE_WAVES - 1u) / SHADE_WAVES);      // one wave per segment
-  if (cfg.shade_sort) hipLaunchKernelGGL(k_shade<true>, grid, dim3(SHADE_BLOCK), 0, s, sc, fr, q, qi, bounce);
-  else hipLaunchKernelGGL(k_shade<false>, grid, dim3(SHADE_BLOCK), 0, s, sc, fr, q, qi, bounce);
+  if (cfg.shade_sort) hipLaunchKernelGGL((k_shade<true, false>), grid, dim3(SHADE_BLOCK), 0, s, sc, fr, q, qi, bounce);
+  else if (cfg.shade_tables_lds) hipLaunchKernelGGL((k_shade<false, true>), grid, dim3(SHADE_BLOCK), 0, s, sc, fr, q, qi, bounce);
+  else hipLaunchKernelGGL((k_shade<false, false>), grid, dim3(SHADE_BLOCK), 0, s, sc, fr, q, qi, bounce);
+}
+// the emitter, material and environment-row tables of this scene all fit k_shade's LDS copies
+bool pt_shade_tables_fit(const DevScene& sc) {
+  return sc.n_lights <= SHADE_LDS_LIGHTS && sc.n_mats <= SHADE_LDS_MATS && (!sc.env_ok || sc.env_h <= (int)SHADE_LDS_ENV_ROWS);
 }
 void pt_launch_accumulate(hipStream_t s, const DevFrame& fr, const DevQueues& q, float4* accum, uint32_t n_samples) {
   hipLaunchKernelGGL(k_accumulate, dim3((fr.n_owned + 255u) / 256u), dim3(256), 0, s, fr, (const float4*)q.lpath, accum, n_samples);

@@ -822,6 +822,7 @@ int commit_upload(ptc_ctx* c, std::chrono::steady_clock::time_point t0) {
   for (int k = 0; k < 3; ++k) { d.grid_lo[k] = B.grid_lo[k]; d.grid_step[k] = B.grid_step[k]; }
   c->dsc = d;
   { int rc2 = configure_launch(c); if (rc2) { free_all(c->scene_allocs); return rc2; } }
+  c->cfg.shade_tables_lds = pt_shade_tables_fit(c->dsc) ? 1 : 0;
   for (int l = 0; l < c->n_lanes; ++l) {
     const DevScene ds = lane_scene(c, l);
     HIP_TRY(c, hipMemcpy(c->lanes[(size_t)l].d_scene, &ds, sizeof ds, hipMemcpyHostToDevice));

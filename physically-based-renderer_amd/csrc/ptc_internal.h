@@ -108,7 +108,8 @@ inline void ptc_seg_layout(uint32_t n, uint32_t max_seg, uint32_t& n_seg, uint32
 inline size_t ptc_seg_slots(uint32_t cap, uint32_t max_seg) { return (size_t)cap + 64u * (size_t)max_seg + 64u; }
 
 struct LaunchCfg { int n_cu; int trace_blocks_per_cu; int stack_lds; /* stack entries kept in LDS per lane */ int shade_waves; /* waves of k_shade's grid = upper bound of n_seg */
-                   int shade_sort; /* 1: k_shade sorts its slots by material class before shading (PTC_SHADE_SORT=1); 0: it takes them in queue order */ };
+                   int shade_sort; /* 1: k_shade sorts its slots by material class before shading (PTC_SHADE_SORT=1); 0: it takes them in queue order */
+                   int shade_tables_lds; /* 1: the scene's emitter / material / environment-row tables all fit k_shade's LDS copies (pt_shade_tables_fit): the variant without global fallbacks runs */ };
 
 // ---- kernel launchers (pt_kernels.hip) ------------------------------------------------------------
 int pt_trace_block_threads();   // threads per block of the trace kernels (compile-time constant of pt_kernels.hip)
@@ -117,6 +118,7 @@ int pt_trace_blocks_per_cu(size_t lds_bytes);                    // resident tra
 void pt_launch_set_counts(hipStream_t, const LaunchCfg&, const DevQueues&, uint32_t n_rays, uint32_t n_shadow);   // identity layout: ray i at slot i
 void pt_launch_scan(hipStream_t, const LaunchCfg&, const DevQueues&, int qi_next);   // after k_shade: chunk prefixes of the rays it wrote to ray[qi_next] and of its shadow rays
 int pt_shade_block_threads();
+bool pt_shade_tables_fit(const DevScene&);
 void pt_launch_raygen(hipStream_t, const DevCamera&, const DevFrame&, const DevQueues&, uint32_t first_sample, uint32_t n_samples, bool raster);
 void pt_launch_trace_closest(hipStream_t, const LaunchCfg&, const DevScene&, const DevQueues&, int qi, bool cull);
 void pt_launch_shade(hipStream_t, const LaunchCfg&, const DevScene* scene_on_device, const DevFrame&, const DevQueues&, int qi, uint32_t bounce);   // every ray of a wavefront launch is at the same bounce

@@ -599,6 +599,34 @@ def test_scene_dynamics_refit(gpu, ora, name, kw, w, h, spp, seed, mb):
     print(f"{name}: commit {pt.stats()['seconds_commit'] * 1e3:.1f} ms, refit {pt.stats()['seconds_refit'] * 1e3:.1f} ms")
 
 
+def test_tables_beyond_the_lds_copies(gpu, ora):
+    """k_shade keeps the emitter table, the material table and the environment's row cdf in LDS when they fit (64 emitters, 64 materials, 2048
+    rows) and runs a variant without any fallback then; a scene beyond every one of the three limits takes the other variant, which reads them from
+    global memory: 90 materials, 120 emitters, an environment 2100 rows high — image and counters are the oracle's, and so are those of the same
+    scene cut down to fit."""
+    sc = gpu.scene
+    rng = np.random.default_rng(5)
+    base = gpu.scenes.cornell_box()
+    for n_quads, env_rows in ((90, 2100), (12, 16)):
+        mats, meshes, insts = [], [], []
+        for k in range(n_quads):
+            em = (float(rng.uniform(1, 6)),) * 3 if k % 3 == 0 or k >= 30 and k < 60 else (0.0, 0.0, 0.0)
+            mats.append(sc.Material((*[float(x) for x in rng.uniform(0.2, 0.9, 3)], 1.0), float(rng.choice([0.0, 1.0])), float(rng.uniform(0.1, 1.0)), em))
+            c = rng.uniform(-0.9, 0.9, 3); e1 = rng.normal(0, 0.25, 3); e2 = rng.normal(0, 0.25, 3)
+            v, i = gpu.scenes._quad(tuple(c), tuple(c + e1), tuple(c + e1 + e2), tuple(c + e2))
+            meshes.append(sc.MeshDesc(v, i, k))
+            insts.append(sc.InstanceDesc(k, (0.0, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0), (1.0, 1.0, 1.0)))
+        env = rng.uniform(0.0, 1.5, (env_rows, 4, 3)).astype(np.float32)
+        d = sc.SceneDesc(mats, meshes, insts, base.camera, f"tables{n_quads}", env=env)
+        pt, o = _pair(gpu, ora, d)
+        assert pt.stats()["n_emitters"] > 64 or n_quads < 64
+        g, c = pt.render(40, 40, 3, seed=9, max_bounces=4), o.render(40, 40, 3, seed=9, max_bounces=4)
+        assert _bits_equal(g, c), f"{n_quads} quads: {int((g != c).any(-1).sum())} pixels differ"
+        sg, so = pt.stats(), o.stats()
+        for key in COUNTERS:
+            assert sg[key] == so[key], (n_quads, key)
+
+
 def _single_triangle_scene(gpu):
     sc = gpu.scene
     d = gpu.scenes.cornell_box()
