@@ -36,8 +36,9 @@
 #define TRACE_NODE_MIN 40         // leave the node loop when fewer lanes than this are still at interior nodes
 #endif                            // while others wait at a leaf (keeps both phases well populated; 24: -6 %, 32: -1.5 %, 48: -3 %, 56: -18 %)
 #ifndef SHADE_BLOCK
-#define SHADE_BLOCK 512           // a block only shares the staged light / material tables; its waves never synchronise after that (64: +19 % kernel time,
-                                  // 128: +1 %, 256: 0, 512: -2 %: profiles/r03_shade_variants.txt)
+#define SHADE_BLOCK 256           // a block only shares the staged light / material / row-cdf tables; its waves never synchronise after that.  Round 3a (FLAT gathers): 64: +19 % kernel
+                                  // time, 128: +1 %, 256: 0, 512: -2 %; round 3b (global gathers, 64 segments per CU): 128 / 256 / 512 = 0.1208 / 0.1180 / 0.1178 s per 6 steps on the atrium,
+                                  // 0.1677 / 0.1662 / 0.1831 on the textured atrium — smaller blocks free their wave slots sooner (profiles/r03_shade_segments.txt)
 #endif
 #ifndef SHADE_MIN_WAVES
 #define SHADE_MIN_WAVES 4         // <= 128 VGPRs: four independent waves per SIMD
