@@ -1117,15 +1117,15 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(const De
   const uint32_t wave = threadIdx.x >> 6;
   const bool lds_lights = TABLES_LDS || sc.n_lights <= SHADE_LDS_LIGHTS, lds_mats = TABLES_LDS || sc.n_mats <= SHADE_LDS_MATS;
   if (lds_lights) {
-    for (uint32_t i = threadIdx.x; i < sc.n_lights * 5u; i += SHADE_BLOCK) s_light[i] = dsc.lights[i];
-    for (uint32_t i = threadIdx.x; i < sc.n_lights; i += SHADE_BLOCK) s_cdf[i] = dsc.cdf[i];
+    for (uint32_t i = threadIdx.x; i < sc.n_lights * 5u; i += SHADE_BLOCK) s_light[i] = ld4((AS_GLOBAL const fx4*)dsc.lights, i);
+    for (uint32_t i = threadIdx.x; i < sc.n_lights; i += SHADE_BLOCK) s_cdf[i] = ((AS_GLOBAL const float*)dsc.cdf)[i];
   }
   if (lds_mats)
-    for (uint32_t i = threadIdx.x; i < sc.n_mats * 4u; i += SHADE_BLOCK) s_mat[i] = dsc.mats[i];
+    for (uint32_t i = threadIdx.x; i < sc.n_mats * 4u; i += SHADE_BLOCK) s_mat[i] = ld4((AS_GLOBAL const fx4*)dsc.mats, i);
   const bool lds_marg = sc.env_ok != 0 && (TABLES_LDS || sc.env_h <= SHADE_LDS_ENV_ROWS);
   if (lds_marg) {
-    for (uint32_t i = threadIdx.x; i < (uint32_t)sc.env_h; i += SHADE_BLOCK) s_marg[i] = dsc.env_marg[i];
-    for (uint32_t i = threadIdx.x; i <= PTC_ENV_GUIDE; i += SHADE_BLOCK) s_marg_guide[i] = dsc.env_marg_guide[i];
+    for (uint32_t i = threadIdx.x; i < (uint32_t)sc.env_h; i += SHADE_BLOCK) s_marg[i] = ((AS_GLOBAL const float*)dsc.env_marg)[i];
+    for (uint32_t i = threadIdx.x; i <= PTC_ENV_GUIDE; i += SHADE_BLOCK) s_marg_guide[i] = ((AS_GLOBAL const uint16_t*)dsc.env_marg_guide)[i];
   }
   __syncthreads();
   const Dual<float, TABLES_LDS> env_marg = {(AS_LDS const float*)s_marg, (AS_GLOBAL const float*)dsc.env_marg, lds_marg};
