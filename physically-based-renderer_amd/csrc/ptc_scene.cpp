@@ -256,83 +256,172 @@ inline uint32_t morton_last_left(const std::vector<uint64_t>& codes, uint32_t lo
   return (uint32_t)(first_set - codes.begin()) - 1u;
 }
 
-void build_split_tree(const std::vector<Box>& tbox, std::vector<uint32_t>& ord, std::vector<SplitNode>& out, bool lbvh) {
-  const uint32_t n = (uint32_t)ord.size();
-  std::vector<float> ctr((size_t)n * 3);
-  for (uint32_t p = 0; p < n; ++p)
-    for (int k = 0; k < 3; ++k) ctr[(size_t)p * 3 + k] = 0.5f * (tbox[p].lo[k] + tbox[p].hi[k]);
-  std::vector<uint64_t> codes;
-  if (lbvh) codes = sort_by_morton_code(ctr, ord);
-  std::vector<uint32_t> right_part(n);
-  out.clear();
-  out.reserve(n);
+// Where the range [lo, hi] of `ord` is cut: returns the last position of the left part (the SAH path partitions ord[lo..hi] in place, stably; `scratch`
+// holds hi - lo + 1 entries).  A pure function of the range's content, so disjoint ranges can be cut by different threads.
+uint32_t split_range(const std::vector<Box>& tbox, const std::vector<float>& ctr, const std::vector<uint64_t>& codes, bool lbvh, std::vector<uint32_t>& ord,
+                     uint32_t* scratch, uint32_t lo, uint32_t hi) {
+  if (lbvh) return morton_last_left(codes, lo, hi);
+  struct Bin { Box box; uint32_t count; };
+  float cl[3], ch[3];
+  for (int k = 0; k < 3; ++k) { cl[k] = std::numeric_limits<float>::infinity(); ch[k] = -cl[k]; }
+  for (uint32_t i = lo; i <= hi; ++i) {
+    const float* c = &ctr[(size_t)ord[i] * 3];
+    for (int k = 0; k < 3; ++k) { cl[k] = cl[k] < c[k] ? cl[k] : c[k]; ch[k] = ch[k] > c[k] ? ch[k] : c[k]; }
+  }
+  float best_cost = std::numeric_limits<float>::infinity();
+  int best_axis = -1, best_bin = 0;
+  for (int k = 0; k < 3; ++k) {
+    if (!(ch[k] > cl[k])) continue;
+    const float scale = (float)kSahBins / (ch[k] - cl[k]);
+    Bin bins[kSahBins];
+    for (Bin& bn : bins) { bn.box = empty_box(); bn.count = 0; }
+    for (uint32_t i = lo; i <= hi; ++i) {
+      const uint32_t p = ord[i];
+      int j = (int)((ctr[(size_t)p * 3 + k] - cl[k]) * scale);
+      j = j > kSahBins - 1 ? kSahBins - 1 : j;
+      bins[j].count++;
+      grow(bins[j].box, tbox[p]);
+    }
+    float suffix_area[kSahBins];
+    uint32_t suffix_count[kSahBins];
+    Box acc = empty_box();
+    uint32_t cnt = 0;
+    for (int j = kSahBins - 1; j >= 1; --j) {
+      cnt += bins[j].count;
+      grow(acc, bins[j].box);
+      suffix_count[j] = cnt;
+      suffix_area[j] = cnt ? box_half_area(acc) : 0.0f;
+    }
+    acc = empty_box();
+    cnt = 0;
+    for (int j = 0; j + 1 < kSahBins; ++j) {
+      cnt += bins[j].count;
+      grow(acc, bins[j].box);
+      if (cnt == 0 || suffix_count[j + 1] == 0) continue;
+      const float cost = box_half_area(acc) * (float)cnt + suffix_area[j + 1] * (float)suffix_count[j + 1];
+      if (cost < best_cost) { best_cost = cost; best_axis = k; best_bin = j; }
+    }
+  }
+  if (best_axis < 0) return lo + (hi - lo) / 2;
+  const float scale = (float)kSahBins / (ch[best_axis] - cl[best_axis]);
+  uint32_t nl = 0, nr = 0;
+  for (uint32_t i = lo; i <= hi; ++i) {
+    const uint32_t p = ord[i];
+    int j = (int)((ctr[(size_t)p * 3 + best_axis] - cl[best_axis]) * scale);
+    j = j > kSahBins - 1 ? kSahBins - 1 : j;
+    if (j <= best_bin) ord[lo + nl++] = p; else scratch[nr++] = p;
+  }
+  std::copy(scratch, scratch + nr, ord.begin() + lo + nl);
+  return lo + nl - 1;
+}
+
+// split_range for a LARGE range, its passes spread over the pool (the top of the tree is a handful of such ranges and everything else waits for them).
+// Same cut: bounds and bins are minima / maxima / counts — the same in any order (only the sign of a zero can differ, and areas and comparisons do not read
+// it) — and the partition keeps the order of both parts (per-chunk counts, exclusive prefix, every chunk writes its own stretch of the scratch buffer).
+uint32_t split_range_parallel(const std::vector<Box>& tbox, const std::vector<float>& ctr, std::vector<uint32_t>& ord, uint32_t* scratch, uint32_t lo, uint32_t hi) {
+  struct Bin { Box box; uint32_t count; };
+  const size_t n = (size_t)hi - lo + 1;
+  const size_t nc = std::min<size_t>((size_t)HostPool::get().size() * 2, n / 8192);
+  const size_t per = (n + nc - 1) / nc;
+  auto chunk = [&](size_t c, size_t& a, size_t& b) { a = lo + c * per; b = std::min<size_t>(a + per, (size_t)hi + 1); };
+  struct Bounds { float cl[3], ch[3]; };
+  std::vector<Bounds> cb(nc);
+  HostPool::get().run(nc, [&](size_t c) {
+    size_t a, b; chunk(c, a, b);
+    Bounds r;
+    for (int k = 0; k < 3; ++k) { r.cl[k] = std::numeric_limits<float>::infinity(); r.ch[k] = -r.cl[k]; }
+    for (size_t i = a; i < b; ++i) {
+      const float* q = &ctr[(size_t)ord[i] * 3];
+      for (int k = 0; k < 3; ++k) { r.cl[k] = r.cl[k] < q[k] ? r.cl[k] : q[k]; r.ch[k] = r.ch[k] > q[k] ? r.ch[k] : q[k]; }
+    }
+    cb[c] = r;
+  });
+  float cl[3], ch[3];
+  for (int k = 0; k < 3; ++k) { cl[k] = std::numeric_limits<float>::infinity(); ch[k] = -cl[k]; }
+  for (const Bounds& r : cb)
+    for (int k = 0; k < 3; ++k) { cl[k] = cl[k] < r.cl[k] ? cl[k] : r.cl[k]; ch[k] = ch[k] > r.ch[k] ? ch[k] : r.ch[k]; }
+  float scale[3];
+  for (int k = 0; k < 3; ++k) scale[k] = ch[k] > cl[k] ? (float)kSahBins / (ch[k] - cl[k]) : 0.0f;
+  std::vector<Bin> part(nc * 3 * kSahBins);
+  HostPool::get().run(nc, [&](size_t c) {
+    size_t a, b; chunk(c, a, b);
+    Bin* bins = &part[c * 3 * kSahBins];
+    for (int j = 0; j < 3 * kSahBins; ++j) { bins[j].box = empty_box(); bins[j].count = 0; }
+    for (size_t i = a; i < b; ++i) {
+      const uint32_t p = ord[i];
+      for (int k = 0; k < 3; ++k) {
+        if (!(ch[k] > cl[k])) continue;
+        int j = (int)((ctr[(size_t)p * 3 + (size_t)k] - cl[k]) * scale[k]);
+        j = j > kSahBins - 1 ? kSahBins - 1 : j;
+        bins[k * kSahBins + j].count++;
+        grow(bins[k * kSahBins + j].box, tbox[p]);
+      }
+    }
+  });
+  float best_cost = std::numeric_limits<float>::infinity();
+  int best_axis = -1, best_bin = 0;
+  for (int k = 0; k < 3; ++k) {
+    if (!(ch[k] > cl[k])) continue;
+    Bin bins[kSahBins];
+    for (Bin& bn : bins) { bn.box = empty_box(); bn.count = 0; }
+    for (size_t c = 0; c < nc; ++c)
+      for (int j = 0; j < kSahBins; ++j) { const Bin& o = part[(c * 3 + (size_t)k) * kSahBins + (size_t)j]; if (o.count) { bins[j].count += o.count; grow(bins[j].box, o.box); } }
+    float suffix_area[kSahBins];
+    uint32_t suffix_count[kSahBins];
+    Box acc = empty_box();
+    uint32_t cnt = 0;
+    for (int j = kSahBins - 1; j >= 1; --j) {
+      cnt += bins[j].count;
+      grow(acc, bins[j].box);
+      suffix_count[j] = cnt;
+      suffix_area[j] = cnt ? box_half_area(acc) : 0.0f;
+    }
+    acc = empty_box();
+    cnt = 0;
+    for (int j = 0; j + 1 < kSahBins; ++j) {
+      cnt += bins[j].count;
+      grow(acc, bins[j].box);
+      if (cnt == 0 || suffix_count[j + 1] == 0) continue;
+      const float cost = box_half_area(acc) * (float)cnt + suffix_area[j + 1] * (float)suffix_count[j + 1];
+      if (cost < best_cost) { best_cost = cost; best_axis = k; best_bin = j; }
+    }
+  }
+  if (best_axis < 0) return lo + (hi - lo) / 2;
+  const float sc = scale[best_axis], c0 = cl[best_axis];
+  auto goes_left = [&](uint32_t p) { int j = (int)((ctr[(size_t)p * 3 + (size_t)best_axis] - c0) * sc); j = j > kSahBins - 1 ? kSahBins - 1 : j; return j <= best_bin; };
+  std::vector<uint32_t> nleft(nc + 1, 0u);
+  HostPool::get().run(nc, [&](size_t c) {
+    size_t a, b; chunk(c, a, b);
+    uint32_t k = 0;
+    for (size_t i = a; i < b; ++i) k += goes_left(ord[i]) ? 1u : 0u;
+    nleft[c + 1] = k;
+  });
+  for (size_t c = 0; c < nc; ++c) nleft[c + 1] += nleft[c];
+  const uint32_t nl = nleft[nc];
+  HostPool::get().run(nc, [&](size_t c) {
+    size_t a, b; chunk(c, a, b);
+    uint32_t l = nleft[c], r = nl + (uint32_t)(a - lo) - nleft[c];
+    for (size_t i = a; i < b; ++i) { const uint32_t p = ord[i]; if (goes_left(p)) scratch[l++] = p; else scratch[r++] = p; }
+  });
+  HostPool::get().run(nc, [&](size_t c) {
+    size_t a, b; chunk(c, a, b);
+    std::copy(scratch + (a - lo), scratch + (b - lo), ord.begin() + (ptrdiff_t)a);
+  });
+  return lo + nl - 1;
+}
+
+// The subtree over [lo, hi] (hi > lo), appended to `out` with indices local to `out` (its root is out[first]); parents before children.
+void build_subtree(const std::vector<Box>& tbox, const std::vector<float>& ctr, const std::vector<uint64_t>& codes, bool lbvh, std::vector<uint32_t>& ord,
+                   uint32_t* scratch, uint32_t lo0, uint32_t hi0, std::vector<SplitNode>& out) {
   struct Work { uint32_t lo, hi; int32_t node; };
   std::vector<Work> todo;
-  out.push_back({0, n - 1, 0, 0});
-  todo.push_back({0, n - 1, 0});
-  struct Bin { Box box; uint32_t count; };
+  const int32_t root = (int32_t)out.size();
+  out.push_back({lo0, hi0, 0, 0});
+  todo.push_back({lo0, hi0, root});
   while (!todo.empty()) {
     const Work w = todo.back();
     todo.pop_back();
-    uint32_t last_left;   // last position of the left part
-    if (lbvh) {
-      last_left = morton_last_left(codes, w.lo, w.hi);
-    } else {
-      float cl[3], ch[3];
-      for (int k = 0; k < 3; ++k) { cl[k] = std::numeric_limits<float>::infinity(); ch[k] = -cl[k]; }
-      for (uint32_t i = w.lo; i <= w.hi; ++i) {
-        const float* c = &ctr[(size_t)ord[i] * 3];
-        for (int k = 0; k < 3; ++k) { cl[k] = cl[k] < c[k] ? cl[k] : c[k]; ch[k] = ch[k] > c[k] ? ch[k] : c[k]; }
-      }
-      float best_cost = std::numeric_limits<float>::infinity();
-      int best_axis = -1, best_bin = 0;
-      for (int k = 0; k < 3; ++k) {
-        if (!(ch[k] > cl[k])) continue;
-        const float scale = (float)kSahBins / (ch[k] - cl[k]);
-        Bin bins[kSahBins];
-        for (Bin& b : bins) { b.box = empty_box(); b.count = 0; }
-        for (uint32_t i = w.lo; i <= w.hi; ++i) {
-          const uint32_t p = ord[i];
-          int j = (int)((ctr[(size_t)p * 3 + k] - cl[k]) * scale);
-          j = j > kSahBins - 1 ? kSahBins - 1 : j;
-          bins[j].count++;
-          grow(bins[j].box, tbox[p]);
-        }
-        float suffix_area[kSahBins];
-        uint32_t suffix_count[kSahBins];
-        Box acc = empty_box();
-        uint32_t cnt = 0;
-        for (int j = kSahBins - 1; j >= 1; --j) {
-          cnt += bins[j].count;
-          grow(acc, bins[j].box);
-          suffix_count[j] = cnt;
-          suffix_area[j] = cnt ? box_half_area(acc) : 0.0f;
-        }
-        acc = empty_box();
-        cnt = 0;
-        for (int j = 0; j + 1 < kSahBins; ++j) {
-          cnt += bins[j].count;
-          grow(acc, bins[j].box);
-          if (cnt == 0 || suffix_count[j + 1] == 0) continue;
-          const float cost = box_half_area(acc) * (float)cnt + suffix_area[j + 1] * (float)suffix_count[j + 1];
-          if (cost < best_cost) { best_cost = cost; best_axis = k; best_bin = j; }
-        }
-      }
-      if (best_axis < 0) {
-        last_left = w.lo + (w.hi - w.lo) / 2;
-      } else {
-        const float scale = (float)kSahBins / (ch[best_axis] - cl[best_axis]);
-        uint32_t nl = 0, nr = 0;
-        for (uint32_t i = w.lo; i <= w.hi; ++i) {
-          const uint32_t p = ord[i];
-          int j = (int)((ctr[(size_t)p * 3 + best_axis] - cl[best_axis]) * scale);
-          j = j > kSahBins - 1 ? kSahBins - 1 : j;
-          if (j <= best_bin) ord[w.lo + nl++] = p; else right_part[nr++] = p;
-        }
-        std::copy(right_part.begin(), right_part.begin() + nr, ord.begin() + w.lo + nl);
-        last_left = w.lo + nl - 1;
-      }
-    }
+    const uint32_t last_left = split_range(tbox, ctr, codes, lbvh, ord, scratch, w.lo, w.hi);
     auto link = [&](uint32_t lo, uint32_t hi) -> int32_t {
       if (lo == hi) return ~(int32_t)lo;
       const int32_t id = (int32_t)out.size();
@@ -343,6 +432,65 @@ void build_split_tree(const std::vector<Box>& tbox, std::vector<uint32_t>& ord, 
     const int32_t l = link(w.lo, last_left), r = link(last_left + 1, w.hi);
     out[(size_t)w.node].left = l;
     out[(size_t)w.node].right = r;
+  }
+}
+
+// The binary tree over all triangles.  The top is cut on the calling thread until the ranges are small (the cuts of a large range are what
+// everything below waits for, and they are few); every range at or below that size is a task for the pool, built into its own array and
+// appended afterwards — its nodes after all nodes of the top, so that parents still come before children in `out` (what the bottom-up passes rely
+// on).  The tree is the one the sequential build makes: a cut depends on its range alone.
+void build_split_tree(const std::vector<Box>& tbox, std::vector<uint32_t>& ord, std::vector<SplitNode>& out, bool lbvh, std::vector<uint32_t>& sub_first) {
+  const uint32_t n = (uint32_t)ord.size();
+  sub_first.clear();
+  std::vector<float> ctr((size_t)n * 3);
+  parallel_for(n, 16384, [&](size_t p0, size_t p1) {
+    for (size_t p = p0; p < p1; ++p)
+      for (int k = 0; k < 3; ++k) ctr[p * 3 + (size_t)k] = 0.5f * (tbox[p].lo[k] + tbox[p].hi[k]);
+  });
+  std::vector<uint64_t> codes;
+  if (lbvh) codes = sort_by_morton_code(ctr, ord);
+  std::vector<uint32_t> right_part(n);
+  out.clear();
+  out.reserve(n);
+  const unsigned threads = HostPool::get().size();
+  const uint32_t task_size = threads > 1 ? std::max<uint32_t>(2048u, n / (threads * 8u)) : n;      // one thread: the whole tree is "the top"
+  struct Work { uint32_t lo, hi; int32_t node; };
+  struct Task { uint32_t lo, hi; int32_t parent; bool right; };
+  std::vector<Work> todo;
+  std::vector<Task> tasks;
+  out.push_back({0, n - 1, 0, 0});
+  todo.push_back({0, n - 1, 0});
+  while (!todo.empty()) {
+    const Work w = todo.back();
+    todo.pop_back();
+    const uint32_t last_left = (!lbvh && threads > 1 && w.hi - w.lo + 1u >= 32768u) ? split_range_parallel(tbox, ctr, ord, right_part.data() + w.lo, w.lo, w.hi)
+                                                                                     : split_range(tbox, ctr, codes, lbvh, ord, right_part.data() + w.lo, w.lo, w.hi);
+    auto link = [&](uint32_t lo, uint32_t hi, bool right) -> int32_t {
+      if (lo == hi) return ~(int32_t)lo;
+      if (threads > 1 && hi - lo + 1u <= task_size) { tasks.push_back({lo, hi, w.node, right}); return 0; }     // patched when the task's nodes have their places
+      const int32_t id = (int32_t)out.size();
+      out.push_back({lo, hi, 0, 0});
+      todo.push_back({lo, hi, id});
+      return id;
+    };
+    const int32_t l = link(w.lo, last_left, false), r = link(last_left + 1, w.hi, true);
+    out[(size_t)w.node].left = l;
+    out[(size_t)w.node].right = r;
+  }
+  if (tasks.empty()) return;
+  sub_first.push_back((uint32_t)out.size());           // node indices [sub_first[t], sub_first[t + 1]) are task t's subtree; below sub_first[0]: the top
+  std::vector<std::vector<SplitNode>> sub(tasks.size());
+  parallel_for(tasks.size(), 1, [&](size_t t0, size_t t1) {
+    for (size_t t = t0; t < t1; ++t) {
+      sub[t].reserve(tasks[t].hi - tasks[t].lo);
+      build_subtree(tbox, ctr, codes, lbvh, ord, right_part.data() + tasks[t].lo, tasks[t].lo, tasks[t].hi, sub[t]);
+    }
+  });
+  for (size_t t = 0; t < tasks.size(); ++t) {
+    const int32_t base = (int32_t)out.size();
+    for (const SplitNode& nd : sub[t]) out.push_back({nd.lo, nd.hi, nd.left >= 0 ? nd.left + base : nd.left, nd.right >= 0 ? nd.right + base : nd.right});
+    (tasks[t].right ? out[(size_t)tasks[t].parent].right : out[(size_t)tasks[t].parent].left) = base;
+    sub_first.push_back((uint32_t)out.size());
   }
 }
 
@@ -364,6 +512,7 @@ struct Topology {
   uint64_t next_unit = 4;
   uint32_t n_tri_records = 0, toplet_budget = 0;
   std::vector<float> wbt;            // world bitangent per vertex
+  std::vector<uint32_t> sub_first;   // binary-tree node ranges of the subtrees the build handed to the pool (bottom-up passes run over them in parallel, then over the top)
 };
 
 }  // namespace
@@ -706,14 +855,28 @@ std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vec
   std::vector<uint32_t>& child_base = topo->child_base; // node index → index of its first interior child
   std::vector<uint32_t>& block_order = topo->block_order; // node indices in the order their children blocks were allocated
   // boxes of all radix nodes, bottom-up (iterative post-order)
-  auto compute_radix_boxes = [&]() {      // radix nodes are numbered parents-first: descending index order is a valid post-order
+  // radix nodes are numbered parents-first, so descending index order is a valid post-order; the subtrees the build handed to the pool are disjoint index
+  // ranges behind the top's, so they go first, in parallel, and the top last
+  auto bottom_up = [&](auto&& visit) {
+    const std::vector<uint32_t>& sf = topo->sub_first;
+    size_t top_end = radix.size();
+    if (sf.size() >= 2 && sf.back() == radix.size()) {
+      parallel_for(sf.size() - 1, 1, [&](size_t t0, size_t t1) {
+        for (size_t t = t0; t < t1; ++t)
+          for (size_t idx = sf[t + 1]; idx-- > sf[t];) visit(idx);
+      });
+      top_end = sf[0];
+    }
+    for (size_t idx = top_end; idx-- > 0;) visit(idx);
+  };
+  auto compute_radix_boxes = [&]() {
     radix_box.assign(radix.size(), empty_box());
-    for (size_t idx = radix.size(); idx-- > 0;) {
+    bottom_up([&](size_t idx) {
       const SplitNode& r = radix[idx];
       Box b = r.left < 0 ? tbox[ord[(size_t)~r.left]] : radix_box[(size_t)r.left];
       grow(b, r.right < 0 ? tbox[ord[(size_t)~r.right]] : radix_box[(size_t)r.right]);
       radix_box[idx] = b;
-    }
+    });
   };
   if (refit) {    // same tree, same slots: only the boxes of the children follow the moved triangles
     compute_radix_boxes();
@@ -731,13 +894,13 @@ std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vec
     const Wide w = make_wide(kid, 2);
     order.push_back({-1, 0}); wide.push_back(w); child_base.push_back(1); block_order.push_back(0);
   } else {
-    build_split_tree(tbox, ord, radix, bvh_builder == 1);
+    build_split_tree(tbox, ord, radix, bvh_builder == 1, topo->sub_first);
     lap("  binary tree");
     compute_radix_boxes();
     lap("  binary boxes");
     // cost tables, bottom-up: radix nodes are numbered parents-first, so descending index order is a valid post-order
     dp.assign(radix.size(), Dp());
-    for (size_t idx = radix.size(); idx-- > 0;) {
+    bottom_up([&](size_t idx) {
       const SplitNode& r = radix[idx];
       Dp& d = dp[idx];
       float dist[9];
@@ -757,7 +920,7 @@ std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vec
       for (int i = 2; i <= 7; ++i) {
         if (dist[i] < d.c[i - 1]) { d.c[i] = dist[i]; d.same[i] = 0; } else { d.c[i] = d.c[i - 1]; d.same[i] = 1; }
       }
-    }
+    });
     lap("  collapse cost tables");
     auto number = [&](int32_t r, uint32_t depth) {
       order.push_back({r, depth});
