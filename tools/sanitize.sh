@@ -3,6 +3,7 @@
 #   1. libptc.so / libptc_gltf.so with the HOST code instrumented (clang, -fno-gpu-sanitize), CPU test-suite on it
 #   2. the oracle instrumented (gcc), its CPU tests
 #   3. mutation fuzzers of the PNG decoder and the glTF loader (tools/fuzz_png.py, tools/fuzz_gltf.py)
+#   4. ThreadSanitizer on the host thread pool: commit (parallel tree build, SAH and LBVH) + host refits of the full-size atrium on a description-only context
 # Everything is built into build_san/ (git-ignored).  usage: tools/sanitize.sh [fuzz-iterations]
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd); OUT=$ROOT/build_san; mkdir -p $OUT
@@ -38,4 +39,22 @@ g++ $SAN -std=c++17 -fPIC -I$ROOT/include -I$PKG/host -shared -o $OUT/libgltf_fu
 LD_PRELOAD=$GA ASAN_OPTIONS=detect_leaks=0 python $ROOT/tools/fuzz_png.py $OUT $((ITERS * 10))
 LD_PRELOAD=$GA ASAN_OPTIONS=detect_leaks=0 python $ROOT/tools/fuzz_jpeg.py $OUT $((ITERS * 10))
 LD_PRELOAD=$GA ASAN_OPTIONS=detect_leaks=0 python $ROOT/tools/fuzz_gltf.py $OUT $ITERS
+mkdir -p $OUT/tsan
+( cd $PKG/csrc && /opt/rocm/bin/hipcc -fsanitize=thread -fno-gpu-sanitize -g -O1 --offload-arch=gfx950 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
+    -fno-fast-math -I$ROOT/include -shared -o $OUT/tsan/libptc.so pt_kernels.hip pt_refit.hip ptc_api.cpp ptc_scene.cpp )
+cat > $OUT/tsan/run.py <<P
+import sys, copy
+sys.path.insert(0, '$ROOT'); sys.path.insert(0, '$PKG')
+from pbr_amd import ptc
+ptc.LIB_PATH = '$OUT/tsan/libptc.so'
+import pbr_amd as pbr
+for name, kw, b in (("atrium", {}, "sah"), ("atrium", {"scale": 0.3}, "lbvh"), ("textured_objects", {}, "sah")):
+    d = copy.deepcopy(pbr.scenes.by_name(name, **kw)); d.bvh_builder = b
+    pt = pbr.PathTracer(pbr.DEVICE_NONE).load_scene(d)
+    pt.scene_refit(); pt.scene_refit()
+    assert pt.refit_host_parts()["levels_ok"] == 1
+print("tsan: host pool clean")
+P
+TS=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.tsan-x86_64.so)
+LD_PRELOAD=$TS TSAN_OPTIONS="halt_on_error=1 exitcode=66" python $OUT/tsan/run.py
 echo "sanitize: all clean"
