@@ -64,8 +64,8 @@ PT_DEV unsigned long long wave_sum(unsigned long long v) {
 // bookkeeping kernels: per-segment counts -> chunk prefix (ptc_internal.h, "SEGMENTED queues")
 //
 // One block of SCAN_BLOCK threads.  The trace kernels hand out rays in chunks that never straddle a segment; the chunk size follows the
-// queue's length: TRACE_CHUNK rays when the queue is long, down to one wave's worth when it is short (about one static and one dynamic
-// chunk per wave of the persistent grid), so that a small late-bounce queue still spreads over the whole chip.
+// queue's length: TRACE_CHUNK rays when the queue is long, down to one wave's worth when it is short (about one chunk, a static one, per wave of
+// the persistent grid), so that a small late-bounce queue still spreads over the whole chip.
 #define SCAN_BLOCK 1024
 PT_DEV uint32_t block_sum_1024(uint32_t v, uint32_t* s_w /*[16]*/, uint32_t& excl) {   // returns the block total, excl = exclusive prefix of this thread
   const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
@@ -88,8 +88,11 @@ PT_DEV void scan_chunks(const uint32_t* seg, uint32_t n_seg, uint32_t* pre, uint
   uint32_t mine = 0, dummy;
   for (uint32_t sg = s0; sg < s1; ++sg) mine += seg[sg];
   const uint32_t total = block_sum_1024(mine, s_w, dummy);
-  const uint32_t per_wave = total / (trace_waves * 2u);
-  const uint32_t chunk = per_wave >= TRACE_CHUNK ? TRACE_CHUNK : (per_wave < 64u ? 64u : (per_wave & ~63u));
+  // One chunk per wave of the grid when the queue is short (all of them static: no atomic at all), TRACE_CHUNK rays when it is long.  Round 3a aimed at two
+  // chunks per wave, which for a queue of 2 M rays means 32 k chunks of 64: the one work counter serves ~88 atomics per us, the kernel needs a chunk every
+  // 6 ns — such launches ran at the speed of the counter (0.8 ms instead of 0.2).  From 256 rays per chunk on the counter is not the limit.
+  const uint32_t per_wave = (total + trace_waves - 1u) / trace_waves;
+  const uint32_t chunk = per_wave >= TRACE_CHUNK ? TRACE_CHUNK : (per_wave <= 64u ? 64u : ((per_wave + 63u) & ~63u));
   uint32_t chunks = 0;
   for (uint32_t sg = s0; sg < s1; ++sg) chunks += (seg[sg] + chunk - 1u) / chunk;
   uint32_t run;

@@ -114,6 +114,7 @@ struct ptc_ctx {
   DevRefit drf{};
   bool host_stale = false;          // the device refitted in place: built's vertex-dependent arrays are those of an earlier state until refresh_host_copy
   bool last_refit_on_device = false;
+  int trace_rays_per_lane = 8;      // PTC_TRACE_RAYS_PER_LANE: rays per lane of the trace kernels' grid a batch should offer before the grid is made smaller (run_batch)
   std::vector<float> xf_live;       // instance transforms of the last refit the device completed (a refused one re-flattens its scratch vertices from these)
   // lanes: lane 0 is the context's primary stream (resolve, tonemap, conversions, the reduce)
   std::vector<Lane> lanes;
@@ -130,6 +131,9 @@ struct ptc_ctx {
   uint32_t pending = 0;             // samples accepted by frame_add_samples and not yet issued (deferred batching)
   uint32_t per_batch = 1;           // samples of one full batch = max_batch_paths / owned pixels / lanes
   DevBuf<uint32_t> owned;
+  bool owned_key_valid = false;     // c->owned holds the list for (owned_w, owned_h, owned_rank, owned_count)
+  int owned_w = 0, owned_h = 0, owned_rank = 0, owned_count = 0;
+  uint32_t owned_n = 0;
   DevBuf<float4> accum, radiance;
   DevBuf<uint32_t> ldr;
   DevBuf<uint2> half;               // RGBA16F copy of the radiance buffer
@@ -311,25 +315,35 @@ int run_batch(ptc_ctx* c, int l, uint32_t first_sample, uint32_t n_samples) {
   hipStream_t st = ln.stream;
   const DevQueues q = batch_queues(c, l, n_paths);
   const DevScene sc = lane_scene(c, l);
+  // The persistent grid of the trace kernels follows the batch: a wave wants several refills' worth of rays (c->trace_rays_per_lane per lane) to run in its
+  // steady state; 8192 waves over the 2 M rays of a 1080p x 1 spp frame are 4 refills each, most of the launch is start-up and drain (0.8 ms for bounce 0,
+  // 0.25 ms for the last bounces: tools/viewer_loop.py).  Batches of the benchmark's size keep the full grid.
+  LaunchCfg cfg = c->cfg;
+  {
+    const uint64_t per_block = (uint64_t)pt_trace_block_threads() * (uint64_t)c->trace_rays_per_lane;
+    uint64_t per_cu = ((uint64_t)n_paths + per_block * (uint64_t)cfg.n_cu - 1u) / (per_block * (uint64_t)cfg.n_cu);
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu < (uint64_t)cfg.trace_blocks_per_cu) cfg.trace_blocks_per_cu = (int)per_cu;
+  }
   if (c->spans.size() > kMaxSpans) {      // bounded event pool: harvest what has completed; if the host runs far ahead of
     collect_times(c, false);              // the device, wait for the oldest batch (back-pressure) instead of growing
     if (c->spans.size() > kMaxSpans) { (void)hipEventSynchronize(c->spans[c->spans.size() - kMaxSpans].b); collect_times(c, false); }
   }
   ScopedSpan whole(c, st, 3);
-  pt_launch_set_counts(st, c->cfg, q, n_paths, 0);
+  pt_launch_set_counts(st, cfg, q, n_paths, 0);
   if (is_raster(c->integrator)) {
     pt_launch_raygen(st, c->cam, c->fr, q, 0, 1, true);
-    { ScopedSpan t(c, st, 0); pt_launch_trace_closest(st, c->cfg, sc, q, 0, true); c->stats.launches_trace_closest++; }
+    { ScopedSpan t(c, st, 0); pt_launch_trace_closest(st, cfg, sc, q, 0, true); c->stats.launches_trace_closest++; }
     pt_launch_shade_raster(st, sc, c->cam, c->fr, q, c->accum.p, c->integrator == PTC_INTEGRATOR_RASTER_GBUFFER16);
   } else {
     pt_launch_raygen(st, c->cam, c->fr, q, first_sample, n_samples, false);
     for (int b = 0; b <= c->fr.max_bounces; ++b) {
-      { ScopedSpan t(c, st, 0); pt_launch_trace_closest(st, c->cfg, sc, q, b & 1, false); c->stats.launches_trace_closest++; }
-      { ScopedSpan t(c, st, 2); pt_launch_shade(st, c->cfg, ln.d_scene, c->fr, q, b & 1, (uint32_t)b); }
+      { ScopedSpan t(c, st, 0); pt_launch_trace_closest(st, cfg, sc, q, b & 1, false); c->stats.launches_trace_closest++; }
+      { ScopedSpan t(c, st, 2); pt_launch_shade(st, cfg, ln.d_scene, c->fr, q, b & 1, (uint32_t)b); }
       if (b == c->fr.max_bounces) break;                         // the last bounce's shade produces no rays
-      pt_launch_scan(st, c->cfg, q, (b + 1) & 1);
+      pt_launch_scan(st, cfg, q, (b + 1) & 1);
       if (sc.n_lights > 0 || sc.env_ok) {
-        ScopedSpan t(c, st, 1); pt_launch_trace_any(st, c->cfg, sc, q, nullptr); c->stats.launches_trace_any++;
+        ScopedSpan t(c, st, 1); pt_launch_trace_any(st, cfg, sc, q, nullptr); c->stats.launches_trace_any++;
       }
     }
     // sample-order accumulation: wait for the previous batch's accumulate (it ran on the previous lane)
@@ -473,6 +487,7 @@ ptc_ctx* ptc_create(int device_id) {
   // waves buy nothing, while the sort reads the hit words a second time and turns the ray loads into gathers: -11 % k_shade time without it on the
   // atrium, -5 % on the textured atrium (profiles/r03_shade_variants.txt).  Output compaction (ballot + mbcnt prefix) is always on.
   if (const char* s = std::getenv("PTC_SHADE_SORT")) c->cfg.shade_sort = std::atoi(s) != 0 ? 1 : 0;
+  if (const char* s = std::getenv("PTC_TRACE_RAYS_PER_LANE")) { int v = std::atoi(s); if (v >= 1 && v <= 4096) c->trace_rays_per_lane = v; }
   if (const char* s = std::getenv("PTC_NODELETS")) c->toplet_budget = (uint32_t)std::strtoul(s, nullptr, 10);
   if (const char* s = std::getenv("PTC_BATCH_PATHS")) { size_t v = std::strtoull(s, nullptr, 10); if (v >= 1024) c->max_batch_paths = v; }
   if (const char* s = std::getenv("PTC_TIMING")) c->timing = std::atoi(s) != 0;
@@ -858,18 +873,26 @@ int ptc_frame_begin(ptc_ctx* c, int w, int h, int spp_total, uint64_t seed, int 
   if (integrator != PTC_INTEGRATOR_PATH && !is_raster(integrator)) return fail(c, PTC_E_ARG, "frame_begin: unknown integrator");
   if (tile_count < 1 || tile_rank < 0 || tile_rank >= tile_count) return fail(c, PTC_E_ARG, "frame_begin: bad tile rank/count");
   { int rs = sync_all_lanes(c); if (rs) return rs; }
-  std::vector<uint32_t> owned;
-  ptc_owned_pixels(w, h, tile_rank, tile_count, owned);
   int rc;
-  if ((rc = ensure_buf(c, c->owned, owned.size()))) return rc;
-  if (!owned.empty()) HIP_TRY(c, hipMemcpy(c->owned.p, owned.data(), owned.size() * 4, hipMemcpyHostToDevice));
-  if ((rc = ensure_buf(c, c->accum, owned.size()))) return rc;
+  // the list of owned pixels (tile-Morton order) depends on the image size and the tile assignment only: a viewer that renders frame after frame at
+  // one size keeps the list it has on the device (2 M entries: 10 ms of host time and an 8 MB upload per frame otherwise — tools/viewer_loop.py)
+  if (!(c->owned_key_valid && c->owned_w == w && c->owned_h == h && c->owned_rank == tile_rank && c->owned_count == tile_count && c->owned.p)) {
+    std::vector<uint32_t> owned;
+    ptc_owned_pixels(w, h, tile_rank, tile_count, owned);
+    c->owned_key_valid = false;
+    if ((rc = ensure_buf(c, c->owned, owned.size()))) return rc;
+    if (!owned.empty()) HIP_TRY(c, hipMemcpy(c->owned.p, owned.data(), owned.size() * 4, hipMemcpyHostToDevice));
+    c->owned_n = (uint32_t)owned.size();
+    c->owned_w = w; c->owned_h = h; c->owned_rank = tile_rank; c->owned_count = tile_count; c->owned_key_valid = true;
+  }
+  const size_t n_owned = c->owned_n;
+  if ((rc = ensure_buf(c, c->accum, n_owned))) return rc;
   if ((rc = ensure_buf(c, c->radiance, (size_t)w * h))) return rc;
   hipStream_t s0 = c->lanes[0].stream;
-  HIP_TRY(c, hipMemsetAsync(c->accum.p, 0, (owned.size() ? owned.size() : 1) * sizeof(float4), s0));
+  HIP_TRY(c, hipMemsetAsync(c->accum.p, 0, (n_owned ? n_owned : 1) * sizeof(float4), s0));
   HIP_TRY(c, hipMemsetAsync(c->radiance.p, 0, (size_t)w * h * sizeof(float4), s0));
   c->rad_w = w; c->rad_h = h;
-  c->fr.w = w; c->fr.h = h; c->fr.max_bounces = max_bounces; c->fr.n_owned = (uint32_t)owned.size(); c->fr.owned = c->owned.p;
+  c->fr.w = w; c->fr.h = h; c->fr.max_bounces = max_bounces; c->fr.n_owned = (uint32_t)n_owned; c->fr.owned = c->owned.p;
   {  // seed_hash = pcg(seed_lo + pcg(seed_hi)), same hash as pt_device.h
     auto pcg = [](uint32_t v) { uint32_t s = v * 747796405u + 2891336453u; uint32_t x = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u; return (x >> 22) ^ x; };
     c->fr.seed_hash = pcg((uint32_t)seed + pcg((uint32_t)(seed >> 32)));
@@ -880,7 +903,11 @@ int ptc_frame_begin(ptc_ctx* c, int w, int h, int spp_total, uint64_t seed, int 
   // batches actually issued (frame_add_samples), not by spp_total: a progressive loop adding one sample at a time needs
   // queues for one sample per pixel only.
   size_t batch_paths = c->max_batch_paths;
-  {   // no more than 60 % of the device memory that is free now (plus what the lanes' queues already hold) goes into queues
+  size_t min_cap = (size_t)-1;
+  for (const auto& ln : c->lanes) min_cap = ln.q.cap < min_cap ? ln.q.cap : min_cap;
+  if (n_owned && (uint64_t)n_owned * (uint64_t)c->spp_total * (uint64_t)c->n_lanes <= (uint64_t)min_cap && min_cap <= batch_paths) {
+    batch_paths = min_cap * (size_t)c->n_lanes;     // the whole frame fits the queues every lane already has: nothing will be allocated, no need to ask how much memory is free
+  } else {   // no more than 60 % of the device memory that is free now (plus what the lanes' queues already hold) goes into queues
     size_t free_b = 0, total_b = 0, held = 0;
     for (const auto& ln : c->lanes) held += (size_t)ln.q.cap * kQueueBytesPerPath;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -888,12 +915,12 @@ int ptc_frame_begin(ptc_ctx* c, int w, int h, int spp_total, uint64_t seed, int 
       if (fit < batch_paths) batch_paths = fit;
     }
   }
-  size_t per = owned.empty() ? 1 : batch_paths / owned.size() / (size_t)c->n_lanes;
+  size_t per = !n_owned ? 1 : batch_paths / n_owned / (size_t)c->n_lanes;
   if (per < 1) per = 1;
   if (per > 0x7fffffffu) per = 0x7fffffffu;
   {   // slot indices are 32 bits, and the segmented layout pads a batch by up to 64 slots per segment
     const uint64_t max_slots = 0xfffffff0ull - 64ull * (uint64_t)c->cfg.shade_waves - 64ull;
-    if (!owned.empty() && (uint64_t)owned.size() * per > max_slots) per = max_slots / owned.size();
+    if (n_owned && (uint64_t)n_owned * per > max_slots) per = max_slots / n_owned;
     if (per < 1) per = 1;
   }
   c->per_batch = (uint32_t)per;

@@ -96,10 +96,15 @@ enum { ST_SEGMENTS = 0, ST_SHADOW, ST_HITS, ST_NODES_C, ST_TRIS_C, ST_NODES_A, S
        // utilisation of a phase = lane-level count / (64 x wave-level count)
        ST_DIAG_NODE_ITERS, ST_DIAG_TRI_ITERS, ST_DIAG_LEAF_VISITS, ST_DIAG_ROUNDS, ST_DIAG_REFILLED, ST_N };
 
-// Segment layout of a batch of n slots over at most max_seg segments: n_seg = min(max_seg, ceil(n / 64)) (at least 1), seg_len =
+// Segment layout of a batch of n slots over at most max_seg segments: n_seg = min(max_seg, ceil(n / PTC_SEG_MIN_LEN)) (at least 1), seg_len =
 // ceil(n / n_seg) rounded up to a multiple of 64.  n_seg * seg_len <= ptc_seg_slots(n, max_seg).
+// A segment is at least one full trace chunk long (512 slots): with the 64 of round 3a a 1080p x 1 spp frame (2 M paths) was cut into 16384
+// segments of 128 slots, hence >= 16384 chunks of a few rays each at the later bounces — every refill of a trace wave then cost an atomic and a
+// search of the chunk prefix for a handful of rays, and EVERY trace launch of such a frame took 0.5-0.8 ms however few rays it had (11.5 ms per
+// frame, tools/viewer_loop.py); batches of the benchmark's size (535 M slots) are at max_seg either way.
+#define PTC_SEG_MIN_LEN 512u
 inline void ptc_seg_layout(uint32_t n, uint32_t max_seg, uint32_t& n_seg, uint32_t& seg_len) {
-  uint32_t s = (n + 63u) / 64u;
+  uint32_t s = (n + PTC_SEG_MIN_LEN - 1u) / PTC_SEG_MIN_LEN;
   if (s > max_seg) s = max_seg;
   if (s < 1u) s = 1u;
   const uint32_t per = (n + s - 1u) / s;
