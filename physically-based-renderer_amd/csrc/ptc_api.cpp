@@ -905,8 +905,9 @@ int ptc_frame_begin(ptc_ctx* c, int w, int h, int spp_total, uint64_t seed, int 
   size_t batch_paths = c->max_batch_paths;
   size_t min_cap = (size_t)-1;
   for (const auto& ln : c->lanes) min_cap = ln.q.cap < min_cap ? ln.q.cap : min_cap;
-  if (n_owned && (uint64_t)n_owned * (uint64_t)c->spp_total * (uint64_t)c->n_lanes <= (uint64_t)min_cap && min_cap <= batch_paths) {
-    batch_paths = min_cap * (size_t)c->n_lanes;     // the whole frame fits the queues every lane already has: nothing will be allocated, no need to ask how much memory is free
+  if (n_owned && (uint64_t)n_owned * (uint64_t)c->spp_total <= (uint64_t)min_cap) {
+    // the whole frame fits the queues every lane already has (frame_add_samples refuses more than spp_total): nothing will be allocated,
+    // no need to ask the driver how much memory is free (a call of 0.1-0.2 ms, every frame of a viewer's loop)
   } else {   // no more than 60 % of the device memory that is free now (plus what the lanes' queues already hold) goes into queues
     size_t free_b = 0, total_b = 0, held = 0;
     for (const auto& ln : c->lanes) held += (size_t)ln.q.cap * kQueueBytesPerPath;
