@@ -113,6 +113,29 @@ def test_batch_size_is_clamped_to_free_device_memory(gpu):
         del os.environ["PTC_BATCH_PATHS"]
 
 
+def test_owned_pixel_list_is_kept_only_while_it_is_valid(gpu):
+    """ptc_frame_begin keeps the device's list of owned pixels from frame to frame (a viewer renders one size over and over); a change of the image
+    size or of the tile assignment must replace it: a context taken through a sequence of sizes and tile ranks renders, every time, the bits of
+    a fresh context given that frame alone — and a 1-sample-per-call progressive frame in between is not disturbed either."""
+    d = gpu.scenes.by_name("cornell")
+    pt = gpu.PathTracer(0).load_scene(d)
+    def frame(p, w, h, rank, count, seed):
+        p.frame_begin(w, h, 3, seed=seed, max_bounces=4, tile_rank=rank, tile_count=count)
+        for _ in range(3):
+            p.frame_add_samples(1)
+        p.frame_resolve(); p.sync()
+        return p.read_radiance()
+    seq = [(48, 32, 0, 1, 5), (48, 32, 0, 1, 6), (48, 32, 1, 2, 6), (48, 32, 0, 2, 6), (32, 48, 0, 1, 6), (48, 32, 0, 1, 5), (96, 64, 2, 3, 7), (48, 32, 0, 1, 5)]
+    first = None
+    for w, h, rank, count, seed in seq:
+        got = frame(pt, w, h, rank, count, seed)
+        want = frame(gpu.PathTracer(0).load_scene(d), w, h, rank, count, seed)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (w, h, rank, count, seed)
+        if (w, h, rank, count, seed) == seq[0]:
+            first = got if first is None else first
+            assert np.array_equal(got.view(np.uint32), first.view(np.uint32))
+
+
 def test_small_calls_merge_into_full_batches(gpu, ora):
     """Deferred batching: samples added in small calls are issued as full wavefront batches (launches as wide as one
     big call's), a partial batch goes out at resolve; bits do not depend on how the samples were handed over."""
