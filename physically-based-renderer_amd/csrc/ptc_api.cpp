@@ -42,6 +42,10 @@ struct Lane {
   uint2* stack_ovf = nullptr;       // traversal-stack overflow slab (belongs to the committed scene)
   DevScene* d_scene = nullptr;      // this lane's DevScene in device memory (k_shade reads it through a pointer instead of ~200 B of kernel arguments)
   hipEvent_t acc_done = nullptr;    // "this lane's last accumulate finished"
+  // PTC_TRACE_OVERLAP=1: the shadow rays of bounce b are traced on a second stream beside the closest-hit launch of bounce b + 1
+  hipStream_t stream2 = nullptr;
+  uint2* stack_ovf2 = nullptr;      // the any-hit launches' own overflow slab (concurrent kernels must not share one)
+  std::vector<hipEvent_t> ev_scan, ev_any;
 };
 
 // ---- RCCL, loaded on first use (a renderer that never reduces does not need librccl at load time) -------------------
@@ -115,6 +119,11 @@ struct ptc_ctx {
   bool host_stale = false;          // the device refitted in place: built's vertex-dependent arrays are those of an earlier state until refresh_host_copy
   bool last_refit_on_device = false;
   int trace_rays_per_lane = 8;      // PTC_TRACE_RAYS_PER_LANE: rays per lane of the trace kernels' grid a batch should offer before the grid is made smaller (run_batch)
+  int trace_overlap = 1;            // PTC_TRACE_OVERLAP: the shadow rays of bounce b are traced on the lane's second stream beside the closest-hit launch of bounce b + 1 (they are
+                                    // independent; k_shade(b + 1) waits for both).  1 (default) = batches of up to 2^26 paths, whose launches do not keep the chip full for long:
+                                    // -5 % .. -17 % frame time from 16 spp down to 1 spp at 1080p (profiles/r03_viewer_loop.txt); 2 = every batch (+0.4 % at the benchmark's
+                                    // batch size, but the two kernels' launch durations then include each other: not the default, so that what bench.py and rocprofv3 time
+                                    // per kernel stays a kernel's own time); 0 = never
   std::vector<float> xf_live;       // instance transforms of the last refit the device completed (a refused one re-flattens its scratch vertices from these)
   // lanes: lane 0 is the context's primary stream (resolve, tonemap, conversions, the reduce)
   std::vector<Lane> lanes;
@@ -295,6 +304,12 @@ int configure_launch(ptc_ctx* c) {
     int rc = dev_alloc(c, c->scene_allocs, &pl, total_waves * ovf * 64);
     if (rc) return rc;
     ln.stack_ovf = pl;
+    ln.stack_ovf2 = nullptr;
+    if (c->trace_overlap) {
+      if ((rc = dev_alloc(c, c->scene_allocs, &pl, total_waves * ovf * 64))) return rc;
+      ln.stack_ovf2 = pl;
+      if (!ln.stream2 && hipStreamCreateWithFlags(&ln.stream2, hipStreamNonBlocking) != hipSuccess) return fail(c, PTC_E_DEVICE, "configure_launch: hipStreamCreate failed");
+    }
   }
   return PTC_OK;
 }
@@ -337,12 +352,29 @@ int run_batch(ptc_ctx* c, int l, uint32_t first_sample, uint32_t n_samples) {
     pt_launch_shade_raster(st, sc, c->cam, c->fr, q, c->accum.p, c->integrator == PTC_INTEGRATOR_RASTER_GBUFFER16);
   } else {
     pt_launch_raygen(st, c->cam, c->fr, q, first_sample, n_samples, false);
+    const bool shadows = sc.n_lights > 0 || sc.env_ok;
+    const bool small_batch = n_paths <= (1u << 26);
+    const bool overlap = (c->trace_overlap == 2 || (c->trace_overlap == 1 && small_batch)) && shadows && ln.stream2 && ln.stack_ovf2;
+    if (overlap) {
+      const size_t need = (size_t)c->fr.max_bounces + 1;
+      while (ln.ev_scan.size() < need) { hipEvent_t e = nullptr; HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); ln.ev_scan.push_back(e); }
+      while (ln.ev_any.size() < need) { hipEvent_t e = nullptr; HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); ln.ev_any.push_back(e); }
+    }
+    DevScene sc_any = sc;
+    if (overlap) sc_any.stack_ovf = ln.stack_ovf2;
     for (int b = 0; b <= c->fr.max_bounces; ++b) {
       { ScopedSpan t(c, st, 0); pt_launch_trace_closest(st, cfg, sc, q, b & 1, false); c->stats.launches_trace_closest++; }
+      // k_shade(b) overwrites the shadow queue any(b - 1) reads and adds to the path radiance it adds to
+      if (overlap && b > 0) HIP_TRY(c, hipStreamWaitEvent(st, ln.ev_any[(size_t)b - 1], 0));
       { ScopedSpan t(c, st, 2); pt_launch_shade(st, cfg, ln.d_scene, c->fr, q, b & 1, (uint32_t)b); }
       if (b == c->fr.max_bounces) break;                         // the last bounce's shade produces no rays
       pt_launch_scan(st, cfg, q, (b + 1) & 1);
-      if (sc.n_lights > 0 || sc.env_ok) {
+      if (overlap) {      // any(b) on the second stream, beside closest(b + 1)
+        HIP_TRY(c, hipEventRecord(ln.ev_scan[(size_t)b], st));
+        HIP_TRY(c, hipStreamWaitEvent(ln.stream2, ln.ev_scan[(size_t)b], 0));
+        { ScopedSpan t(c, ln.stream2, 1); pt_launch_trace_any(ln.stream2, cfg, sc_any, q, nullptr); c->stats.launches_trace_any++; }
+        HIP_TRY(c, hipEventRecord(ln.ev_any[(size_t)b], ln.stream2));
+      } else if (shadows) {
         ScopedSpan t(c, st, 1); pt_launch_trace_any(st, cfg, sc, q, nullptr); c->stats.launches_trace_any++;
       }
     }
@@ -488,6 +520,7 @@ ptc_ctx* ptc_create(int device_id) {
   // atrium, -5 % on the textured atrium (profiles/r03_shade_variants.txt).  Output compaction (ballot + mbcnt prefix) is always on.
   if (const char* s = std::getenv("PTC_SHADE_SORT")) c->cfg.shade_sort = std::atoi(s) != 0 ? 1 : 0;
   if (const char* s = std::getenv("PTC_TRACE_RAYS_PER_LANE")) { int v = std::atoi(s); if (v >= 1 && v <= 4096) c->trace_rays_per_lane = v; }
+  if (const char* s = std::getenv("PTC_TRACE_OVERLAP")) { int v = std::atoi(s); if (v >= 0 && v <= 2) c->trace_overlap = v; }
   if (const char* s = std::getenv("PTC_NODELETS")) c->toplet_budget = (uint32_t)std::strtoul(s, nullptr, 10);
   if (const char* s = std::getenv("PTC_BATCH_PATHS")) { size_t v = std::strtoull(s, nullptr, 10); if (v >= 1024) c->max_batch_paths = v; }
   if (const char* s = std::getenv("PTC_TIMING")) c->timing = std::atoi(s) != 0;
@@ -525,6 +558,9 @@ void ptc_destroy(ptc_ctx* c) {
     if (ln.q.seg_ray[0]) (void)hipFree(ln.q.seg_ray[0]);
     if (ln.d_scene) (void)hipFree(ln.d_scene);
     if (ln.stream) (void)hipStreamDestroy(ln.stream);
+    if (ln.stream2) (void)hipStreamDestroy(ln.stream2);
+    for (hipEvent_t e : ln.ev_scan) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ln.ev_any) (void)hipEventDestroy(e);
   }
   free_all(c->scene_allocs);
   c->owned.release(); c->accum.release(); c->radiance.release(); c->ldr.release(); c->half.release();
