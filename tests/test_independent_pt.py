@@ -16,14 +16,21 @@ def _independent_cornell(pbr, w, h, spp, max_bounces, seed):
 
 
 def _independent(d, w, h, spp, max_bounces, seed):
-    tris, alb, emi, met, rough = [], [], [], [], []
+    tris, alb, emi, met, rough, vattr, texid = [], [], [], [], [], [], []
     for inst in d.instances:                                            # identity transforms in this scene: positions are world positions
         m = d.meshes[inst.mesh]
         P = np.asarray(m.vertices["position"], np.float64)
         I = np.asarray(m.indices, np.int64).reshape(-1, 3)
         mat = d.materials[m.material]
+        Nv, Tv, UV = (np.asarray(m.vertices[k], np.float64) for k in ("normal", "tangent", "texCoords"))
+        Bv = np.cross(Nv, Tv[:, :3]) * Tv[:, 3:4]                       # vertex.glsl:25-36: B = cross(N, T.xyz) * T.w, per vertex, normalised
+        Bv /= np.maximum(np.linalg.norm(Bv, axis=1, keepdims=True), 1e-30)
         for a, b, c in I:
             tris.append((P[a], P[b], P[c])); alb.append(mat.base_color[:3]); emi.append(mat.emissive); met.append(mat.metallic); rough.append(mat.roughness)
+            vattr.append([np.concatenate([UV[i], Nv[i], Tv[i, :3], Bv[i]]) for i in (a, b, c)])
+            texid.append((mat.tex_color, mat.tex_normal, mat.tex_mr))
+    vattr, texid = np.asarray(vattr, np.float64), np.asarray(texid, np.int64)      # (tri, 3 vertices, 11), (tri, 3)
+    textures = [np.asarray(t, np.float64) / 255.0 for t in getattr(d, "textures", [])]
     A = np.array([t[0] for t in tris]); E1 = np.array([t[1] - t[0] for t in tris]); E2 = np.array([t[2] - t[0] for t in tris])
     NG = np.cross(E1, E2); NG /= np.linalg.norm(NG, axis=1, keepdims=True)
     alb, emi, met, rough = np.asarray(alb, np.float64), np.asarray(emi, np.float64), np.asarray(met, np.float64), np.asarray(rough, np.float64)
@@ -78,6 +85,35 @@ def _independent(d, w, h, spp, max_bounces, seed):
             nn = np.where(front[:, None], ng, -ng)
             with np.errstate(invalid="ignore"):                          # rays that left the box: t = inf, masked by `alive`
                 P = org + dirs * np.where(hit, th_, 0.0)[:, None] + nn * 1e-7
+            # the surface the BRDF sees: vertex attributes interpolated with the hit's barycentrics, textures looked up NEAREST / REPEAT (the reference's
+            # default sampler), glTF channels (roughness = G, metallic = B), normal map through the interpolated tangent frame (fragment.glsl:19-31)
+            base_k, met_k, rough_k, ns = alb[k].copy(), met[k].copy(), rough[k].copy(), nn.copy()
+            if (texid >= 0).any():
+                bu, bv_ = uu[np.arange(n), k], vv[np.arange(n), k]
+                bw = 1.0 - bu - bv_
+                at = vattr[k]
+                ip = at[:, 0] * bw[:, None] + at[:, 1] * bu[:, None] + at[:, 2] * bv_[:, None]
+                uv, Ni, Ti, Bi = ip[:, 0:2], ip[:, 2:5], ip[:, 5:8], ip[:, 8:11]
+                fu = uv - np.floor(uv)
+                def tap(ids):
+                    out = np.ones((n, 4))
+                    for t_id in np.unique(ids[ids >= 0]):
+                        tx = textures[t_id]; th_px, tw_px = tx.shape[:2]
+                        sel = ids == t_id
+                        x = np.minimum((fu[sel, 0] * tw_px).astype(np.int64), tw_px - 1); y = np.minimum((fu[sel, 1] * th_px).astype(np.int64), th_px - 1)
+                        out[sel] = tx[y, x]
+                    return out
+                tc, tn_, tm = texid[k, 0], texid[k, 1], texid[k, 2]
+                base_k = np.where((tc >= 0)[:, None], base_k * tap(tc)[:, :3], base_k)
+                mr = tap(tm)
+                rough_k = np.where(tm >= 0, rough_k * mr[:, 1], rough_k); met_k = np.where(tm >= 0, met_k * mr[:, 2], met_k)
+                nm = 2.0 * tap(tn_)[:, :3] - 1.0
+                nmap = Ti * nm[:, 0:1] + Bi * nm[:, 1:2] + Ni * nm[:, 2:3]
+                nmap /= np.maximum(np.linalg.norm(nmap, axis=1, keepdims=True), 1e-30)
+                ns = np.where((tn_ >= 0)[:, None], nmap, Ni / np.maximum(np.linalg.norm(Ni, axis=1, keepdims=True), 1e-30))
+                ns = np.where(((ns * ng).sum(1) < 0)[:, None], -ns, ns)           # the shading normal on the geometric normal's side,
+                ns = np.where(front[:, None], ns, -ns)                            # both towards the viewer,
+                ns = np.where(((ns * -dirs).sum(1) > 0)[:, None], ns, nn)         # and the geometric normal where the viewer is below the shading normal
             # uniform hemisphere about nn: pdf 1/(2 pi); f = albedo/pi; weight = albedo * cos * 2
             z, phi = rng.random(n), 2 * math.pi * rng.random(n)
             r = np.sqrt(np.maximum(0.0, 1 - z * z))
@@ -87,24 +123,26 @@ def _independent(d, w, h, spp, max_bounces, seed):
             wi = t1 * (r * np.cos(phi))[:, None] + t2 * (r * np.sin(phi))[:, None] + nn * z[:, None]
             # BRDF from its definition: Lambert base(1-m)/pi + Cook-Torrance D G F / (4 n.v n.l), GGX D, separable Smith G1,
             # Schlick F, alpha = max(r^2, 1e-3), F0 = 0.04 (1-m) + base m; materials with metallic 0 and roughness >= 1 are Lambert only
-            m_, r_ = met[k][:, None], rough[k]
-            cd = alb[k] * (1 - m_)
+            m_, r_ = met_k[:, None], rough_k
+            cl = (ns * wi).sum(1)                                          # the BRDF's cosine is the shading normal's; below it there is no contribution
+            cd = base_k * (1 - m_)
             fr = cd / math.pi
-            ggx = ~((met[k] == 0) & (r_ >= 1))
+            ggx = ~((met_k == 0) & (r_ >= 1))
             if ggx.any():
                 wo = -dirs
-                nv = np.maximum((nn * wo).sum(1), 1e-4)
+                nv = np.maximum((ns * wo).sum(1), 1e-4)
                 hv = wo + wi
                 hv /= np.maximum(np.linalg.norm(hv, axis=1, keepdims=True), 1e-30)
-                nh, vh = (nn * hv).sum(1), (wo * hv).sum(1)
+                nh, vh = (ns * hv).sum(1), (wo * hv).sum(1)
                 al = np.maximum(r_ * r_, 1e-3); a2 = al * al
                 D = a2 / (math.pi * (nh * nh * (a2 - 1) + 1) ** 2)
                 g1 = lambda x: 2 * x / (x + np.sqrt(a2 + (1 - a2) * x * x))
-                F0 = 0.04 * (1 - m_) + alb[k] * m_
+                F0 = 0.04 * (1 - m_) + base_k * m_
                 F = F0 + (1 - F0) * (np.maximum(1 - vh, 0.0) ** 5)[:, None]
-                spec = (D * g1(nv) * g1(np.maximum(z, 1e-9)) / (4 * nv * np.maximum(z, 1e-9)))[:, None] * F
+                cz = np.maximum(cl, 1e-9)
+                spec = (D * g1(nv) * g1(cz) / (4 * nv * cz))[:, None] * F
                 fr = fr + np.where(ggx[:, None], spec, 0.0)
-            T = T * fr * (2 * math.pi * z)[:, None]                      # f cos / pdf, pdf = 1 / (2 pi)
+            T = T * fr * (2 * math.pi * np.maximum(cl, 0.0))[:, None]     # f cos / pdf, pdf = 1 / (2 pi) over the geometric hemisphere
             org, dirs = P, wi
             alive &= T.max(1) > 0
             T = np.where(alive[:, None], T, 0.0)
@@ -208,3 +246,48 @@ def test_an_independent_estimator_agrees_under_an_environment_light(ora, pbr):
         s = np.sqrt((var[..., c] + ovar[..., c]).reshape(h // B, B, w // B, B).sum((1, 3))) / (B * B)
         bad = np.abs(a - b) > 4 * s + 0.04 * np.maximum(b, 0.02)
         assert not bad.any(), (c, a[bad], b[bad], s[bad])
+
+
+def test_an_independent_estimator_agrees_on_a_textured_normal_mapped_surface(ora, pbr):
+    """... and with R7's textures in play: base colour x texel, the glTF metal-rough channels (G = roughness, B = metallic), a tangent-space normal map
+    through the per-vertex T / B / N frame, NEAREST + REPEAT lookups at uv beyond [0, 1) — each taken from its definition in the reference's
+    fragment shader (geometry_pass/fragment.glsl:19-31, vertex.glsl:25-36), not from the oracle.  A swapped channel, a flipped bitangent, a
+    transposed texture or a wrong wrap changes the image far beyond Monte-Carlo error."""
+    sc = pbr.scene
+    quad = pbr.scenes._quad
+    rng = np.random.default_rng(21)
+    T_ = 8
+    albedo = np.concatenate([rng.integers(60, 256, (T_, T_, 3)), np.full((T_, T_, 1), 255)], 2).astype(np.uint8)
+    albedo[:, : T_ // 2, 0] //= 3                                                    # left half less red: a transposed or mirrored lookup shows
+    mr = np.zeros((T_, T_, 4), np.uint8); mr[..., 3] = 255
+    mr[..., 1] = rng.integers(90, 256, (T_, T_)); mr[..., 2] = rng.integers(0, 2, (T_, T_)) * 200        # G roughness, B metallic
+    yy, xx = np.mgrid[0:T_, 0:T_]
+    nx, ny = 0.45 * np.sin(2 * math.pi * xx / T_), 0.35 * np.cos(2 * math.pi * yy / T_) + 0.2           # asymmetric in y: the bitangent's sign matters
+    nz = np.sqrt(1 - nx * nx - ny * ny)
+    nmap = np.stack([np.round((nx * 0.5 + 0.5) * 255), np.round((ny * 0.5 + 0.5) * 255), np.round((nz * 0.5 + 0.5) * 255), np.full((T_, T_), 255)], 2).astype(np.uint8)
+    mats = [sc.Material((0.9, 0.8, 0.7, 1.0), 1.0, 0.8, (0.0, 0.0, 0.0), 0, 1, 2), sc.Material((0.0, 0.0, 0.0, 1.0), 0.0, 1.0, (7.0, 6.0, 5.0)),
+            sc.Material((0.5, 0.6, 0.7, 1.0), 0.0, 1.0)]
+    fv, fi = quad((-2, 0, 2), (2, 0, 2), (2, 0, -2), (-2, 0, -2))
+    fv["texCoords"] = np.array([(-0.3, -0.2), (1.9, -0.2), (1.9, 1.6), (-0.3, 1.6)], np.float32)       # beyond [0, 1): REPEAT
+    q = [((fv, fi), 0), (quad((-0.9, 1.6, -0.9), (0.9, 1.6, -0.9), (0.9, 1.6, 0.9), (-0.9, 1.6, 0.9)), 1), (quad((-2, 0, -2), (2, 0, -2), (2, 2.5, -2), (-2, 2.5, -2)), 2)]
+    meshes = [sc.MeshDesc(v, i, m) for (v, i), m in q]
+    inst = [sc.InstanceDesc(k, (0.0, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0), (1.0, 1.0, 1.0)) for k in range(3)]
+    d = sc.SceneDesc(mats, meshes, inst, sc.CameraDesc((0.4, 1.0, 3.2), (0.0, 0.2, 0.0), math.radians(50.0), 1.0), "textured_floor", textures=[albedo, nmap, mr])
+    w = h = 16
+    mb = 3
+    ind, var = _independent(d, w, h, 3000, mb, seed=777)
+    o = ora.Oracle().load_scene(d)
+    r1 = o.render(w, h, 512, seed=25, max_bounces=mb)[..., :3].astype(np.float64)
+    r2 = o.render(w, h, 512, seed=26, max_bounces=mb)[..., :3].astype(np.float64)
+    ref, ovar = 0.5 * (r1 + r2), ((r1 - r2) ** 2) / 4
+    se = math.sqrt(var.sum() + ovar.sum()) / var.size
+    assert ref.mean() > 0.05
+    assert abs(ind.mean() - ref.mean()) <= 4 * se + 0.015 * ref.mean(), (ind.mean(), ref.mean(), se)
+    B = 4
+    for c in range(3):
+        a = ind[..., c].reshape(h // B, B, w // B, B).mean((1, 3))
+        b = ref[..., c].reshape(h // B, B, w // B, B).mean((1, 3))
+        s = np.sqrt((var[..., c] + ovar[..., c]).reshape(h // B, B, w // B, B).sum((1, 3))) / (B * B)
+        bad = np.abs(a - b) > 4 * s + 0.04 * np.maximum(b, 0.02)
+        assert not bad.any(), (c, a[bad], b[bad], s[bad])
+    print("textured: independent %.4f oracle %.4f (se %.4f)" % (ind.mean(), ref.mean(), se))
