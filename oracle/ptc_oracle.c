@@ -521,8 +521,11 @@ static uint32_t sah_split(build_t* b, uint32_t lo, uint32_t hi) {
 /* LBVH (BASELINE north_star: "flattened LBVH"; Lauterbach et al. 2009, Karras 2012): the binary tree is the radix tree of the
  * triangles' Morton codes.  Code of a triangle: its box centre, per axis q = (uint32)((ctr - cl) * (2097152 / (ch - cl))) clamped to
  * 2^21 - 1 (cl, ch = bounds of all centres; 0 on a degenerate axis), bits interleaved x -> bit 0, y -> bit 1, z -> bit 2 (63 bits).
- * The initial order is ascending (code, primitive id).  A range splits where the highest bit in which its first and last code
- * differ flips from 0 to 1; a range of equal codes is cut at its middle index. */
+ * The initial order is ascending (code, primitive id).  The tree is the radix tree of the keys (code, sorted position) — Karras 2012,
+ * sec. 4: duplicate codes are told apart by their position, so the rule below is one rule and every internal node can be found on
+ * its own (the device build, csrc/pt_build.hip, does): a range splits where the highest bit in which its first and last KEY differ
+ * flips from 0 to 1 — a bit of the code, or, in a range of one code, a bit of the position.  (Until round 4 a range of one code was
+ * cut at its middle index, which no per-node rule reproduces.) */
 static inline uint64_t expand21(uint32_t v) {
   uint64_t x = v & 0x1fffffu;
   x = (x | x << 32) & 0x1f00000000ffffull;
@@ -563,7 +566,10 @@ static uint64_t* morton_order(ora_ctx* c, const float* tlo, const float* thi, ui
 }
 static uint32_t morton_split(const build_t* b, uint32_t lo, uint32_t hi) {
   const uint64_t c0 = b->codes[lo], c1 = b->codes[hi];
-  if (c0 == c1) return lo + (hi - lo) / 2;
+  if (c0 == c1) {                          /* the key goes on with the sorted position: split where the highest bit in which lo and hi differ turns 1 */
+    const uint32_t pbit = 1u << (31 - __builtin_clz(lo ^ hi));
+    return (hi & ~(pbit - 1u)) - 1u;
+  }
   const uint64_t bit = 1ull << (63 - __builtin_clzll(c0 ^ c1));
   uint32_t a = lo, z = hi;                 /* codes[a] has the bit clear, codes[z] has it set */
   while (z - a > 1) { uint32_t m = a + (z - a) / 2; if (b->codes[m] & bit) z = m; else a = m; }

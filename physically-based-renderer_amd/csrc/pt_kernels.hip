@@ -30,8 +30,12 @@
 #define TRACE_CHUNK 512u          // rays per work-fetch atomic
 #endif
 #ifndef TRACE_REFILL_IDLE
-#define TRACE_REFILL_IDLE 12      // refill as soon as this many lanes are idle (8-wide tree: 4: -3 %, 8: -1 %, 20: -1.5 %, 32: -14 %)
+#define TRACE_REFILL_IDLE 1       // idle lanes that make the wave hand out prepared rays (round 4: a hand-out is ~25 vector instructions; the round-3 refill cost ~85 at 0.27 lane utilisation and waited for 12)
 #endif
+#ifndef TRACE_RING
+#define TRACE_RING 64             // prepared rays a wave holds in LDS (struct RayRing)
+#endif
+#define RING_FIELDS 5             // slot, inv.x, inv.y, inv.z, octant
 #ifndef TRACE_NODE_MIN
 #define TRACE_NODE_MIN 40         // leave the node loop when fewer lanes than this are still at interior nodes
 #endif                            // while others wait at a leaf (keeps both phases well populated; 24: -6 %, 32: -1.5 %, 48: -3 %, 56: -18 %)
@@ -177,18 +181,18 @@ struct WStack {
   typedef unsigned int ux2 __attribute__((ext_vector_type(2)));
   typedef __attribute__((address_space(3))) ux2 lds_u2;
   typedef __attribute__((address_space(1))) ux2 glb_u2;
-  lds_u2* lds; glb_u2* ovf; int sp; int L;
-  PT_DEV void init(uint2* lds_base, uint2* ovf_base, int l) { lds = (lds_u2*)lds_base; ovf = (glb_u2*)ovf_base; sp = 0; L = l; }
+  lds_u2* lds; glb_u2* ovf; int sp; int L;     // ovf: the WAVE's slab (a uniform pointer: it lives in scalar registers; the lane's column is added where it is used, on the rare deep pushes)
+  PT_DEV void init(uint2* lds_base, uint2* ovf_wave, int l) { lds = (lds_u2*)lds_base; ovf = (glb_u2*)ovf_wave; sp = 0; L = l; }
   PT_DEV void reset() { sp = 0; }
   PT_DEV void push(uint32_t base, uint32_t mask) {
     const ux2 e = {base, mask};
-    if (sp < L) lds[sp * 64] = e; else ovf[(sp - L) * 64] = e;      // explicit address spaces: ds_write_b64 / global_store_dwordx2
+    if (sp < L) lds[sp * 64] = e; else ovf[(sp - L) * 64 + (int)lane_id()] = e;      // explicit address spaces: ds_write_b64 / global_store_dwordx2
     ++sp;
   }
   PT_DEV uint2 pop() {
     --sp;
     ux2 e;
-    if (sp < L) e = lds[sp * 64]; else e = ovf[(sp - L) * 64];      // ds_read_b64 / global_load_dwordx2, never FLAT
+    if (sp < L) e = lds[sp * 64]; else e = ovf[(sp - L) * 64 + (int)lane_id()];      // ds_read_b64 / global_load_dwordx2, never FLAT
     return make_uint2(e.x, e.y);
   }
   PT_DEV bool empty() const { return sp == 0; }
@@ -377,9 +381,8 @@ struct Reservoir {
     next = lo * q.seg_len + j * chunk;
     end = lo * q.seg_len + ((j + 1u) * chunk < live ? (j + 1u) * chunk : live);
   }
-  PT_DEV bool refill(const DevQueues& q, const uint32_t* pre, const uint32_t* seg, uint32_t* ctr, bool idle, uint32_t lane, uint32_t& ri) {
-    const uint64_t mi = __ballot(idle);
-    if (!mi) return false;
+  // the next (at most `want`) consecutive slots of the wave's current chunk: [first, first + n); n = 0: the queue is exhausted
+  PT_DEV uint32_t take(const DevQueues& q, const uint32_t* pre, const uint32_t* seg, uint32_t* ctr, uint32_t lane, uint32_t want, uint32_t& first) {
     if (next >= end && !exhausted) {
       if (static_left) { static_left = false; open_chunk(q, pre, seg, my_static, lane); }
       else {
@@ -392,12 +395,51 @@ struct Reservoir {
       }
     }
     const uint32_t avail = end - next;
-    if (avail == 0) return false;
-    const uint32_t rank = mbcnt64(mi), need = (uint32_t)__popcll(mi);
-    const bool take = idle && rank < avail;
-    if (take) ri = next + rank;
-    next += need < avail ? need : avail;
-    return take;
+    const uint32_t n = avail < want ? avail : want;
+    first = next; next += n;
+    return n;
+  }
+};
+
+// Prepared rays of a wave (round 4).  The round-3 refill ran make_ray — three IEEE divisions, ~85 vector instructions with the queue loads — for
+// the ~17 idle lanes of a round, i.e. at 0.27 lane utilisation, and was therefore put off until 12 lanes had nothing to do: on average 13 % of a
+// wave's lanes sat idle through its node and leaf iterations.  Now the wave PREPARES the next TRACE_RING rays of its chunk with all 64 lanes
+// (queue loads, safe_dir, the divisions, the octant) and parks (slot, inv, octant) in LDS; handing one to an idle lane is five ds_reads and the
+// two queue loads of (o, d) — second readers of lines the staging brought to L2 —, cheap enough to do as soon as a lane is free.  Which lane
+// gets which ray changes neither a hit (written to the ray's own slot) nor a counter (sums over rays).
+struct RayRing {
+  typedef __attribute__((address_space(3))) uint32_t lds_u32;
+  lds_u32* f;      // this wave's [RING_FIELDS][TRACE_RING] words
+  uint32_t n;      // prepared rays left (wave-uniform); they are handed out from the top
+  PT_DEV void init(uint32_t* base) { f = (lds_u32*)base; n = 0; }
+  PT_DEV void stage(Reservoir& res, const DevQueues& q, const uint32_t* pre, const uint32_t* seg, uint32_t* ctr, const float4* QA, const float4* QB, uint32_t lane) {
+    uint32_t first;
+    const uint32_t k = res.take(q, pre, seg, ctr, lane, TRACE_RING, first);
+    if (lane < k) {
+      const uint32_t ri = first + lane;
+      const float4 A = QA[ri], B = QB[ri];
+      const ray_t r = make_ray(V3(A.x, A.y, A.z), V3(A.w, B.x, B.y));
+      f[lane] = ri;
+      f[TRACE_RING + lane] = __float_as_uint(r.inv.x); f[2 * TRACE_RING + lane] = __float_as_uint(r.inv.y); f[3 * TRACE_RING + lane] = __float_as_uint(r.inv.z);
+      f[4 * TRACE_RING + lane] = (r.inv.x >= 0.0f ? 1u : 0u) | (r.inv.y >= 0.0f ? 2u : 0u) | (r.inv.z >= 0.0f ? 4u : 0u);
+    }
+    n = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  PT_DEV bool pop(bool idle, uint32_t& ri, v3& inv, uint32_t& oct) {
+    const uint64_t m = __ballot(idle);
+    const uint32_t rank = mbcnt64(m), need = (uint32_t)__popcll(m);
+    const bool got = idle && rank < n;
+    if (got) {
+      const uint32_t i = n - 1u - rank;
+      ri = f[i];
+      inv = V3(__uint_as_float(f[TRACE_RING + i]), __uint_as_float(f[2 * TRACE_RING + i]), __uint_as_float(f[3 * TRACE_RING + i]));
+      oct = f[4 * TRACE_RING + i];
+    }
+    n -= need < n ? need : n;
+    return got;
   }
 };
 
@@ -407,13 +449,14 @@ struct Reservoir {
 #define DIAG_ITER(var) do { } while (0)
 #endif
 
-// LDS of a trace block: [n_lds_units × 16 B: the top of the tree][waves × L × 64 stack entries of 8 B][2 KiB slot-order table (closest hit only)]
-struct TraceLds { uint32_t top_addr; uint2* stack; uint8_t* order_tab; };
-PT_DEV TraceLds trace_lds(float4* lds_raw, const DevScene& sc, int stack_lds) {
+// LDS of a trace block: [n_lds_units × 16 B: the top of the tree][waves × L × 64 stack entries of 8 B][2 KiB slot-order table (closest hit only)][waves × RING_FIELDS × TRACE_RING words: the prepared rays]
+struct TraceLds { uint32_t top_addr; uint2* stack; uint8_t* order_tab; uint32_t* ring; };
+PT_DEV TraceLds trace_lds(float4* lds_raw, const DevScene& sc, int stack_lds, bool closest) {
   TraceLds t;
   t.top_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_raw;
   t.stack = reinterpret_cast<uint2*>(lds_raw + sc.n_lds_units);
   t.order_tab = reinterpret_cast<uint8_t*>(t.stack + (size_t)TRACE_WAVES * (size_t)stack_lds * 64u);
+  t.ring = reinterpret_cast<uint32_t*>(t.order_tab + (closest ? ORDER_TABLE_BYTES : 0));
   return t;
 }
 // triangle record at unit address k: from the staged top of the tree or from global memory (two explicit address spaces: a
@@ -442,7 +485,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_closest(
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
   if (Reservoir::block_has_no_work(&q.cnt[CNT_RAY_TOTAL])) return;     // a short queue: most blocks of the persistent grid leave before staging anything
-  const TraceLds L = trace_lds(lds_raw, sc, stack_lds);
+  const TraceLds L = trace_lds(lds_raw, sc, stack_lds, true);
   uint8_t* order_tab = L.order_tab;
   for (uint32_t i = threadIdx.x; i < sc.n_lds_units; i += TRACE_BLOCK) lds_raw[i] = sc.recs[i];
   build_order_table(order_tab);
@@ -462,35 +505,48 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_closest(
   const uint32_t* seg_cnt = q.seg_ray[qi];
   WStack st;
   st.init(L.stack + (size_t)wave * (size_t)stack_lds * 64u + lane,
-          sc.stack_ovf + ((size_t)(blockIdx.x * TRACE_WAVES + wave) * sc.ovf_depth) * 64u + lane, stack_lds);
+          sc.stack_ovf + ((size_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * TRACE_WAVES + wave)) * sc.ovf_depth) * 64u, stack_lds);
   int cur = CUR_DONE;
   uint32_t ri = 0, oct = 0, gbase = 0, gmask = 0, tbase = 0, tmask = 0;
   ray_t r = make_ray(V3(0, 0, 0), V3(0, 0, 1));
   float tmin = 0.0f, best_t = PT_T_INF, best_u = 0.0f, best_v = 0.0f;
   int best_prim = 0x7fffffff, best_cls = 0;
   bool found = false;
+  RayRing ring; ring.init(L.ring + (size_t)wave * RING_FIELDS * TRACE_RING);
   for (;;) {
-    // ---- refill idle lanes from the wave's reservoir ----
-    const bool got = res.refill(q, q.pre_ray, seg_cnt, &q.cnt[CNT_WORK_TRACE], cur == CUR_DONE, lane, ri);
-    nr += (unsigned long long)__popcll(__ballot(got));
-    if (got) {
-      const float4 A = rq.A[ri], Bq = rq.B[ri];
-      r = make_ray(V3(A.x, A.y, A.z), V3(A.w, Bq.x, Bq.y));
-      oct = ray_octant(r);
-      tmin = CULL ? Bq.z : 0.0f;
-      best_t = CULL ? Bq.w : PT_T_INF; best_u = 0.0f; best_v = 0.0f; best_prim = 0x7fffffff; best_cls = 0; found = false;
-      st.reset();
-      gmask = 0; tmask = 0;
-      cur = 0;
+    // ---- hand prepared rays to the idle lanes (RayRing) ----
+    {
+      bool idle = cur == CUR_DONE;
+      uint64_t mi = __ballot(idle);
+      if ((uint32_t)__popcll(mi) >= TRACE_REFILL_IDLE || !__ballot(cur != CUR_DONE)) {
+        while (mi) {
+          if (ring.n == 0u) {
+            if (res.exhausted) break;
+            ring.stage(res, q, q.pre_ray, seg_cnt, &q.cnt[CNT_WORK_TRACE], rq.A, rq.B, lane);
+            if (ring.n == 0u) break;
+          }
+          v3 inv = V3(0, 0, 0); uint32_t oc = 0;
+          const bool got = ring.pop(idle, ri, inv, oc);
+          nr += (unsigned long long)__popcll(__ballot(got));
+          if (got) {
+            const float4 A = rq.A[ri], Bq = rq.B[ri];
+            r.o = V3(A.x, A.y, A.z); r.d = V3(A.w, Bq.x, Bq.y); r.inv = inv;
+            oct = oc;
+            tmin = CULL ? Bq.z : 0.0f;
+            best_t = CULL ? Bq.w : PT_T_INF; best_u = 0.0f; best_v = 0.0f; best_prim = 0x7fffffff; best_cls = 0; found = false;
+            st.reset();
+            gmask = 0; tmask = 0;
+            cur = 0;
+          }
+          idle = cur == CUR_DONE; mi = __ballot(idle);
+        }
+      }
     }
     STAMP(t_refill);
-    if (!__ballot(cur != CUR_DONE)) {
-      if (res.exhausted) break;
-      continue;
-    }
-    // ---- traverse until enough lanes have finished to make a refill worthwhile ----
+    if (!__ballot(cur != CUR_DONE)) break;        // nothing in flight, nothing prepared, the queue exhausted
+    // ---- one cycle: node visits while enough lanes walk, one leaf pass, publish ----
     DIAG_ITER(d_round);
-    do {
+    {
       for (;;) {
         const uint64_t mn = __ballot(cur >= 0);
         if (!mn) break;
@@ -679,7 +735,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_closest(
         cur = CUR_DONE;
       }
       STAMP(t_fin);
-    } while (__popcll(__ballot(cur == CUR_DONE)) < TRACE_REFILL_IDLE || (res.exhausted && res.next >= res.end && __ballot(cur != CUR_DONE)));
+    }
   }
   const unsigned long long c_tris = wave_sum(nt);
   if (lane == 0 && nr) {
@@ -709,7 +765,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_any(DevS
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
   if (Reservoir::block_has_no_work(&q.cnt[CNT_SH_TOTAL])) return;
-  const TraceLds L = trace_lds(lds_raw, sc, stack_lds);
+  const TraceLds L = trace_lds(lds_raw, sc, stack_lds, false);
   for (uint32_t i = threadIdx.x; i < sc.n_lds_units; i += TRACE_BLOCK) lds_raw[i] = sc.recs[i];
   __syncthreads();
   unsigned long long nv = 0, nr = 0;
@@ -717,30 +773,43 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_any(DevS
   Reservoir res; res.init(&q.cnt[CNT_SH_TOTAL], (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * TRACE_WAVES + wave)));
   WStack st;
   st.init(L.stack + (size_t)wave * (size_t)stack_lds * 64u + lane,
-          sc.stack_ovf + ((size_t)(blockIdx.x * TRACE_WAVES + wave) * sc.ovf_depth) * 64u + lane, stack_lds);
+          sc.stack_ovf + ((size_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * TRACE_WAVES + wave)) * sc.ovf_depth) * 64u, stack_lds);
   int cur = CUR_DONE;
   uint32_t ri = 0, path = 0, oct = 0, gbase = 0, gmask = 0, tbase = 0, tmask = 0;
   ray_t r = make_ray(V3(0, 0, 0), V3(0, 0, 1));
   float tmax = 0.0f;
   bool occluded = false;
+  RayRing ring; ring.init(L.ring + (size_t)wave * RING_FIELDS * TRACE_RING);
   for (;;) {
-    const bool got = res.refill(q, q.pre_sh, q.seg_sh, &q.cnt[CNT_WORK_SHADOW], cur == CUR_DONE, lane, ri);
-    nr += (unsigned long long)__popcll(__ballot(got));
-    if (got) {
-      const float4 A = q.shadow.A[ri], Bq = q.shadow.B[ri];
-      r = make_ray(V3(A.x, A.y, A.z), V3(A.w, Bq.x, Bq.y));
-      oct = ray_octant(r);
-      tmax = Bq.z; path = __float_as_uint(Bq.w);
-      occluded = false;
-      st.reset();
-      gmask = 0; tmask = 0;
-      cur = 0;
+    {
+      bool idle = cur == CUR_DONE;
+      uint64_t mi = __ballot(idle);
+      if ((uint32_t)__popcll(mi) >= TRACE_REFILL_IDLE || !__ballot(cur != CUR_DONE)) {
+        while (mi) {
+          if (ring.n == 0u) {
+            if (res.exhausted) break;
+            ring.stage(res, q, q.pre_sh, q.seg_sh, &q.cnt[CNT_WORK_SHADOW], q.shadow.A, q.shadow.B, lane);
+            if (ring.n == 0u) break;
+          }
+          v3 inv = V3(0, 0, 0); uint32_t oc = 0;
+          const bool got = ring.pop(idle, ri, inv, oc);
+          nr += (unsigned long long)__popcll(__ballot(got));
+          if (got) {
+            const float4 A = q.shadow.A[ri], Bq = q.shadow.B[ri];
+            r.o = V3(A.x, A.y, A.z); r.d = V3(A.w, Bq.x, Bq.y); r.inv = inv;
+            oct = oc;
+            tmax = Bq.z; path = __float_as_uint(Bq.w);
+            occluded = false;
+            st.reset();
+            gmask = 0; tmask = 0;
+            cur = 0;
+          }
+          idle = cur == CUR_DONE; mi = __ballot(idle);
+        }
+      }
     }
-    if (!__ballot(cur != CUR_DONE)) {
-      if (res.exhausted) break;
-      continue;
-    }
-    do {
+    if (!__ballot(cur != CUR_DONE)) break;
+    {
       for (;;) {
         const uint64_t mn = __ballot(cur >= 0);
         if (!mn) break;
@@ -887,7 +956,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_any(DevS
         }
         cur = CUR_DONE;
       }
-    } while (__popcll(__ballot(cur == CUR_DONE)) < TRACE_REFILL_IDLE || (res.exhausted && res.next >= res.end && __ballot(cur != CUR_DONE)));
+    }
   }
   const unsigned long long c_tris = wave_sum(nt);
   if (lane == 0 && nr) {
@@ -1518,7 +1587,7 @@ __global__ __launch_bounds__(256) void k_tonemap(const float4* radiance, uint32_
 // =================================================================================================
 // launchers
 static size_t trace_lds_bytes(const LaunchCfg& cfg, const DevScene& sc, bool closest) {
-  return (size_t)sc.n_lds_units * 16 + (size_t)TRACE_WAVES * cfg.stack_lds * 64 * 8 + (closest ? ORDER_TABLE_BYTES : 0);
+  return (size_t)sc.n_lds_units * 16 + (size_t)TRACE_WAVES * cfg.stack_lds * 64 * 8 + (closest ? ORDER_TABLE_BYTES : 0) + (size_t)TRACE_WAVES * RING_FIELDS * TRACE_RING * 4;
 }
 
 int pt_trace_block_threads() { return TRACE_BLOCK; }

@@ -107,6 +107,7 @@ struct ptc_ctx {
   int bvh_builder = PTC_BVH_SAH;         // builder of the scene being described
   // committed scene
   bool committed = false;
+  size_t committed_insts = 0;       // instances the committed scene was built from (ptc_scene_refit refuses a description that has grown since)
   std::shared_ptr<HostBuilt> built = std::make_shared<HostBuilt>();   // the host build; the contexts of a ptc_group share one (ptc_group_scene_commit)
   DevScene dsc{};
   DevCamera cam{};
@@ -284,15 +285,22 @@ struct ScopedSpan {   // records a start/stop event pair around launches on one 
 int configure_launch(ptc_ctx* c) {
   // Traversal stack: at most one group of pending children per tree level, so a ray needs at most depth+1 entries.
   // `stack_lds` of them live in LDS (8 B each, 512 B per level and wave), the rest in a global overflow slab.
-  // LDS per block = staged top of the tree (4.6 KB) + waves·stack_lds·512 B + the 2-KiB slot-order table.
+  // LDS per block = staged top of the tree (1.2 KB) + waves·stack_lds·512 B + the 2-KiB slot-order table + the waves' prepared rays (5 KB) + 512 B static.
+  // Default: the most stack entries (at most 6) with which the register limit of 8 blocks (32 waves) per CU still fits the 160 KiB of LDS — 5 since the
+  // prepared rays of round 4 (19.1 KB per block).
   const int need = (int)c->built->max_depth + 2;
-  int l = 6;    // stack entries per lane kept in LDS: 18.6 KB per block, 8 blocks (32 waves, the register limit) share a CU
-  if (const char* e = std::getenv("PTC_STACK_LDS")) { int v = std::atoi(e); if (v >= 1 && v <= 64) l = v; }
+  int l = 6, per_cu = 0;
+  bool l_forced = false;
+  if (const char* e = std::getenv("PTC_STACK_LDS")) { int v = std::atoi(e); if (v >= 1 && v <= 64) { l = v; l_forced = true; } }
   if (l > need) l = need;
-  c->cfg.stack_lds = l;
-  const size_t lds = pt_trace_lds_bytes(c->cfg, c->dsc);
-  if (lds > 160u * 1024u) return fail(c, PTC_E_ARG, "configure_launch: staged tree top + stack exceed the 160 KiB of LDS");
-  int per_cu = pt_trace_blocks_per_cu(lds);     // registers, static LDS and launch bounds included
+  size_t lds = 0;
+  for (;; --l) {
+    c->cfg.stack_lds = l;
+    lds = pt_trace_lds_bytes(c->cfg, c->dsc);
+    if (lds > 160u * 1024u) { if (l > 1 && !l_forced) continue; return fail(c, PTC_E_ARG, "configure_launch: staged tree top + stack exceed the 160 KiB of LDS"); }
+    per_cu = pt_trace_blocks_per_cu(lds);     // registers, static LDS and launch bounds included
+    if (per_cu >= 8 || l <= 2 || l_forced) break;
+  }
   if (per_cu < 1) return fail(c, PTC_E_DEVICE, "configure_launch: the trace kernels do not fit a CU with this LDS size");
   if (const char* e = std::getenv("PTC_TRACE_BLOCKS_PER_CU")) { int v = std::atoi(e); if (v >= 1 && v <= per_cu) per_cu = v; }
   c->cfg.trace_blocks_per_cu = per_cu;
@@ -694,6 +702,20 @@ int ensure_refit_plan(ptc_ctx* c) {
   return PTC_OK;
 }
 
+// A refit moves the committed scene: ptc_add_mesh / ptc_add_instance* are accepted after a commit (they describe the NEXT commit), and a refit of a
+// description that has grown since would index the committed arrays out of bounds — on the device without anybody noticing.  Same test, same
+// error as the host path (build_or_refit), made before anything is uploaded or launched.
+bool description_matches_commit(const ptc_ctx* c) {
+  if (c->insts.size() != c->committed_insts) return false;
+  uint64_t nv = 0, nt = 0;
+  for (const HostInstance& in : c->insts) {
+    if (in.mesh < 0 || (size_t)in.mesh >= c->meshes.size()) return false;
+    nv += c->meshes[(size_t)in.mesh].v.size(); nt += c->meshes[(size_t)in.mesh].idx.size() / 3;
+  }
+  return nv == c->built->wverts.size() && nt == c->built->n_tris;
+}
+const char* const kDescriptionChanged = "scene_refit: the scene's meshes or instances changed since the commit (only transforms may)";
+
 // Refit on the device.  Returns PTC_OK, an error, or +1: "not this way" (the set of emitters changed) — the caller refits on the host.
 // may_write_built: c->built is this context's own, or a group's fresh copy every member writes the same values to.
 int device_refit(ptc_ctx* c) {
@@ -770,6 +792,7 @@ int ptc_update_instance(ptc_ctx* c, int instance, const float t[3], const float 
 int ptc_scene_refit(ptc_ctx* c) {
   if (!c) return PTC_E_ARG;
   if (!c->committed) return fail(c, PTC_E_STATE, "scene_refit: scene not committed");
+  if (!description_matches_commit(c)) return fail(c, PTC_E_STATE, kDescriptionChanged);
   if (c->device >= 0) {
     HIP_TRY(c, hipSetDevice(c->device));
     { int rf = flush(c); if (rf) return rf; }
@@ -834,6 +857,7 @@ namespace {
 int commit_upload(ptc_ctx* c, std::chrono::steady_clock::time_point t0) {
   ptc_make_camera(c->cam_pos, c->cam_target, c->cam_fov, c->cam_aspect, c->cam);
   c->in_frame = false; c->pending = 0;
+  c->committed_insts = c->insts.size();
   if (c->device < 0) {   // description-only context: nothing to upload
     c->committed = true;
     std::memset(&c->stats, 0, sizeof c->stats);
@@ -1223,6 +1247,7 @@ int ptc_group_scene_refit(ptc_group* g) {
   if (!g || g->ctx.empty()) return PTC_E_ARG;
   ptc_ctx* c0 = g->ctx[0];
   if (!c0->committed) { g->err = "ptc_group_scene_refit: the group's scene is not committed"; return PTC_E_STATE; }
+  if (!description_matches_commit(c0)) { g->err = kDescriptionChanged; return PTC_E_STATE; }
   // device 0's instances carry the new transforms (ptc_update_instance* on ptc_group_ctx(g, 0)): one refit on the host, the arrays go to every device
   for (ptc_ctx* c : g->ctx) {
     if (hipSetDevice(c->device) != hipSuccess) { g->err = "ptc_group_scene_refit: hipSetDevice failed"; return PTC_E_DEVICE; }
@@ -1240,7 +1265,11 @@ int ptc_group_scene_refit(ptc_group* g) {
       c->built = mine;
       const int rc = device_refit(c);
       if (rc > 0) { host_way = true; break; }      // decided from the description alone, before any kernel ran: all devices take the host path together
-      if (rc) { g->err = "device " + std::to_string(i) + ": " + ptc_last_error(c); return rc; }
+      if (rc) {
+        g->err = "device " + std::to_string(i) + ": " + ptc_last_error(c);
+        if (i == 0) return rc;                     // nothing has been refitted yet (a refused refit leaves the device's scene as it was)
+        host_way = true; break;                    // devices 0..i-1 hold the new state: the host path below brings ALL of them to one state, or fails as a whole
+      }
       c->in_frame = false; c->pending = 0;
       c->stats.seconds_refit = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }

@@ -218,8 +218,9 @@ inline float box_half_area(const Box& b) {
 
 // ---- LBVH option (BASELINE north_star's "flattened LBVH"): the binary tree is the radix tree of 63-bit Morton codes ------------
 // Per axis q = (uint32)((centre - cl) * (2^21 / (ch - cl))) clamped to 2^21 - 1 over the bounds cl..ch of all box centres (0 on a
-// degenerate axis); x in bit 0, y in bit 1, z in bit 2 of each triple.  Positions are ordered by (code, primitive id); a range splits
-// where the highest bit in which its end codes differ turns 1, a range of one code at its middle index.
+// degenerate axis); x in bit 0, y in bit 1, z in bit 2 of each triple.  Positions are ordered by (code, primitive id); the tree is the radix
+// tree of the keys (code, sorted position): a range splits where the highest bit in which its end KEYS differ turns 1 — a bit of the code or,
+// in a range of one code, of the position — so that every internal node can be found on its own (the device build, pt_build.hip).
 inline uint64_t spread_bits_3(uint32_t v) {
   uint64_t r = 0;
   for (int b = 0; b < 21; ++b) r |= (uint64_t)((v >> b) & 1u) << (3 * b);
@@ -249,7 +250,10 @@ std::vector<uint64_t> sort_by_morton_code(const std::vector<float>& ctr, std::ve
 }
 inline uint32_t morton_last_left(const std::vector<uint64_t>& codes, uint32_t lo, uint32_t hi) {
   const uint64_t diff = codes[lo] ^ codes[hi];
-  if (!diff) return lo + (hi - lo) / 2;
+  if (!diff) {                             // one code: the key goes on with the sorted position (Karras 2012, sec. 4)
+    const uint32_t pbit = 1u << (31 - __builtin_clz(lo ^ hi));
+    return (hi & ~(pbit - 1u)) - 1u;
+  }
   const uint64_t top = (uint64_t)1 << (63 - __builtin_clzll(diff));
   // the bit is clear at lo and set at hi, and the codes are sorted: find the last position where it is clear
   const auto first_set = std::partition_point(codes.begin() + lo, codes.begin() + hi + 1, [top](uint64_t c) { return (c & top) == 0; });

@@ -392,3 +392,22 @@ def test_refit_equals_oracle_and_keeps_the_topology(ora, pbr, name, kw):
         pt.update_instance(10 ** 6, (0, 0, 0), (1, 0, 0, 0), (1, 1, 1))
     with pytest.raises(pbr.PtcError):
         pbr.PathTracer(pbr.DEVICE_NONE).scene_refit()                  # nothing committed
+
+
+def test_refit_refuses_a_description_that_changed_since_the_commit(pbr):
+    """ptc_add_instance* / ptc_add_mesh are accepted after a commit (they describe the next one); a refit of such a description would index the
+    committed arrays out of bounds, so ptc_scene_refit refuses it before anything is computed — and a fresh commit takes it."""
+    import ctypes as C
+    d = pbr.scenes.by_name("cornell")
+    pt = pbr.PathTracer(pbr.DEVICE_NONE).load_scene(d)
+    f3 = lambda *v: (C.c_float * len(v))(*v)
+    assert pt._L.ptc_add_instance(pt._h, 0, f3(0.0, 0.1, 0.0), f3(1.0, 0.0, 0.0, 0.0), f3(1.0, 1.0, 1.0)) >= 0
+    with pytest.raises(pbr.PtcError, match="changed since the commit"):
+        pt.scene_refit()
+    pt.update_instance(len(d.instances), (0.0, 0.2, 0.0), (1.0, 0.0, 0.0, 0.0), (1.0, 1.0, 1.0))     # the new instance exists in the description
+    with pytest.raises(pbr.PtcError, match="changed since the commit"):
+        pt.scene_refit()
+    assert pt._L.ptc_scene_commit(pt._h) == 0
+    pt.scene_refit()
+    assert pt.stats()["n_triangles"] > pbr.PathTracer(pbr.DEVICE_NONE).load_scene(d).stats()["n_triangles"]
+
