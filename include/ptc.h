@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PTC_ABI_VERSION 3
+#define PTC_ABI_VERSION 4
 
 typedef struct ptc_ctx ptc_ctx;
 
@@ -91,6 +91,15 @@ typedef struct ptc_stats {
   uint32_t n_bvh_nodes;
   uint32_t n_emitters;
   uint32_t bvh_max_depth;
+  /* ABI 4 (round 4): what a moved scene's tree costs, so that a caller can decide when a refit is no longer enough.
+   * bvh_sa_cost = the surface-area cost of the 8-wide tree as it lies in HBM: sum over the nodes' child slots of half_area(child box) /
+   * half_area(scene box), a two-triangle leaf counted twice — the expected number of node visits + triangle tests of a random long ray, up to a
+   * constant.  Written by ptc_scene_commit (host build), by every ptc_scene_refit and ptc_scene_rebuild (one reduction inside the node pass, in
+   * fixed point: the same bits whatever the order).  bvh_sa_cost_built = its value when the tree's TOPOLOGY was made (commit or rebuild): the ratio
+   * of the two is what examples/viewer_shim.cpp watches. */
+  double bvh_sa_cost;
+  double bvh_sa_cost_built;
+  double seconds_rebuild;     /* the last ptc_scene_rebuild: flatten + LBVH build + refit pass, all on the device                */
 } ptc_stats;
 
 /* ---- context ------------------------------------------------------------------------------
@@ -157,6 +166,16 @@ int ptc_add_instance_matrix(ptc_ctx*, int mesh, const float model[16]);
 int ptc_update_instance(ptc_ctx*, int instance, const float t[3], const float q_wxyz[4], const float s[3]);
 int ptc_update_instance_matrix(ptc_ctx*, int instance, const float model[16]);
 int ptc_scene_refit(ptc_ctx*);
+/* A refit keeps the tree of the commit: topology and octant slots follow the geometry they were made for, and the viewer turns its nodes without
+ * bound (App.cpp:306-313: rotate(rotation, deltaTime) every frame) — after a third of a turn the atrium's rays visit 1.5x the nodes
+ * (profiles/r04_refit_curve.txt).  ptc_scene_rebuild applies the pending instance transforms like ptc_scene_refit and then builds a NEW tree for the
+ * geometry as it now lies in HBM, ON THE DEVICE (csrc/pt_build.hip): 63-bit Morton codes, LDS radix sort, the radix tree, bottom-up boxes and collapse
+ * costs, the same cost-optimal 8-wide collapse, octant slots, quantisation and unit layout as the host's LBVH builder (PTC_BVH_LBVH) — the bytes a
+ * fresh ptc_scene_commit of the moved scene with that builder would upload (tests/test_gpu_parity.py compares them), in milliseconds and without
+ * the description crossing the bus again.  The image does not depend on the tree; counters and speed are those of the new tree.  Whatever builder
+ * the commit used, the rebuilt tree is the LBVH.  Needs a device; PTC_E_STATE before the first commit; a move that changes which triangles are
+ * emitters falls back to a host build + upload (as ptc_scene_refit does).  ptc_stats.bvh_sa_cost / bvh_sa_cost_built say when it is worth calling. */
+int ptc_scene_rebuild(ptc_ctx*);
 
 /* pbr::makeCameraData (engine/pbr/CameraData.hpp:22-32): lookAtRH(pos,target,up=(0,-1,0)),
  * perspective fovY/aspect; y-down un-flipped viewport (PbrRenderSystem.cpp:425-430). */

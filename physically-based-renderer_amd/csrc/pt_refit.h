@@ -42,6 +42,8 @@ struct DevRefit {     // device copies of the plan and the scratch arrays; owned
   float* wbt;                   // world bitangent, 3 floats per world vertex
   float* nbox;                  // 6 floats per 64-byte record of the unit array: box of the node at unit address 4*i (written deepest level first)
   uint32_t* bounds;             // [0..5] scene box lo.xyz hi.xyz as order-preserving integers (atomic min / max), [6] non-finite flag, [7] pad
+  unsigned long long* cost;     // surface-area cost of the tree (ptc_stats.bvh_sa_cost) in units of 2^-20, summed by the node pass
+  const uint32_t* prim_cls;     // material class per primitive (word 7 of its triangle record): what a rebuild (pt_build.hip) writes into the new records
   float4* recs; float4* shade;  // the scene's arrays, rewritten in place
   uint32_t n_verts, n_tris, shade_stride;
 };
@@ -49,4 +51,7 @@ struct DevRefit {     // device copies of the plan and the scratch arrays; owned
 void pt_launch_refit_geometry(hipStream_t, const DevRefit&);
 void pt_refit_decode_bounds(const uint32_t raw[8], float lo[3], float hi[3], bool* non_finite);
 // nodes and triangle records, level by level from the leaves up
-void pt_launch_refit_nodes(hipStream_t, const DevRefit&, const std::vector<uint32_t>& level_first, const float grid_lo[3], const float grid_step[3]);
+// scene_half_area: half area of the scene box (the denominator of the cost sum; <= 0: no sum)
+void pt_launch_refit_nodes(hipStream_t, const DevRefit&, const std::vector<uint32_t>& level_first, const float grid_lo[3], const float grid_step[3], float scene_half_area);
+// the cost term of one child slot in units of 2^-20 (shared by the host build, which sums the same terms)
+#define PTC_SA_COST_ONE 1048576.0f

@@ -131,9 +131,10 @@ __device__ inline void write_triangle(const DevRefit& r, uint32_t at, const floa
   r.recs[at + 2] = make_float4(c[0] - a[0], c[1] - a[1], c[2] - a[2], 0.0f);
 }
 
-__global__ __launch_bounds__(kNodeBlock) void k_refit_nodes(const DevRefit r, uint32_t first, uint32_t count, float glx, float gly, float glz, float gsx, float gsy, float gsz) {
+__global__ __launch_bounds__(kNodeBlock) void k_refit_nodes(const DevRefit r, uint32_t first, uint32_t count, float glx, float gly, float glz, float gsx, float gsy, float gsz, float scene_area) {
   const uint32_t i = blockIdx.x * kNodeBlock + threadIdx.x;
-  if (i >= count) return;
+  unsigned long long my_cost = 0ull;
+  if (i < count) {
   const uint32_t addr = r.level_nodes[first + i];
   const uint4 head = reinterpret_cast<const uint4*>(r.recs)[addr];
   const uint32_t imask = (head.z >> 8) & 255u, lmask = (head.z >> 16) & 255u, two = (head.z >> 24) & 255u, block = head.w;
@@ -228,6 +229,20 @@ __global__ __launch_bounds__(kNodeBlock) void k_refit_nodes(const DevRefit r, ui
   out[3] = make_uint4(whi[1][0], whi[1][1], whi[2][0], whi[2][1]);
   float* nb = r.nbox + (size_t)(addr >> 2) * 6;
   for (int k = 0; k < 6; ++k) nb[k] = nbx[k];
+  // surface-area cost of this node's children (ptc_stats.bvh_sa_cost): half_area(child) / half_area(scene) per used slot, a two-triangle leaf twice
+  if (scene_area > 0.0f) {
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) {
+      if (!((used >> sl) & 1u)) continue;
+      const float ex = chi[0][sl] - clo[0][sl], ey = chi[1][sl] - clo[1][sl], ez = chi[2][sl] - clo[2][sl];
+      const unsigned long long term = (unsigned long long)(((ex * ey + ey * ez + ez * ex) / scene_area) * PTC_SA_COST_ONE);
+      my_cost += ((two >> sl) & 1u) ? 2ull * term : term;
+    }
+  }
+  }
+  // one atomic per wave (a block is one wave): integer sum, the same bits in any order
+  for (int d = 32; d >= 1; d >>= 1) my_cost += __shfl_xor(my_cost, d);
+  if ((threadIdx.x & 63) == 0 && my_cost) atomicAdd(r.cost, my_cost);
 }
 }  // namespace
 
@@ -250,10 +265,11 @@ void pt_refit_decode_bounds(const uint32_t raw[8], float lo[3], float hi[3], boo
   *non_finite = raw[6] != 0u;
 }
 
-void pt_launch_refit_nodes(hipStream_t st, const DevRefit& r, const std::vector<uint32_t>& level_first, const float gl[3], const float gs[3]) {
+void pt_launch_refit_nodes(hipStream_t st, const DevRefit& r, const std::vector<uint32_t>& level_first, const float gl[3], const float gs[3], float scene_area) {
+  (void)hipMemsetAsync(r.cost, 0, sizeof(unsigned long long), st);
   for (size_t l = 0; l + 1 < level_first.size(); ++l) {
     const uint32_t first = level_first[l], count = level_first[l + 1] - first;
     if (!count) continue;
-    hipLaunchKernelGGL(k_refit_nodes, dim3((count + kNodeBlock - 1) / kNodeBlock), dim3(kNodeBlock), 0, st, r, first, count, gl[0], gl[1], gl[2], gs[0], gs[1], gs[2]);
+    hipLaunchKernelGGL(k_refit_nodes, dim3((count + kNodeBlock - 1) / kNodeBlock), dim3(kNodeBlock), 0, st, r, first, count, gl[0], gl[1], gl[2], gs[0], gs[1], gs[2], scene_area);
   }
 }

@@ -11,6 +11,7 @@
 #include "../../include/ptc.h"
 #include "ptc_internal.h"
 #include "pt_refit.h"
+#include "pt_build.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -125,6 +126,7 @@ struct ptc_ctx {
                                     // -5 % .. -17 % frame time from 16 spp down to 1 spp at 1080p (profiles/r03_viewer_loop.txt); 2 = every batch (+0.4 % at the benchmark's
                                     // batch size, but the two kernels' launch durations then include each other: not the default, so that what bench.py and rocprofv3 time
                                     // per kernel stays a kernel's own time); 0 = never
+  BuildScratch bscratch;            // device scratch of ptc_scene_rebuild (pt_build.hip), grow-only
   std::vector<float> xf_live;       // instance transforms of the last refit the device completed (a refused one re-flattens its scratch vertices from these)
   // lanes: lane 0 is the context's primary stream (resolve, tonemap, conversions, the reduce)
   std::vector<Lane> lanes;
@@ -565,6 +567,7 @@ void ptc_destroy(ptc_ctx* c) {
     if (ln.q.stats) (void)hipFree(ln.q.stats);
     if (ln.q.seg_ray[0]) (void)hipFree(ln.q.seg_ray[0]);
     if (ln.d_scene) (void)hipFree(ln.d_scene);
+    if (c->bscratch.p) { (void)hipFree(c->bscratch.p); c->bscratch = BuildScratch(); }
     if (ln.stream) (void)hipStreamDestroy(ln.stream);
     if (ln.stream2) (void)hipStreamDestroy(ln.stream2);
     for (hipEvent_t e : ln.ev_scan) (void)hipEventDestroy(e);
@@ -694,6 +697,8 @@ int ensure_refit_plan(ptc_ctx* c) {
   if (!rc) rc = dev_alloc(c, c->scene_allocs, &d.wbt, (size_t)P.n_verts * 3);
   if (!rc) rc = dev_alloc(c, c->scene_allocs, &d.nbox, (size_t)(B.n_units / 4u + 1u) * 6);
   if (!rc) rc = dev_alloc(c, c->scene_allocs, &d.bounds, 8);
+  if (!rc) rc = dev_alloc(c, c->scene_allocs, &d.cost, 1);
+  if (!rc) { std::vector<uint32_t> cls; ptc_prim_classes(c->mats, B.tri_mat, cls); rc = dev_upload(c, c->scene_allocs, &d.prim_cls, cls); }
   if (rc) return rc;
   d.recs = const_cast<float4*>(c->dsc.recs); d.shade = const_cast<float4*>(c->dsc.shade);
   d.n_verts = P.n_verts; d.n_tris = P.n_tris; d.shade_stride = B.shade_stride;
@@ -715,6 +720,11 @@ bool description_matches_commit(const ptc_ctx* c) {
   return nv == c->built->wverts.size() && nt == c->built->n_tris;
 }
 const char* const kDescriptionChanged = "scene_refit: the scene's meshes or instances changed since the commit (only transforms may)";
+
+float scene_half_area(const float lo[3], const float hi[3]) {      // the host's box_half_area of the scene box
+  const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+  return ex * ey + ey * ez + ez * ex;
+}
 
 // Refit on the device.  Returns PTC_OK, an error, or +1: "not this way" (the set of emitters changed) — the caller refits on the host.
 // may_write_built: c->built is this context's own, or a group's fresh copy every member writes the same values to.
@@ -742,8 +752,10 @@ int device_refit(ptc_ctx* c) {
   }
   HostBuilt& B = *c->built;
   ptc_refit_grid(lo, hi, B.grid_lo, B.grid_step, &B.ray_eps);
-  pt_launch_refit_nodes(st, d, c->plan.level_first, B.grid_lo, B.grid_step);
+  pt_launch_refit_nodes(st, d, c->plan.level_first, B.grid_lo, B.grid_step, scene_half_area(lo, hi));
   HIP_TRY(c, hipGetLastError());
+  unsigned long long cost_fixed = 0;
+  HIP_TRY(c, hipMemcpyAsync(&cost_fixed, d.cost, sizeof cost_fixed, hipMemcpyDeviceToHost, st));
   B.lights = lights; B.cdf = cdf;
   HIP_TRY(c, hipMemcpyAsync((void*)c->dsc.lights, B.lights.data(), B.lights.size() * 4, hipMemcpyHostToDevice, st));
   HIP_TRY(c, hipMemcpyAsync((void*)c->dsc.cdf, B.cdf.data(), B.cdf.size() * 4, hipMemcpyHostToDevice, st));
@@ -754,6 +766,100 @@ int device_refit(ptc_ctx* c) {
     HIP_TRY(c, hipMemcpyAsync(c->lanes[(size_t)l].d_scene, &ds, sizeof ds, hipMemcpyHostToDevice, st));
   }
   HIP_TRY(c, hipStreamSynchronize(st));
+  B.sa_cost_fixed = cost_fixed;
+  c->stats.bvh_sa_cost = (double)cost_fixed / (double)PTC_SA_COST_ONE;
+  c->host_stale = true; c->last_refit_on_device = true;
+  c->xf_live.swap(xf);
+  return PTC_OK;
+}
+
+// scene_allocs bookkeeping of ptc_scene_rebuild: an array of the committed scene is replaced
+void scene_free(ptc_ctx* c, const void* p) {
+  if (!p) return;
+  auto it = std::find(c->scene_allocs.begin(), c->scene_allocs.end(), const_cast<void*>(p));
+  if (it != c->scene_allocs.end()) { (void)hipFree(*it); c->scene_allocs.erase(it); }
+}
+
+// ptc_scene_rebuild on the device: a refit's geometry pass, then a NEW tree for the vertices as they now lie in HBM (pt_build.hip), then the refit's node pass over
+// it.  Returns PTC_OK, an error, or +1: "not this way" (the set of emitters changed, fewer than two triangles): the caller builds on the host.
+int device_rebuild(ptc_ctx* c) {
+  { int rc = ensure_refit_plan(c); if (rc) return rc; }
+  if (c->built->n_tris < 2u) return 1;
+  std::vector<float> xf, lights, cdf;
+  if (!ptc_refit_instance_transforms(c->insts, xf)) return fail(c, PTC_E_STATE, "scene_commit: non-finite vertex position after the instance transform");
+  if (!ptc_refit_emitters(c->mats, c->meshes, c->insts, c->plan, *c->built, lights, cdf)) return 1;
+  hipStream_t st = c->lanes[0].stream;
+  DevRefit& d = c->drf;
+  HIP_TRY(c, hipMemcpyAsync(d.inst_xf, xf.data(), xf.size() * 4, hipMemcpyHostToDevice, st));
+  pt_launch_refit_geometry(st, d);
+  uint32_t raw[8];
+  HIP_TRY(c, hipMemcpyAsync(raw, d.bounds, sizeof raw, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipStreamSynchronize(st));
+  float lo[3], hi[3]; bool bad = false;
+  pt_refit_decode_bounds(raw, lo, hi, &bad);
+  if (bad) {
+    if (!c->xf_live.empty()) {
+      HIP_TRY(c, hipMemcpyAsync(d.inst_xf, c->xf_live.data(), c->xf_live.size() * 4, hipMemcpyHostToDevice, st));
+      pt_launch_refit_geometry(st, d);
+      HIP_TRY(c, hipStreamSynchronize(st));
+    }
+    return fail(c, PTC_E_STATE, "scene_commit: non-finite vertex position after the instance transform");
+  }
+  BuildOut out;
+  const std::string e = pt_build_lbvh(st, d.wverts, d.widx, d.prim_cls, d.n_tris, c->toplet_budget, c->bscratch, out);
+  if (!e.empty()) return fail(c, PTC_E_DEVICE, e);
+  // the new tree replaces the old one: unit array, the refit's level lists, the per-record boxes
+  float* nbox = nullptr;
+  if (hipMalloc((void**)&nbox, ((size_t)(out.n_units / 4u + 1u) * 6) * sizeof(float)) != hipSuccess) { (void)hipFree(out.recs); (void)hipFree(out.level_nodes); return fail(c, PTC_E_NOMEM, "scene_rebuild: out of device memory"); }
+  scene_free(c, c->dsc.recs); scene_free(c, d.level_nodes); scene_free(c, d.nbox);
+  c->scene_allocs.push_back(out.recs); c->scene_allocs.push_back(out.level_nodes); c->scene_allocs.push_back(nbox);
+  d.recs = out.recs; d.level_nodes = out.level_nodes; d.nbox = nbox;
+  c->plan.level_first = out.level_first; c->plan.level_nodes.clear();
+  HostBuilt& B = *c->built;
+  ptc_refit_grid(lo, hi, B.grid_lo, B.grid_step, &B.ray_eps);
+  pt_launch_refit_nodes(st, d, c->plan.level_first, B.grid_lo, B.grid_step, scene_half_area(lo, hi));
+  HIP_TRY(c, hipGetLastError());
+  unsigned long long cost_fixed = 0;
+  HIP_TRY(c, hipMemcpyAsync(&cost_fixed, d.cost, sizeof cost_fixed, hipMemcpyDeviceToHost, st));
+  B.lights = lights; B.cdf = cdf;
+  HIP_TRY(c, hipMemcpyAsync((void*)c->dsc.lights, B.lights.data(), B.lights.size() * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemcpyAsync((void*)c->dsc.cdf, B.cdf.data(), B.cdf.size() * 4, hipMemcpyHostToDevice, st));
+  // the host's picture of the build: sizes follow the new tree, the arrays come back from HBM when somebody asks (refresh_host_copy), and the topology the host
+  // refit needs is gone — the next host-path refit builds from scratch
+  B.n_nodes = out.n_nodes; B.n_units = out.n_units; B.max_depth = out.max_depth; B.n_tri_records = out.n_tri_records;
+  B.n_lds_units = B.n_units < c->toplet_budget * 4u ? B.n_units : c->toplet_budget * 4u;
+  B.recs.assign((size_t)B.n_units * 4, 0.0f);
+  B.topology.reset();
+  c->dsc.recs = out.recs; c->dsc.n_lds_units = B.n_lds_units; c->dsc.ray_eps = B.ray_eps;
+  for (int k = 0; k < 3; ++k) { c->dsc.grid_lo[k] = B.grid_lo[k]; c->dsc.grid_step[k] = B.grid_step[k]; }
+  {   // a deeper tree needs a deeper overflow slab behind the stack entries kept in LDS
+    const int need = (int)B.max_depth + 2;
+    const uint32_t ovf = (uint32_t)(need - c->cfg.stack_lds > 0 ? need - c->cfg.stack_lds : 1);
+    if (ovf > c->dsc.ovf_depth) {
+      const size_t total_waves = (size_t)c->cfg.n_cu * (size_t)c->cfg.trace_blocks_per_cu * (size_t)(pt_trace_block_threads() / 64);
+      for (auto& ln : c->lanes) {
+        uint2* pl = nullptr;
+        scene_free(c, ln.stack_ovf); ln.stack_ovf = nullptr;
+        int rc = dev_alloc(c, c->scene_allocs, &pl, total_waves * ovf * 64);
+        if (rc) return rc;
+        ln.stack_ovf = pl;
+        if (ln.stack_ovf2) {
+          scene_free(c, ln.stack_ovf2); ln.stack_ovf2 = nullptr;
+          if ((rc = dev_alloc(c, c->scene_allocs, &pl, total_waves * ovf * 64))) return rc;
+          ln.stack_ovf2 = pl;
+        }
+      }
+      c->dsc.ovf_depth = ovf;
+    }
+  }
+  for (int l = 0; l < c->n_lanes; ++l) {
+    const DevScene ds = lane_scene(c, l);
+    HIP_TRY(c, hipMemcpyAsync(c->lanes[(size_t)l].d_scene, &ds, sizeof ds, hipMemcpyHostToDevice, st));
+  }
+  HIP_TRY(c, hipStreamSynchronize(st));
+  B.sa_cost_fixed = cost_fixed;
+  c->stats.bvh_sa_cost = c->stats.bvh_sa_cost_built = (double)cost_fixed / (double)PTC_SA_COST_ONE;
+  c->stats.n_bvh_nodes = B.n_nodes; c->stats.bvh_max_depth = B.max_depth;
   c->host_stale = true; c->last_refit_on_device = true;
   c->xf_live.swap(xf);
   return PTC_OK;
@@ -769,6 +875,20 @@ int refresh_host_copy(ptc_ctx* c) {
   HIP_TRY(c, hipMemcpy(B.shade.data(), c->dsc.shade, B.shade.size() * 4, hipMemcpyDeviceToHost));
   HIP_TRY(c, hipMemcpy(B.wverts.data(), c->drf.wverts, B.wverts.size() * sizeof(HostVertex), hipMemcpyDeviceToHost));
   c->host_stale = false;
+  return PTC_OK;
+}
+// A full host build of the description as it stands + upload (what ptc_scene_commit does), keeping what a refit / rebuild keeps of the statistics.
+int host_build_and_upload(ptc_ctx* c, std::chrono::steady_clock::time_point t0, bool as_refit) {
+  auto built = std::make_shared<HostBuilt>();
+  const std::string e = ptc_build_scene(c->mats, c->meshes, c->insts, c->texs, c->env, c->toplet_budget, as_refit ? c->bvh_builder : PTC_BVH_LBVH, *built);
+  if (!e.empty()) return fail(c, PTC_E_STATE, e);
+  const ptc_stats keep = c->stats;
+  c->built = built;
+  const int rc = commit_upload(c, t0);
+  if (rc) return rc;
+  const double dt = c->stats.seconds_commit;
+  c->stats.seconds_commit = keep.seconds_commit; c->stats.seconds_refit = keep.seconds_refit; c->stats.seconds_rebuild = keep.seconds_rebuild;
+  (as_refit ? c->stats.seconds_refit : c->stats.seconds_rebuild) = dt;
   return PTC_OK;
 }
 }  // namespace
@@ -807,17 +927,36 @@ int ptc_scene_refit(ptc_ctx* c) {
       return rd;
     }
   }
+  if (!c->built->topology) return host_build_and_upload(c, t0, /*as_refit=*/true);      // the tree in HBM was built on the device (ptc_scene_rebuild): the host has no topology to refit
   HostBuilt& B = *c->built;
   const size_t n_recs = B.recs.size(), n_shade = B.shade.size(), n_lights = B.lights.size(), n_cdf = B.cdf.size();
   const std::string e = ptc_refit_scene(c->mats, c->meshes, c->insts, c->texs, c->env, B);
   if (!e.empty()) return fail(c, PTC_E_STATE, e);
   c->in_frame = false; c->pending = 0;
   c->stats.n_emitters = B.n_lights;
+  c->stats.bvh_sa_cost = (double)B.sa_cost_fixed / (double)PTC_SA_COST_ONE;
   if (c->device >= 0) {
     int rc = refit_upload(c, B.recs.size() == n_recs && B.shade.size() == n_shade && B.lights.size() == n_lights && B.cdf.size() == n_cdf, t0);
     if (rc) return rc;
   }
   c->stats.seconds_refit = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return PTC_OK;
+}
+
+int ptc_scene_rebuild(ptc_ctx* c) {
+  { int rd = need_device(c); if (rd) return rd; }
+  if (!c->committed) return fail(c, PTC_E_STATE, "scene_rebuild: scene not committed");
+  if (!description_matches_commit(c)) return fail(c, PTC_E_STATE, kDescriptionChanged);
+  { int rf = flush(c); if (rf) return rf; }
+  { int rs = sync_all_lanes(c); if (rs) return rs; }
+  const auto t0 = std::chrono::steady_clock::now();
+  if (c->built.use_count() > 1) c->built = std::make_shared<HostBuilt>(*c->built);      // a group shares one build: this context now gets its own
+  const char* how = std::getenv("PTC_REBUILD");
+  int rd = (how && std::strcmp(how, "host") == 0) ? 1 : device_rebuild(c);
+  if (rd < 0) return rd;
+  if (rd > 0) { if ((rd = host_build_and_upload(c, t0, /*as_refit=*/false))) return rd; }      // PTC_REBUILD=host, an emitter appeared or vanished, a single triangle
+  else c->stats.seconds_rebuild = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  c->in_frame = false; c->pending = 0;
   return PTC_OK;
 }
 
@@ -864,6 +1003,7 @@ int commit_upload(ptc_ctx* c, std::chrono::steady_clock::time_point t0) {
     c->stats.seconds_commit = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     c->stats.n_triangles = c->built->n_tris; c->stats.n_bvh_nodes = c->built->n_nodes; c->stats.n_emitters = c->built->n_lights;
     c->stats.bvh_max_depth = c->built->max_depth;
+    c->stats.bvh_sa_cost = c->stats.bvh_sa_cost_built = (double)c->built->sa_cost_fixed / (double)PTC_SA_COST_ONE;
     return PTC_OK;
   }
   c->committed = false;
@@ -906,6 +1046,7 @@ int commit_upload(ptc_ctx* c, std::chrono::steady_clock::time_point t0) {
   std::memset(&c->stats, 0, sizeof c->stats);
   c->stats.seconds_commit = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   c->stats.n_triangles = B.n_tris; c->stats.n_bvh_nodes = B.n_nodes; c->stats.n_emitters = B.n_lights; c->stats.bvh_max_depth = B.max_depth;
+  c->stats.bvh_sa_cost = c->stats.bvh_sa_cost_built = (double)B.sa_cost_fixed / (double)PTC_SA_COST_ONE;
   return PTC_OK;
 }
 }  // namespace
@@ -993,6 +1134,7 @@ int ptc_frame_begin(ptc_ctx* c, int w, int h, int spp_total, uint64_t seed, int 
   std::memset(&c->stats, 0, sizeof c->stats);
   c->stats.seconds_commit = keep.seconds_commit; c->stats.seconds_refit = keep.seconds_refit; c->stats.n_triangles = keep.n_triangles; c->stats.n_bvh_nodes = keep.n_bvh_nodes;
   c->stats.n_emitters = keep.n_emitters; c->stats.bvh_max_depth = keep.bvh_max_depth;
+  c->stats.bvh_sa_cost = keep.bvh_sa_cost; c->stats.bvh_sa_cost_built = keep.bvh_sa_cost_built; c->stats.seconds_rebuild = keep.seconds_rebuild;
   c->in_frame = true;
   return PTC_OK;
 }

@@ -163,6 +163,7 @@ struct HostBuilt {
   std::vector<float> cdf;
   uint32_t n_nodes = 0, n_tris = 0, n_tri_records = 0, n_lights = 0, max_depth = 0, n_units = 0, n_lds_units = 0;
   float ray_eps = 0.0f;
+  uint64_t sa_cost_fixed = 0;    // surface-area cost of the 8-wide tree in units of 2^-20 (ptc_stats.bvh_sa_cost; the device refit sums the same terms: pt_refit.hip)
   std::shared_ptr<void> topology;   // what ptc_refit_scene keeps of the build (ptc_scene.cpp: Topology)
 };
 
@@ -173,6 +174,8 @@ std::string ptc_build_scene(const std::vector<HostMaterial>&, const std::vector<
 // the instances' matrices changed since ptc_build_scene filled `out`: same tree, new boxes / records (ptc_scene.cpp)
 std::string ptc_refit_scene(const std::vector<HostMaterial>&, const std::vector<HostMesh>&, const std::vector<HostInstance>&,
                             const std::vector<HostTexture>&, const HostEnv&, HostBuilt& out);
+// material class of every primitive (word 7 of its triangle record; ptc_scene.cpp, "texture sets and material classes")
+void ptc_prim_classes(const std::vector<HostMaterial>&, const std::vector<int32_t>& tri_mat, std::vector<uint32_t>& out);
 void ptc_trs_to_matrix(const float t[3], const float q_wxyz[4], const float s[3], float m16[16]);
 void ptc_make_camera(const float pos[3], const float target[3], float fov, float aspect, DevCamera& cam);
 // pixels owned by (rank,count) in tile-Morton order

@@ -987,9 +987,20 @@ std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vec
   for (int k = 0; k < 3; ++k) { const float st = (sb.hi[k] - sb.lo[k]) / 65535.0f; grid_step[k] = st > 0.0f ? st : 1.0f; B.grid_lo[k] = sb.lo[k]; B.grid_step[k] = grid_step[k]; }
   uint32_t maxd = 0;
   for (uint32_t idx = 0; idx < B.n_nodes; ++idx) if (order[idx].depth > maxd) maxd = order[idx].depth;
+  // surface-area cost of the tree (ptc_stats.bvh_sa_cost): per used child slot half_area(child) / half_area(scene), a two-triangle leaf twice, each term
+  // truncated to 2^-20 and summed as an integer — the terms and the sum k_refit_nodes forms on the device (pt_refit.hip)
+  std::atomic<uint64_t> sa_cost{0};
+  const float scene_area = box_half_area(sb);
   parallel_for(B.n_nodes, 1024, [&](size_t n0, size_t n1) {
+  uint64_t cost_part = 0;
   for (uint32_t idx = (uint32_t)n0; idx < (uint32_t)n1; ++idx) {
     const Wide& w = wide[idx];
+    if (scene_area > 0.0f)
+      for (int sl = 0; sl < kWide; ++sl) {
+        if (!w.used[sl]) continue;
+        const uint64_t term = (uint64_t)((box_half_area(w.slot[sl].box) / scene_area) * PTC_SA_COST_ONE);
+        cost_part += (w.slot[sl].leaf && w.slot[sl].hi - w.slot[sl].lo + 1u == 2u) ? 2u * term : term;
+      }
     uint32_t word[kNodeWords] = {0};
     uint32_t e[3], oq[3], qlo[3][kWide], qhi[3][kWide];
     int sl_of[kWide], nk = 0;                      // used slots in ascending order
@@ -1034,7 +1045,9 @@ std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vec
     }
     std::memcpy(&B.recs[(size_t)node_addr[idx] * 4], word, sizeof word);
   }
+  sa_cost.fetch_add(cost_part);
   });
+  B.sa_cost_fixed = sa_cost.load();
   lap("emit nodes + triangles");
   B.max_depth = maxd;
   B.n_tri_records = n_tri_records;
@@ -1232,6 +1245,26 @@ std::string ptc_refit_scene(const std::vector<HostMaterial>& mats, const std::ve
 }
 
 // ---- the host's share of a refit on the device (pt_refit.h) -----------------------------------------------------------------------
+void ptc_prim_classes(const std::vector<HostMaterial>& mats, const std::vector<int32_t>& tri_mat, std::vector<uint32_t>& out) {
+  // as build_or_refit numbers them: a texture SET is a distinct (colour, normal, metal-rough) triple among the textured materials, in material order
+  std::vector<int32_t> mat_set(mats.size(), -1), set_tex;
+  for (size_t i = 0; i < mats.size(); ++i) {
+    const HostMaterial& m = mats[i];
+    if (m.tex_color < 0 && m.tex_normal < 0 && m.tex_mr < 0) continue;
+    int32_t found = -1;
+    for (size_t k = 0; k * 3 < set_tex.size(); ++k)
+      if (set_tex[k * 3] == m.tex_color && set_tex[k * 3 + 1] == m.tex_normal && set_tex[k * 3 + 2] == m.tex_mr) { found = (int32_t)k; break; }
+    if (found < 0) { found = (int32_t)(set_tex.size() / 3); set_tex.push_back(m.tex_color); set_tex.push_back(m.tex_normal); set_tex.push_back(m.tex_mr); }
+    mat_set[i] = found;
+  }
+  out.resize(tri_mat.size());
+  for (size_t p = 0; p < tri_mat.size(); ++p) {
+    const size_t mi = (size_t)tri_mat[p];
+    const HostMaterial& hm = mats[mi];
+    out[p] = mat_set[mi] >= 0 ? 2u + (uint32_t)mat_set[mi] % 5u : ((hm.metallic == 0.0f && hm.roughness >= 1.0f) ? 0u : 1u);
+  }
+}
+
 void ptc_refit_plan(const std::vector<HostMaterial>& mats, const std::vector<HostMesh>& meshes, const std::vector<HostInstance>& insts, const HostBuilt& B, RefitPlan& P) {
   P = RefitPlan();
   const Topology& topo = *std::static_pointer_cast<Topology>(B.topology);

@@ -25,12 +25,12 @@ INTEGRATOR_PATH = 0
 INTEGRATOR_RASTER_COMPAT = 1
 INTEGRATOR_RASTER_GBUFFER16 = 2   # raster-compat lit from the reference's G-buffer formats (RGBA16F P/N, UNORM16 albedo)
 COMM_ID_BYTES = 128
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every symbol include/ptc.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "ptc_create", "ptc_destroy", "ptc_last_error", "ptc_abi_version", "ptc_build_info", "ptc_scene_begin", "ptc_add_material",
-    "ptc_add_texture_rgba8", "ptc_add_mesh", "ptc_add_instance", "ptc_add_instance_matrix", "ptc_update_instance", "ptc_update_instance_matrix", "ptc_scene_refit", "ptc_set_camera", "ptc_set_env_latlong_rgb32f", "ptc_set_texture_filter", "ptc_set_bvh_builder", "ptc_scene_commit", "ptc_render",
+    "ptc_add_texture_rgba8", "ptc_add_mesh", "ptc_add_instance", "ptc_add_instance_matrix", "ptc_update_instance", "ptc_update_instance_matrix", "ptc_scene_refit", "ptc_scene_rebuild", "ptc_set_camera", "ptc_set_env_latlong_rgb32f", "ptc_set_texture_filter", "ptc_set_bvh_builder", "ptc_scene_commit", "ptc_render",
     "ptc_frame_begin", "ptc_frame_add_samples", "ptc_frame_reserve", "ptc_frame_resolve", "ptc_frame_checkpoint", "ptc_frame_restore", "ptc_frame_set_sample_range", "ptc_sync", "ptc_read_radiance_rgba32f",
     "ptc_radiance_device_ptr", "ptc_write_radiance_rgba32f", "ptc_tonemap_rgba8", "ptc_get_stats",
     "ptc_debug_trace_closest", "ptc_debug_trace_any", "ptc_debug_get_flat_scene", "ptc_debug_get_bvh", "ptc_debug_get_counters",
@@ -50,6 +50,7 @@ class PtcStats(C.Structure):
         ("seconds_shade", C.c_double), ("seconds_commit", C.c_double), ("seconds_reduce", C.c_double), ("seconds_refit", C.c_double),
         ("launches_trace_closest", C.c_uint32), ("launches_trace_any", C.c_uint32),
         ("n_triangles", C.c_uint32), ("n_bvh_nodes", C.c_uint32), ("n_emitters", C.c_uint32), ("bvh_max_depth", C.c_uint32),
+        ("bvh_sa_cost", C.c_double), ("bvh_sa_cost_built", C.c_double), ("seconds_rebuild", C.c_double),
     ]
 
     def as_dict(self):
@@ -91,6 +92,7 @@ def load_library():
     L.ptc_update_instance.argtypes = [vp, C.c_int, fp, fp, fp]
     L.ptc_update_instance_matrix.argtypes = [vp, C.c_int, fp]
     L.ptc_scene_refit.argtypes = [vp]
+    L.ptc_scene_rebuild.argtypes = [vp]
     L.ptc_set_camera.argtypes = [vp, fp, fp, C.c_float, C.c_float]
     L.ptc_set_env_latlong_rgb32f.argtypes = [vp, fp, C.c_int, C.c_int]
     L.ptc_set_texture_filter.argtypes = [vp, C.c_int]
@@ -231,6 +233,11 @@ class PathTracer:
 
     def scene_refit(self):
         self._ck(self._L.ptc_scene_refit(self._h))
+        return self
+
+    def scene_rebuild(self):
+        """ptc_scene_rebuild: pending transforms + a new LBVH for the moved geometry, built on the device."""
+        self._ck(self._L.ptc_scene_rebuild(self._h))
         return self
 
     # ---- rendering --------------------------------------------------------------------------------

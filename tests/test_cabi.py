@@ -18,11 +18,11 @@ def test_library_exports_every_declared_symbol(pbr):
     for sym in declared:
         assert hasattr(L, sym), f"libptc.so does not export {sym}"
     assert sorted(pbr.ptc.ABI_SYMBOLS) == declared
-    assert L.ptc_abi_version() == pbr.ptc.ABI_VERSION == 3
+    assert L.ptc_abi_version() == pbr.ptc.ABI_VERSION == 4
     gl = open(os.path.join(ROOT, "include", "ptc_gltf.h")).read()
     for sym in set(re.findall(r"\b(ptc_(?:gltf|png)_[a-z0-9_]+)\s*\(", gl)):
         assert hasattr(pbr.gltf._load(), sym), f"libptc_gltf.so does not export {sym}"
-    assert C.sizeof(pbr.ptc.PtcStats) == 9 * 8 + 7 * 8 + 6 * 4
+    assert C.sizeof(pbr.ptc.PtcStats) == 9 * 8 + 7 * 8 + 6 * 4 + 3 * 8
 
 
 def test_no_cpu_fallback(pbr):

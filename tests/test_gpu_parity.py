@@ -692,6 +692,84 @@ def test_refit_on_the_device_writes_the_bytes_of_the_host_refit(gpu, name, kw, b
     print(f"{name}: commit {dev.stats()['seconds_commit'] * 1e3:.1f} ms, refit on the device {dev.stats()['seconds_refit'] * 1e3:.2f} ms")
 
 
+def _coincident_scene(gpu):
+    """300 triangles of which 200 share one box centre (one Morton code): the LBVH tells them apart by their sorted position."""
+    sc = gpu.scene
+    d = gpu.scenes.cornell_box()
+    rng = np.random.default_rng(5)
+    cents = np.concatenate([np.tile([[0.1, 0.2, -0.3]], (200, 1)), rng.uniform(-0.8, 0.8, (100, 3))])
+    n, e = len(cents), 0.04
+    pos = np.zeros((3 * n, 3), np.float32)
+    pos[0::3], pos[1::3], pos[2::3] = cents + (-e, -e, 0), cents + (e, -e, 0), cents + (0, e, 0)
+    v = np.zeros(3 * n, sc.MESH_VERTEX)
+    v["position"], v["normal"], v["tangent"] = pos, (0, 0, 1), (1, 0, 0, 1)
+    return sc.SceneDesc(d.materials, [sc.MeshDesc(v, np.arange(3 * n, dtype=np.uint32), 0), d.meshes[5]],
+                        [sc.InstanceDesc(0, (0, 0, 0), (1, 0, 0, 0), (1, 1, 1)), sc.InstanceDesc(1, (0, 0, 0), (1, 0, 0, 0), (1, 1, 1))], d.camera, "coincident")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kw,commit_builder", [("cornell", {}, "lbvh"), ("sphere10k", {}, "lbvh"), ("atrium", {"scale": 0.05}, "lbvh"), ("atrium", {"scale": 0.05}, "sah"),
+                                                     ("textured_atrium", {"scale": 0.05, "tex_size": 64, "env_size": (64, 32)}, "lbvh"), ("textured_objects", {}, "sah"),
+                                                     ("coincident", {}, "lbvh"), ("atrium", {}, "lbvh")])
+def test_rebuild_on_the_device_writes_the_bytes_of_the_host_lbvh_build(gpu, ora, name, kw, commit_builder):
+    """csrc/pt_build.hip against the host's LBVH builder (which tests/test_host_logic.py holds against the oracle's, tree for tree): ptc_scene_rebuild —
+    Morton keys, LDS radix sort, radix tree, bottom-up boxes and collapse costs, 8-wide collapse, octant slots, layout, then the refit kernels for the
+    planes — leaves in HBM, byte for byte, the unit array, origin grid, shading records, emitter table and vertices that a fresh ptc_scene_commit of
+    the same geometry with PTC_BVH_LBVH computes on the host: right after the commit (whatever builder the commit used), and after the instances
+    have moved.  The 249,936-triangle atrium is in the list at full size; `coincident` has 200 triangles with one Morton code."""
+    import copy
+    d = copy.deepcopy(_coincident_scene(gpu) if name == "coincident" else gpu.scenes.by_name(name, **kw))
+    d.bvh_builder = commit_builder
+    dev = gpu.PathTracer(0).load_scene(d)
+    d_l = copy.deepcopy(d); d_l.bvh_builder = "lbvh"
+    want = _scene_bytes(gpu.PathTracer(gpu.DEVICE_NONE).load_scene(d_l))
+    w, h = 96, 54
+    img0 = dev.render(w, h, 2, seed=7, max_bounces=4)
+    dev.scene_rebuild()
+    got = _scene_bytes(dev)
+    for key in want:
+        assert want[key].shape == got[key].shape and np.array_equal(want[key], got[key]), f"{key} differs in {int((want[key] != got[key]).sum()) if want[key].shape == got[key].shape else -1} words"
+    st = dev.stats()
+    assert st["seconds_rebuild"] > 0.0 and st["bvh_sa_cost"] == st["bvh_sa_cost_built"] > 0.0
+    assert _bits_equal(dev.render(w, h, 2, seed=7, max_bounces=4), img0), "the image does not depend on the tree"
+    # move, refit (the cost figure follows the refitted boxes), rebuild: the bytes of a fresh LBVH commit of the moved scene
+    rng = np.random.default_rng(3)
+    for i, it in enumerate(d_l.instances):
+        if i % 3 == 0:
+            a = 1.3 + 0.1 * i
+            ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+            if getattr(it, "matrix", None) is not None:
+                r = np.eye(4, dtype=np.float32); r[0, 0] = r[2, 2] = math.cos(a); r[0, 2] = -math.sin(a); r[2, 0] = math.sin(a)
+                it.matrix = (np.asarray(it.matrix, np.float32).reshape(4, 4) @ r).astype(np.float32).reshape(16)
+                dev.update_instance(i, matrix=it.matrix)
+            else:
+                it.q_wxyz = (math.cos(a / 2), *(math.sin(a / 2) * ax))
+                it.s = tuple(np.float32(x) * np.float32(1.0 + 0.2 * (k == 1)) for k, x in enumerate(it.s))
+                dev.update_instance(i, it.t, it.q_wxyz, it.s)
+    dev.scene_refit()
+    refit_cost, built_cost = dev.stats()["bvh_sa_cost"], dev.stats()["bvh_sa_cost_built"]
+    assert built_cost == st["bvh_sa_cost_built"] and refit_cost > 0.0
+    o = ora.Oracle().load_scene(d_l)
+    ref = o.render(w, h, 2, seed=7, max_bounces=4)
+    assert _bits_equal(dev.render(w, h, 2, seed=7, max_bounces=4), ref)
+    dev.scene_rebuild()
+    want = _scene_bytes(gpu.PathTracer(gpu.DEVICE_NONE).load_scene(d_l))
+    got = _scene_bytes(dev)
+    for key in want:
+        assert want[key].shape == got[key].shape and np.array_equal(want[key], got[key]), f"after the move: {key} differs"
+    g = dev.render(w, h, 2, seed=7, max_bounces=4)
+    assert _bits_equal(g, ref)
+    sg, so = dev.stats(), o.stats()
+    for key in COUNTERS:
+        assert sg[key] == so[key], key                       # the rebuilt tree IS the oracle's LBVH of the moved scene: its traversal counters too
+    # and a refit after the rebuild runs on the device over the new tree
+    dev.scene_refit()
+    assert dev.internals()["refit_on_device"] == 1
+    assert _bits_equal(dev.render(w, h, 2, seed=7, max_bounces=4), ref)
+    print(f"{name}: {st['n_triangles']} triangles, rebuild on the device {dev.stats()['seconds_rebuild'] * 1e3:.2f} ms (commit on the host {st['seconds_commit'] * 1e3:.1f} ms); "
+          f"SA cost built {built_cost:.2f}, refitted after the move {refit_cost:.2f}, rebuilt {sg['bvh_sa_cost_built']:.2f}")
+
+
 @pytest.mark.gpu
 def test_refit_paths_agree_and_fall_back(gpu, ora):
     """PTC_REFIT=host takes the host refit + upload; a move that changes WHICH triangles are emitters (an emitter scaled to zero area) cannot keep

@@ -6,7 +6,7 @@ n=0
 for spec in "$@"; do
   name="${spec%%=*}"; flags="${spec#*=}"
   mkdir -p ../../build/var/$name
-  ( /opt/rocm/bin/hipcc $flags $F -shared -o ../../build/var/$name/libptc.so pt_kernels.hip pt_refit.hip ptc_api.cpp ptc_scene.cpp > ../../build/var/$name/build.log 2>&1 || echo "build failed: $name" ) &
+  ( /opt/rocm/bin/hipcc $flags $F -shared -o ../../build/var/$name/libptc.so pt_kernels.hip pt_refit.hip pt_build.hip ptc_api.cpp ptc_scene.cpp > ../../build/var/$name/build.log 2>&1 || echo "build failed: $name" ) &
   n=$((n+1)); if [ $((n % 6)) -eq 0 ]; then wait; fi
 done
 wait

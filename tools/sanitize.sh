@@ -11,7 +11,7 @@ PKG=$ROOT/physically-based-renderer_amd; ITERS=${1:-4000}
 CLANG=/opt/rocm/lib/llvm/bin/clang++; RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
 SAN="-fsanitize=address,undefined -fno-omit-frame-pointer -g -O1"
 ( cd $PKG/csrc && /opt/rocm/bin/hipcc $SAN -fno-gpu-sanitize --offload-arch=gfx950 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
-    -fno-fast-math -I$ROOT/include -shared -o $OUT/libptc.so pt_kernels.hip pt_refit.hip ptc_api.cpp ptc_scene.cpp )
+    -fno-fast-math -I$ROOT/include -shared -o $OUT/libptc.so pt_kernels.hip pt_refit.hip pt_build.hip ptc_api.cpp ptc_scene.cpp )
 $CLANG $SAN -std=c++17 -fPIC -ffp-contract=off -I$ROOT/include -I$PKG/host -shared -o $OUT/libptc_gltf.so $PKG/host/ptc_gltf.cpp -L$OUT -lptc -Wl,-rpath,$OUT
 cat > $OUT/run_host.py <<P
 import sys
@@ -41,7 +41,7 @@ LD_PRELOAD=$GA ASAN_OPTIONS=detect_leaks=0 python $ROOT/tools/fuzz_jpeg.py $OUT 
 LD_PRELOAD=$GA ASAN_OPTIONS=detect_leaks=0 python $ROOT/tools/fuzz_gltf.py $OUT $ITERS
 mkdir -p $OUT/tsan
 ( cd $PKG/csrc && /opt/rocm/bin/hipcc -fsanitize=thread -fno-gpu-sanitize -g -O1 --offload-arch=gfx950 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
-    -fno-fast-math -I$ROOT/include -shared -o $OUT/tsan/libptc.so pt_kernels.hip pt_refit.hip ptc_api.cpp ptc_scene.cpp )
+    -fno-fast-math -I$ROOT/include -shared -o $OUT/tsan/libptc.so pt_kernels.hip pt_refit.hip pt_build.hip ptc_api.cpp ptc_scene.cpp )
 cat > $OUT/tsan/run.py <<P
 import sys, copy
 sys.path.insert(0, '$ROOT'); sys.path.insert(0, '$PKG')
