@@ -24,8 +24,10 @@ struct BuildScratch {       // device scratch of the build, grow-only, owned by 
   void* p = nullptr; size_t bytes = 0;
 };
 struct BuildOut {
-  float4* recs = nullptr;            // the new unit array (hipMalloc'ed by the build; the caller owns it)
-  uint32_t* level_nodes = nullptr;   // unit addresses of the nodes by depth, deepest level first (the refit's plan; the caller owns it)
+  // in: buffers the caller can spare (or null) and what they hold; out: the buffers the build wrote (the spare ones when they were large enough, else new
+  // ones, 1/8 larger than needed, the spare ones freed).  The caller owns them either way.
+  float4* recs = nullptr; size_t recs_cap = 0;            // the new unit array; capacity in 16-byte units
+  uint32_t* level_nodes = nullptr; size_t level_cap = 0;  // unit addresses of the nodes by depth, deepest level first (the refit's plan); capacity in entries
   std::vector<uint32_t> level_first; // first index into level_nodes of each level (deepest first), plus the end
   uint32_t n_nodes = 0, n_units = 0, max_depth = 0, n_tri_records = 0;
 };

@@ -127,6 +127,9 @@ struct ptc_ctx {
                                     // batch size, but the two kernels' launch durations then include each other: not the default, so that what bench.py and rocprofv3 time
                                     // per kernel stays a kernel's own time); 0 = never
   BuildScratch bscratch;            // device scratch of ptc_scene_rebuild (pt_build.hip), grow-only
+  struct RebuildBufs { float4* recs = nullptr; size_t recs_cap = 0; uint32_t* levels = nullptr; size_t levels_cap = 0; float* nbox = nullptr; size_t nbox_cap = 0; };
+  RebuildBufs rb_spare, rb_live;    // a rebuild writes the new tree into the spare unit array / level list / box array and the ones it replaces become the spare: no
+                                    // allocation in a viewer's steady state (rb_live: capacities of the arrays in use; the spare set is not in scene_allocs)
   std::vector<float> xf_live;       // instance transforms of the last refit the device completed (a refused one re-flattens its scratch vertices from these)
   // lanes: lane 0 is the context's primary stream (resolve, tonemap, conversions, the reduce)
   std::vector<Lane> lanes;
@@ -202,6 +205,12 @@ template <class T> int dev_upload(ptc_ctx* c, std::vector<void*>& owner, const T
   return PTC_OK;
 }
 void free_all(std::vector<void*>& v) { for (void* p : v) (void)hipFree(p); v.clear(); }
+void free_rebuild_spare(ptc_ctx* c) {      // the arrays a rebuild replaced (kept for the next one); the live set is in scene_allocs
+  if (c->rb_spare.recs) (void)hipFree(c->rb_spare.recs);
+  if (c->rb_spare.levels) (void)hipFree(c->rb_spare.levels);
+  if (c->rb_spare.nbox) (void)hipFree(c->rb_spare.nbox);
+  c->rb_spare = ptc_ctx::RebuildBufs(); c->rb_live = ptc_ctx::RebuildBufs();
+}
 
 template <class T> int ensure_buf(ptc_ctx* c, DevBuf<T>& b, size_t n) {
   if (b.n >= n && b.p) return PTC_OK;
@@ -568,6 +577,7 @@ void ptc_destroy(ptc_ctx* c) {
     if (ln.q.seg_ray[0]) (void)hipFree(ln.q.seg_ray[0]);
     if (ln.d_scene) (void)hipFree(ln.d_scene);
     if (c->bscratch.p) { (void)hipFree(c->bscratch.p); c->bscratch = BuildScratch(); }
+    free_rebuild_spare(c);
     if (ln.stream) (void)hipStreamDestroy(ln.stream);
     if (ln.stream2) (void)hipStreamDestroy(ln.stream2);
     for (hipEvent_t e : ln.ev_scan) (void)hipEventDestroy(e);
@@ -805,13 +815,31 @@ int device_rebuild(ptc_ctx* c) {
     }
     return fail(c, PTC_E_STATE, "scene_commit: non-finite vertex position after the instance transform");
   }
+  if (!c->rb_live.recs) {       // first rebuild since the commit: the arrays in use are the commit's, exactly as large as their content
+    c->rb_live.recs = const_cast<float4*>(c->dsc.recs); c->rb_live.recs_cap = c->built->n_units;
+    c->rb_live.levels = const_cast<uint32_t*>(d.level_nodes); c->rb_live.levels_cap = c->built->n_nodes;
+    c->rb_live.nbox = d.nbox; c->rb_live.nbox_cap = (size_t)(c->built->n_units / 4u + 1u) * 6;
+  }
   BuildOut out;
+  out.recs = c->rb_spare.recs; out.recs_cap = c->rb_spare.recs_cap; out.level_nodes = c->rb_spare.levels; out.level_cap = c->rb_spare.levels_cap;
+  c->rb_spare.recs = nullptr; c->rb_spare.levels = nullptr; c->rb_spare.recs_cap = c->rb_spare.levels_cap = 0;      // the build owns them now (it may free them)
   const std::string e = pt_build_lbvh(st, d.wverts, d.widx, d.prim_cls, d.n_tris, c->toplet_budget, c->bscratch, out);
-  if (!e.empty()) return fail(c, PTC_E_DEVICE, e);
-  // the new tree replaces the old one: unit array, the refit's level lists, the per-record boxes
-  float* nbox = nullptr;
-  if (hipMalloc((void**)&nbox, ((size_t)(out.n_units / 4u + 1u) * 6) * sizeof(float)) != hipSuccess) { (void)hipFree(out.recs); (void)hipFree(out.level_nodes); return fail(c, PTC_E_NOMEM, "scene_rebuild: out of device memory"); }
-  scene_free(c, c->dsc.recs); scene_free(c, d.level_nodes); scene_free(c, d.nbox);
+  if (!e.empty()) { if (out.recs) (void)hipFree(out.recs); if (out.level_nodes) (void)hipFree(out.level_nodes); return fail(c, PTC_E_DEVICE, e); }
+  // the new tree replaces the old one: unit array, the refit's level lists, the per-record boxes; the replaced arrays are the next rebuild's spare set
+  const size_t nbox_need = (size_t)(out.n_units / 4u + 1u) * 6;
+  float* nbox = c->rb_spare.nbox; size_t nbox_cap = c->rb_spare.nbox_cap;
+  c->rb_spare.nbox = nullptr; c->rb_spare.nbox_cap = 0;
+  if (!nbox || nbox_cap < nbox_need) {
+    if (nbox) (void)hipFree(nbox);
+    nbox_cap = nbox_need + nbox_need / 8u;
+    if (hipMalloc((void**)&nbox, nbox_cap * sizeof(float)) != hipSuccess) { (void)hipFree(out.recs); (void)hipFree(out.level_nodes); return fail(c, PTC_E_NOMEM, "scene_rebuild: out of device memory"); }
+  }
+  for (void* old : {(void*)c->rb_live.recs, (void*)c->rb_live.levels, (void*)c->rb_live.nbox}) {       // out of the scene's list, not freed
+    auto it = std::find(c->scene_allocs.begin(), c->scene_allocs.end(), old);
+    if (it != c->scene_allocs.end()) c->scene_allocs.erase(it);
+  }
+  c->rb_spare = c->rb_live;
+  c->rb_live.recs = out.recs; c->rb_live.recs_cap = out.recs_cap; c->rb_live.levels = out.level_nodes; c->rb_live.levels_cap = out.level_cap; c->rb_live.nbox = nbox; c->rb_live.nbox_cap = nbox_cap;
   c->scene_allocs.push_back(out.recs); c->scene_allocs.push_back(out.level_nodes); c->scene_allocs.push_back(nbox);
   d.recs = out.recs; d.level_nodes = out.level_nodes; d.nbox = nbox;
   c->plan.level_first = out.level_first; c->plan.level_nodes.clear();
@@ -1008,6 +1036,7 @@ int commit_upload(ptc_ctx* c, std::chrono::steady_clock::time_point t0) {
   }
   c->committed = false;
   free_all(c->scene_allocs);
+  free_rebuild_spare(c);
   c->refit_ready = false; c->host_stale = false; c->plan = RefitPlan(); c->drf = DevRefit{}; c->xf_live.clear();
   for (auto& ln : c->lanes) ln.stack_ovf = nullptr;
   const HostBuilt& B = *c->built;
