@@ -8,10 +8,10 @@
 //   shim::uploadMesh       Asset::loadMesh after builder.build()    src/pbr_engine/gltf/pbr/gltf/Asset.cpp:221-231
 //   shim::uploadNode       Asset::loadNode (TRS -> pbr::Transform)  src/pbr_engine/gltf/pbr/gltf/Asset.cpp:239-244
 //   shim::Frame::record    App::recordCommands' render call         src/gltf_viewer/App.cpp:384-393
-//   shim::Frame::rotate    App::update's per-frame node rotation    src/gltf_viewer/App.cpp:306-313
+//   shim::Frame::rotate    App::update's per-frame node rotation    src/gltf_viewer/App.cpp:306-313   (refit; a rebuild on the device when the refitted tree has become too costly)
 // main() drives them the way App::run does: load, then a loop of displayed frames, one sample per frame while the camera is still.
 //
-// usage: viewer_shim DEVICE [frames]    DEVICE -1 = description only (PTC_DEVICE_NONE): the scene half runs, the render half reports
+// usage: viewer_shim DEVICE [frames [rebuild_ratio]]    DEVICE -1 = description only (PTC_DEVICE_NONE): the scene half runs, the render half reports
 //                                       "no device" and the program still exits 0 — that is what the CPU test runs.
 #include <pbr_pt.hpp>
 
@@ -69,18 +69,31 @@ public:
     ck(_ctx, ptc_read_radiance_rgba16f(_ctx, _staging16.data()));   // the HdrImage's own format (RGBA16F); the TransferStager copies it into _hdrImage
     return true;
   }
-  // App::update rotates every node a little each frame (App.cpp:306-313): new TRS for the instances, then a refit instead of a rebuild
-  void rotate(std::vector<int> const& instances, pbr::Transform const& T) {
+  // App::update rotates every node a little each frame, without bound (App.cpp:306-313): new TRS for the instances, then a REFIT (0.5 ms at 250 k triangles) —
+  // and, because a refit keeps the topology and the octant slots of the geometry the tree was built for, a REBUILD on the device (2 ms) once the refitted
+  // tree's surface-area cost has grown past `rebuildRatio` times what it was when the tree was built (ptc_stats.bvh_sa_cost / bvh_sa_cost_built: on the atrium
+  // a SAH tree refitted to ratio 1.2 — pi/16 of the viewer's rotation — costs what a freshly built LBVH costs: 14.6 node visits per ray against 12.0 at the commit; after a half turn it is 55 — profiles/r04_refit_curve.txt).  The image is the same either way.
+  void rotate(std::vector<int> const& instances, pbr::Transform const& T, double rebuildRatio = 1.2) {
     for (int id : instances) ck(_ctx, ptc_update_instance(_ctx, id, T.position.data(), T.rotation.data(), T.scale.data()));
     ck(_ctx, ptc_scene_refit(_ctx));
+    ptc_stats st;
+    ck(_ctx, ptc_get_stats(_ctx, &st));
+    if (st.bvh_sa_cost_built > 0.0 && st.bvh_sa_cost > rebuildRatio * st.bvh_sa_cost_built) {
+      const int rc = ptc_scene_rebuild(_ctx);
+      if (rc == PTC_E_DEVICE) return;                         // a description-only context has nothing to rebuild on
+      ck(_ctx, rc);
+      ++_rebuilds;
+    }
   }
   [[nodiscard]] auto staging() const -> std::vector<std::uint16_t> const& { return _staging16; }
+  [[nodiscard]] auto rebuilds() const -> int { return _rebuilds; }
 
 private:
   ptc_ctx* _ctx;
   int _w, _h, _budget;
   std::uint64_t _seed;
   bool _begun = false;
+  int _rebuilds = 0;
   std::vector<std::uint16_t> _staging16;
 };
 
@@ -89,6 +102,7 @@ private:
 int main(int argc, char** argv) {
   const int device = argc > 1 ? std::atoi(argv[1]) : PTC_DEVICE_NONE;
   const int frames = argc > 2 ? std::atoi(argv[2]) : 4;
+  const double rebuildRatio = argc > 3 ? std::atof(argv[3]) : 1.2;
   ptc_ctx* ctx = ptc_create(device);
   if (!ctx) { std::fprintf(stderr, "viewer_shim: %s\n", ptc_last_error(nullptr)); return 1; }
   try {
@@ -124,13 +138,14 @@ int main(int argc, char** argv) {
       if (f == frames / 2 && f > 0) {                          // half way: the node turns, as App::update does every frame
         const float a = 0.25f;
         T.rotation = {std::cos(a / 2), 0.0f, 0.0f, std::sin(a / 2)};
-        frame.rotate(instances, T);
+        frame.rotate(instances, T, rebuildRatio);
         changed = true;
       }
       rendered = frame.record(cam, changed);
     }
     if (rendered) for (std::uint16_t h : frame.staging()) sum += (double)h;
-    std::printf("{\"device\": %d, \"triangles\": %u, \"rendered\": %s, \"frames\": %d, \"staging_sum\": %.0f}\n", device, st.n_triangles, rendered ? "true" : "false", frames, sum);
+    std::printf("{\"device\": %d, \"triangles\": %u, \"rendered\": %s, \"frames\": %d, \"staging_sum\": %.0f, \"rebuilds\": %d}\n", device, st.n_triangles, rendered ? "true" : "false", frames, sum,
+                frame.rebuilds());
     if (!rendered) std::printf("viewer_shim: no device (PTC_DEVICE_NONE): scene described and committed, render calls answered PTC_E_DEVICE\n");
   } catch (std::exception const& e) {
     std::fprintf(stderr, "viewer_shim: %s\n", e.what());

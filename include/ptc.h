@@ -93,8 +93,8 @@ typedef struct ptc_stats {
   uint32_t bvh_max_depth;
   /* ABI 4 (round 4): what a moved scene's tree costs, so that a caller can decide when a refit is no longer enough.
    * bvh_sa_cost = the surface-area cost of the 8-wide tree as it lies in HBM: sum over the nodes' child slots of half_area(child box) /
-   * half_area(scene box), a two-triangle leaf counted twice — the expected number of node visits + triangle tests of a random long ray, up to a
-   * constant.  Written by ptc_scene_commit (host build), by every ptc_scene_refit and ptc_scene_rebuild (one reduction inside the node pass, in
+   * half_area(scene box when the tree's topology was made), a two-triangle leaf counted twice — the expected number of node visits + triangle
+   * tests of a random long ray, up to a constant; the unit stays through refits, so the figures of a moving scene can be compared.  Written by ptc_scene_commit (host build), by every ptc_scene_refit and ptc_scene_rebuild (one reduction inside the node pass, in
    * fixed point: the same bits whatever the order).  bvh_sa_cost_built = its value when the tree's TOPOLOGY was made (commit or rebuild): the ratio
    * of the two is what examples/viewer_shim.cpp watches. */
   double bvh_sa_cost;

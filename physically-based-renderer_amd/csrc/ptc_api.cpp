@@ -762,7 +762,7 @@ int device_refit(ptc_ctx* c) {
   }
   HostBuilt& B = *c->built;
   ptc_refit_grid(lo, hi, B.grid_lo, B.grid_step, &B.ray_eps);
-  pt_launch_refit_nodes(st, d, c->plan.level_first, B.grid_lo, B.grid_step, scene_half_area(lo, hi));
+  pt_launch_refit_nodes(st, d, c->plan.level_first, B.grid_lo, B.grid_step, B.sa_unit);      // the cost in the unit of the build: comparable with bvh_sa_cost_built
   HIP_TRY(c, hipGetLastError());
   unsigned long long cost_fixed = 0;
   HIP_TRY(c, hipMemcpyAsync(&cost_fixed, d.cost, sizeof cost_fixed, hipMemcpyDeviceToHost, st));
@@ -845,7 +845,8 @@ int device_rebuild(ptc_ctx* c) {
   c->plan.level_first = out.level_first; c->plan.level_nodes.clear();
   HostBuilt& B = *c->built;
   ptc_refit_grid(lo, hi, B.grid_lo, B.grid_step, &B.ray_eps);
-  pt_launch_refit_nodes(st, d, c->plan.level_first, B.grid_lo, B.grid_step, scene_half_area(lo, hi));
+  B.sa_unit = scene_half_area(lo, hi);                      // a new topology: a new unit of its cost
+  pt_launch_refit_nodes(st, d, c->plan.level_first, B.grid_lo, B.grid_step, B.sa_unit);
   HIP_TRY(c, hipGetLastError());
   unsigned long long cost_fixed = 0;
   HIP_TRY(c, hipMemcpyAsync(&cost_fixed, d.cost, sizeof cost_fixed, hipMemcpyDeviceToHost, st));

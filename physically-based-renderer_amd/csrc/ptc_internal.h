@@ -164,6 +164,8 @@ struct HostBuilt {
   uint32_t n_nodes = 0, n_tris = 0, n_tri_records = 0, n_lights = 0, max_depth = 0, n_units = 0, n_lds_units = 0;
   float ray_eps = 0.0f;
   uint64_t sa_cost_fixed = 0;    // surface-area cost of the 8-wide tree in units of 2^-20 (ptc_stats.bvh_sa_cost; the device refit sums the same terms: pt_refit.hip)
+  float sa_unit = 0.0f;          // its unit: the half area of the scene box WHEN THE TOPOLOGY WAS BUILT (a refit keeps it, so that the cost of a moved scene is in the
+                                 // units of the commit's and the two can be compared; a scene box that grows with the motion would otherwise hide the growth)
   std::shared_ptr<void> topology;   // what ptc_refit_scene keeps of the build (ptc_scene.cpp: Topology)
 };
 

@@ -987,10 +987,11 @@ std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vec
   for (int k = 0; k < 3; ++k) { const float st = (sb.hi[k] - sb.lo[k]) / 65535.0f; grid_step[k] = st > 0.0f ? st : 1.0f; B.grid_lo[k] = sb.lo[k]; B.grid_step[k] = grid_step[k]; }
   uint32_t maxd = 0;
   for (uint32_t idx = 0; idx < B.n_nodes; ++idx) if (order[idx].depth > maxd) maxd = order[idx].depth;
-  // surface-area cost of the tree (ptc_stats.bvh_sa_cost): per used child slot half_area(child) / half_area(scene), a two-triangle leaf twice, each term
+  // surface-area cost of the tree (ptc_stats.bvh_sa_cost): per used child slot half_area(child) / half_area(scene box at build time), a two-triangle leaf twice, each term
   // truncated to 2^-20 and summed as an integer — the terms and the sum k_refit_nodes forms on the device (pt_refit.hip)
   std::atomic<uint64_t> sa_cost{0};
-  const float scene_area = box_half_area(sb);
+  if (!refit) B.sa_unit = box_half_area(sb);
+  const float scene_area = B.sa_unit;
   parallel_for(B.n_nodes, 1024, [&](size_t n0, size_t n1) {
   uint64_t cost_part = 0;
   for (uint32_t idx = (uint32_t)n0; idx < (uint32_t)n1; ++idx) {

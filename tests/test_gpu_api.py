@@ -370,7 +370,12 @@ def test_viewer_shim_renders_progressively_and_refits(gpu):
     r = subprocess.run([exe, "0", "6"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     info = json.loads(r.stdout.strip().splitlines()[0])
-    assert info["rendered"] is True and info["triangles"] == 4 and info["frames"] == 6 and info["staging_sum"] > 0
+    assert info["rendered"] is True and info["triangles"] == 4 and info["frames"] == 6 and info["staging_sum"] > 0 and info["rebuilds"] == 0
+    # the rebuild policy of Frame::rotate, forced (ratio 0: every refit is followed by ptc_scene_rebuild on the device): the same image
+    r2 = subprocess.run([exe, "0", "6", "0"], capture_output=True, text=True, timeout=120)
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    info2 = json.loads(r2.stdout.strip().splitlines()[0])
+    assert info2["rebuilds"] == 1 and info2["staging_sum"] == info["staging_sum"]
 
 
 def test_checkpoint_resume_and_sample_ranges(gpu):

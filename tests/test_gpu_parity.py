@@ -689,6 +689,8 @@ def test_refit_on_the_device_writes_the_bytes_of_the_host_refit(gpu, name, kw, b
         a, b = _scene_bytes(dev), _scene_bytes(host)
         for key in a:
             assert a[key].shape == b[key].shape and np.array_equal(a[key], b[key]), f"turn {turn}: {key} differs in {int((a[key] != b[key]).sum())} words"
+        # the tree's surface-area cost (one fixed-point reduction inside k_refit_nodes) is the host's sum, to the bit, in the unit of the commit
+        assert dev.stats()["bvh_sa_cost"] == host.stats()["bvh_sa_cost"] > 0.0 and dev.stats()["bvh_sa_cost_built"] == host.stats()["bvh_sa_cost_built"]
     print(f"{name}: commit {dev.stats()['seconds_commit'] * 1e3:.1f} ms, refit on the device {dev.stats()['seconds_refit'] * 1e3:.2f} ms")
 
 
