@@ -127,23 +127,23 @@ def main():
 
         from pbr_amd import gltf
 
-        # rank 0 writes the file once; every rank (one process per GPU) loads it through the library's own loader
+        # rank 0 writes the file once and ships its BYTES (2.9 MB): every rank (one process per GPU, possibly on another node's file system) stores them in a
+        # temporary file of its own and loads that through the library's own loader
         box = [None]
-        td = None
+        td = tempfile.TemporaryDirectory()
+        glb = os.path.join(td.name, "bench_scene.glb")
         if rank == 0:
-            td = tempfile.TemporaryDirectory()
-            box[0] = os.path.join(td.name, "bench_scene.glb")
-            gltf.write_glb(desc, box[0])
+            gltf.write_glb(desc, glb)
+            box[0] = open(glb, "rb").read()
         if world > 1:
             dist.broadcast_object_list(box, src=0)
-        glb = box[0]
+            if rank != 0:
+                with open(glb, "wb") as f:
+                    f.write(box[0])
         n_tri, _, _ = gltf.load_into(pt, glb, camera=desc.camera, env=getattr(desc, "env", None))
         assert n_tri == desc.n_triangles, (n_tri, desc.n_triangles)
         scene_source = f"binary glTF ({os.path.getsize(glb) / 1e6:.1f} MB) written from the generator by rank 0, loaded by ptc_gltf_load"
-        if world > 1:
-            dist.barrier()              # nobody is still reading when rank 0 removes the file
-        if td is not None:
-            td.cleanup()
+        td.cleanup()
     # scene dynamics: what a transform change costs (ptc_scene_refit of the unchanged scene re-computes and re-uploads exactly what a real one does)
     pt.scene_refit()                                       # the first one also builds and uploads the refit plan
     pt.scene_refit()
@@ -236,6 +236,9 @@ def main():
         dist.all_reduce(v, op=dist.ReduceOp.SUM)
         tot = {k: float(x) for k, x in zip(keys, v.tolist())}
 
+    # PTC_TRACE_OVERLAP: 2 = every batch, 1 = batches of <= 2^26 paths: closest(b + 1) and any(b) then run beside each other and their event times include each other
+    ov = int(os.environ.get("PTC_TRACE_OVERLAP", "1"))
+    kernel_overlap = bool(ov == 2 or (ov == 1 and pt.internals()["per_batch"] * (args.width * args.height // max(1, tile_count)) <= (1 << 26)))
     # per-rank times, so that a poor scaling point can be attributed: tile imbalance (spread of the kernel sums), the collective
     # (reduce_ms: the collective as each rank's stream sees it, i.e. including the wait for the slowest rank) or launch tails
     per_rank = None
@@ -248,6 +251,9 @@ def main():
         names = ["seconds_trace_closest", "seconds_trace_any", "seconds_shade", "wall", "seconds_reduce", "paths"]
         per_rank = {n: {"min": min(r[i] for r in rows), "max": max(r[i] for r in rows), "ranks": [r[i] for r in rows]} for i, n in enumerate(names)}
         per_rank["reduce_ms"] = {"min": per_rank["seconds_reduce"]["min"] * 1e3, "max": per_rank["seconds_reduce"]["max"] * 1e3}
+        per_rank["reduce_impl"] = reduce_impl
+        per_rank["batches_per_rank"] = d["launches_trace_closest"] / (args.max_bounces + 1)        # wavefront batches this rank issued in the timed region (rank 0's count)
+        per_rank["kernel_seconds_overlap"] = kernel_overlap
 
     if rank == 0:
         paths = args.width * args.height * S * K
@@ -258,13 +264,23 @@ def main():
         # Rooflines of the three kernels that carry the frame, on this rank.  Units are counted by the kernels; the
         # per-unit instruction and HBM-byte figures come from the committed PMC profile of the same workload.
         model_name = "kernel_model.json" if args.workload == "atrium" else "textured_kernel_model.json"
-        model_path = next((p for p in (os.path.join(ROOT, "profiles", f"r{r:02d}_{model_name}") for r in (3, 2)) if os.path.exists(p)), None)
+        model_path = next((p for p in (os.path.join(ROOT, "profiles", f"r{r:02d}_{model_name}") for r in (4, 3, 2)) if os.path.exists(p)), None)
         model = (_load_json(model_path) if model_path else None) or {}
         # The per-unit figures are only as good as the kernels they were measured on: the library carries the sha256 of the kernel sources
         # it was built from (ptc_build_info), the model the sha256 of the sources that were profiled.  A mismatch is reported, not hidden.
         build_info = pbr_amd.load_library().ptc_build_info().decode()
         lib_sha = build_info.rsplit(" ", 1)[-1]
-        model_stale = not model or model.get("kernel_source_sha256") != lib_sha
+        # ... and on the launch policy they were measured under (grid sizing, LDS split, batch size, overlap mode: ptc_launch_policy)
+        policy, policy_defaults = pt.launch_policy(), pbr_amd.load_library().ptc_launch_policy(None).decode()
+        stale_why = []
+        if not model:
+            stale_why.append("no committed kernel model")
+        else:
+            if model.get("kernel_source_sha256") != lib_sha:
+                stale_why.append("kernel sources differ from the profiled ones")
+            if model.get("launch_policy") != policy:
+                stale_why.append("launch policy differs from the profiled run's")
+        model_stale = bool(stale_why)
         valu = _load_json(os.path.join(ROOT, "profiles", "r02_valu_issue.json")) or {}
         ns_per_instr = valu.get("ns_per_instr_per_simd_at_7_waves")
         valu_peak_measured = N_SIMD / ns_per_instr if ns_per_instr else None          # G wave-instr/s
@@ -321,7 +337,8 @@ def main():
         else:   # no committed profile to calibrate from: report the physical side as unknown rather than a byte model as a bound
             roof = {"bound": "valu_issue", "kernel": "k_trace_closest", "achieved": None, "peak": VALU_PEAK_PAPER_GIPS, "unit": "G wave-instr/s", "frac": None, "traffic": None}
         roof.update({"model": os.path.relpath(model_path, ROOT) if model_path else None, "model_commit": model.get("git_commit"),
-                     "model_kernel_sha256": model.get("kernel_source_sha256"), "library_kernel_sha256": lib_sha, "model_stale": model_stale,
+                     "model_kernel_sha256": model.get("kernel_source_sha256"), "library_kernel_sha256": lib_sha, "model_stale": model_stale, "model_stale_why": stale_why,
+                     "model_launch_policy": model.get("launch_policy"),
                      "avg_launch_ms": tc_sec / n_launch * 1e3, "launches": n_launch,
                      "algorithmic_bytes_per_launch": tc_bytes / n_launch,
                      "algorithmic_GBs": tc_bytes / tc_sec / 1e9 if tc_sec > 0 else 0.0,
@@ -351,6 +368,8 @@ def main():
                              if world > 1 else "single GPU"),
             },
             "library": build_info,
+            "launch_policy": policy,
+            "launch_policy_defaults": policy_defaults,
             "roofline": roof,
             "kernels": kernels,
             "whole_frame": whole,
@@ -361,7 +380,7 @@ def main():
             "scene_refit_seconds": refit_seconds,                # ptc_scene_refit on the device (csrc/pt_refit.hip): flatten + shading records + nodes, in place in HBM
             "scene_refit_host_seconds": refit_host_seconds,      # PTC_REFIT=host: the same on the host's thread pool + upload
             "seconds": {"wall": dt, "trace_closest": d["seconds_trace_closest"], "trace_any": d["seconds_trace_any"], "shade": d["seconds_shade"],
-                        "batches": d.get("seconds_render", 0.0)},
+                        "batches": d.get("seconds_render", 0.0), "kernel_times_overlap": kernel_overlap},
             "per_path": {"segments": tot["segments"] / paths, "shadow_rays": tot["shadow_rays"] / paths,
                          "node_visits": (tot["node_visits_closest"] + tot["node_visits_any"]) / paths,
                          "algorithmic_bytes": tot["algorithmic_bytes"] / paths},

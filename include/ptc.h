@@ -118,6 +118,13 @@ int ptc_abi_version(void);
 /* "ptc abi N gfx950 kernels-sha256 <64 hex digits>": the hash is over the kernel sources this library was built from
  * (csrc/Makefile); bench.py compares it with the hash in the committed kernel model its roofline block is calibrated on. */
 const char* ptc_build_info(void);
+/* "name=value ..." of everything that decides how the kernels are launched: their compile-time constants (block sizes, chunk, ring, thresholds), the
+ * context's knobs after the environment was read (lanes, batch size, overlap mode, nodelets, builder ...) and, once a scene is committed on a device, what
+ * followed from them (trace blocks per CU, stack entries in LDS, queue segments).  ctx == NULL: the built-in defaults, no device needed.  A measured
+ * per-kernel figure is only valid for the policy it was measured under: tools/make_kernel_model.py records this string with the profile, bench.py prints
+ * it and reports model_stale when it differs, tests/test_profiles.py fails when the defaults move without a new profile.  The pointer is valid until the
+ * calling thread's next call. */
+const char* ptc_launch_policy(const ptc_ctx*);
 
 /* ---- scene description --------------------------------------------------------------------
  * Replaces gltf::Asset::loadScene → MeshBuilder::build → TransferStager
@@ -290,7 +297,7 @@ int ptc_comm_destroy(ptc_ctx*);
  * before anything is waited for), reduces onto device 0 and syncs: ptc_group_ctx(g, 0) holds the whole frame
  * (ptc_read_radiance_* / ptc_tonemap_rgba8 on it).  ptc_group_create returns NULL on failure (ptc_group_last_error(NULL)). */
 typedef struct ptc_group ptc_group;
-ptc_group* ptc_group_create(const int* device_ids, int n_devices);
+ptc_group* ptc_group_create(const int* device_ids, int n_devices);   /* every id PTC_DEVICE_NONE: a description-only group (no GPU, no RCCL): the host half of the group calls */
 int ptc_group_size(const ptc_group*);
 /* Commit ONE scene to every device of the group: the scene is described on ptc_group_ctx(g, 0) only; this call flattens it and
  * builds the BVH once on the host (unless device 0 has committed it already: that build is then used) and uploads that one build to
@@ -336,6 +343,9 @@ int ptc_debug_get_counters(ptc_ctx*, uint64_t* out, int n);
  * Pass NULL to query sizes only. */
 int ptc_debug_get_bvh(ptc_ctx*, uint32_t* n_nodes, uint32_t* n_tris, uint32_t* n_units, float* units, float grid[6]);
 
+/* Identity (an address, as a number) of the host build the context renders from.  The contexts of a ptc_group share ONE build after
+ * ptc_group_scene_commit / ptc_group_scene_refit (one flatten + BVH build for N devices): equal values say so.  0 for a null context. */
+uint64_t ptc_debug_host_build_id(const ptc_ctx*);
 /* Context internals for tests of the host logic: [0] HIP events created so far, [1] timing spans waiting to be
  * collected, [2] queue capacity (paths) of a lane, [3] samples of one full batch, [4] samples accepted but not yet
  * issued, [5] trace blocks per CU, [6] stack entries per lane kept in LDS, [7] 1 if the last ptc_scene_refit ran on the

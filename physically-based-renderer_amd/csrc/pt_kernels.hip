@@ -1591,6 +1591,13 @@ static size_t trace_lds_bytes(const LaunchCfg& cfg, const DevScene& sc, bool clo
 }
 
 int pt_trace_block_threads() { return TRACE_BLOCK; }
+#define PT_STR2(x) #x
+#define PT_STR(x) PT_STR2(x)
+// the compile-time half of the launch policy (ptc_launch_policy)
+const char* pt_kernel_policy() {
+  return "trace_block=" PT_STR(TRACE_BLOCK) " trace_min_waves=" PT_STR(TRACE_MIN_WAVES) " chunk=" PT_STR(TRACE_CHUNK) " ring=" PT_STR(TRACE_RING) " refill_idle=" PT_STR(TRACE_REFILL_IDLE)
+         " node_min=" PT_STR(TRACE_NODE_MIN) " leaf_extra=" PT_STR(LEAF_EXTRA) " shade_block=" PT_STR(SHADE_BLOCK) " shade_min_waves=" PT_STR(SHADE_MIN_WAVES);
+}
 
 size_t pt_trace_lds_bytes(const LaunchCfg& cfg, const DevScene& sc) { return trace_lds_bytes(cfg, sc, true); }
 

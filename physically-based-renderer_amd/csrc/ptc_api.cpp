@@ -502,6 +502,25 @@ int ptc_abi_version(void) { return PTC_ABI_VERSION; }
 #ifndef PTC_KERNEL_SHA
 #define PTC_KERNEL_SHA "unknown"
 #endif
+// How the library launches: the kernels' compile-time constants, then what the context (or, without one, a fresh context with an empty environment) uses.
+// A roofline figure belongs to a launch policy as much as to a kernel source: tools/make_kernel_model.py records this string, bench.py compares.
+const char* ptc_launch_policy(const ptc_ctx* c) {
+  static thread_local std::string out;
+  static const ptc_ctx defaults;                     // member initialisers = the built-in defaults (ptc_create then reads the environment)
+  const ptc_ctx& x = c ? *c : defaults;
+  char buf[512];
+  std::snprintf(buf, sizeof buf, " | stack_lds_max=6 segments_per_cu_default=64 nodelets=%u lanes=%d batch_paths=%zu trace_overlap=%d(<=2^26 paths) rays_per_lane=%d shade_sort=%d refit=%s bvh=%s",
+                x.toplet_budget, x.n_lanes, x.max_batch_paths, x.trace_overlap, x.trace_rays_per_lane, x.cfg.shade_sort, x.refit_on_device ? "device" : "host",
+                x.bvh_builder == PTC_BVH_LBVH ? "lbvh" : "sah");
+  out = std::string(pt_kernel_policy()) + buf;
+  if (c && c->committed && c->device >= 0) {
+    std::snprintf(buf, sizeof buf, " | trace_blocks_per_cu=%d stack_lds=%d lds_units=%u ovf_depth=%u shade_segments=%d shade_tables_lds=%d", c->cfg.trace_blocks_per_cu, c->cfg.stack_lds,
+                  c->dsc.n_lds_units, c->dsc.ovf_depth, c->cfg.shade_waves, c->cfg.shade_tables_lds);
+    out += buf;
+  }
+  return out.c_str();
+}
+
 const char* ptc_build_info(void) { return "ptc abi " PTC_STR(PTC_ABI_VERSION) " gfx950 kernels-sha256 " PTC_KERNEL_SHA; }
 
 ptc_ctx* ptc_create(int device_id) {
@@ -1374,6 +1393,13 @@ int ptc_comm_destroy(ptc_ctx* c) {
 
 ptc_group* ptc_group_create(const int* device_ids, int n_devices) {
   if (!device_ids || n_devices < 1 || n_devices > 64) { g_create_error = "ptc_group_create: bad argument"; return nullptr; }
+  bool none = true;
+  for (int i = 0; i < n_devices; ++i) none = none && device_ids[i] == PTC_DEVICE_NONE;
+  if (none) {      // a description-only group (every id PTC_DEVICE_NONE): the host half of the group calls — one build shared by all contexts — without GPUs or RCCL
+    ptc_group* g = new ptc_group();
+    for (int i = 0; i < n_devices; ++i) g->ctx.push_back(ptc_create(PTC_DEVICE_NONE));
+    return g;
+  }
   if (!rccl_load()) { g_create_error = g_rccl.err; return nullptr; }
   ptc_group* g = new ptc_group();
   for (int i = 0; i < n_devices; ++i) {
@@ -1400,8 +1426,10 @@ int ptc_group_scene_commit(ptc_group* g) {
   if (rc) { g->err = std::string("device 0: ") + ptc_last_error(c0); return rc; }
   for (size_t i = 1; i < g->ctx.size(); ++i) {
     ptc_ctx* c = g->ctx[i];
-    if (hipSetDevice(c->device) != hipSuccess) { g->err = "ptc_group_scene_commit: hipSetDevice failed"; return PTC_E_DEVICE; }
-    if ((rc = sync_all_lanes(c))) { g->err = "device " + std::to_string(i) + ": " + ptc_last_error(c); return rc; }
+    if (c->device >= 0) {
+      if (hipSetDevice(c->device) != hipSuccess) { g->err = "ptc_group_scene_commit: hipSetDevice failed"; return PTC_E_DEVICE; }
+      if ((rc = sync_all_lanes(c))) { g->err = "device " + std::to_string(i) + ": " + ptc_last_error(c); return rc; }
+    }
     const auto t0 = std::chrono::steady_clock::now();
     // the description travels too (materials are counted from it, a later ptc_scene_commit on this context rebuilds from it)
     c->mats = c0->mats; c->meshes = c0->meshes; c->insts = c0->insts; c->texs = c0->texs; c->env = c0->env;
@@ -1422,12 +1450,13 @@ int ptc_group_scene_refit(ptc_group* g) {
   if (!description_matches_commit(c0)) { g->err = kDescriptionChanged; return PTC_E_STATE; }
   // device 0's instances carry the new transforms (ptc_update_instance* on ptc_group_ctx(g, 0)): one refit on the host, the arrays go to every device
   for (ptc_ctx* c : g->ctx) {
+    if (c->device < 0) continue;
     if (hipSetDevice(c->device) != hipSuccess) { g->err = "ptc_group_scene_refit: hipSetDevice failed"; return PTC_E_DEVICE; }
     int rc = flush(c); if (!rc) rc = sync_all_lanes(c);
     if (rc) { g->err = std::string("ptc_group_scene_refit: ") + ptc_last_error(c); return rc; }
   }
   const auto t0 = std::chrono::steady_clock::now();
-  if (refit_on_device(c0)) {       // every device refits its own copy in place: nothing but the 84 bytes per instance and the emitter table cross the bus
+  if (c0->device >= 0 && refit_on_device(c0)) {       // every device refits its own copy in place: nothing but the 84 bytes per instance and the emitter table cross the bus
     bool host_way = false;
     auto mine = std::make_shared<HostBuilt>(*c0->built);
     for (size_t i = 0; i < g->ctx.size() && !host_way; ++i) {
@@ -1454,11 +1483,11 @@ int ptc_group_scene_refit(ptc_group* g) {
   const bool same = built->recs.size() == n_recs && built->shade.size() == n_shade && built->lights.size() == n_lights && built->cdf.size() == n_cdf;
   for (size_t i = 0; i < g->ctx.size(); ++i) {
     ptc_ctx* c = g->ctx[i];
-    if (hipSetDevice(c->device) != hipSuccess) { g->err = "ptc_group_scene_refit: hipSetDevice failed"; return PTC_E_DEVICE; }
+    if (c->device >= 0 && hipSetDevice(c->device) != hipSuccess) { g->err = "ptc_group_scene_refit: hipSetDevice failed"; return PTC_E_DEVICE; }
     if (i) c->insts = c0->insts;
     c->built = built;
     c->in_frame = false; c->pending = 0;
-    const int rc = refit_upload(c, same, t0);
+    const int rc = c->device >= 0 ? refit_upload(c, same, t0) : PTC_OK;
     if (rc) { g->err = "device " + std::to_string(i) + ": " + ptc_last_error(c); return rc; }
     c->stats.seconds_refit = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
@@ -1614,6 +1643,9 @@ int ptc_debug_get_bvh(ptc_ctx* c, uint32_t* n_nodes, uint32_t* n_tris, uint32_t*
 // Context internals for tests of the host logic: [0] HIP events created so far, [1] timing spans waiting to be collected,
 // [2] queue capacity (paths) of lane 0, [3] samples of one full batch, [4] samples accepted but not yet issued,
 // [5] trace blocks per CU, [6] stack entries per lane kept in LDS.
+// identity of the host build a context renders from (the contexts of a group share one: ptc_group_scene_commit): tests compare the values
+uint64_t ptc_debug_host_build_id(const ptc_ctx* c) { return c ? (uint64_t)(uintptr_t)c->built.get() : 0u; }
+
 int ptc_debug_get_internals(ptc_ctx* c, uint64_t out[8]) {
   if (!c || !out) return PTC_E_ARG;
   for (int i = 0; i < 8; ++i) out[i] = 0;

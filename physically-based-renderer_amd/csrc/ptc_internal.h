@@ -117,6 +117,7 @@ struct LaunchCfg { int n_cu; int trace_blocks_per_cu; int stack_lds; /* stack en
                    int shade_tables_lds; /* 1: the scene's emitter / material / environment-row tables all fit k_shade's LDS copies (pt_shade_tables_fit): the variant without global fallbacks runs */ };
 
 // ---- kernel launchers (pt_kernels.hip) ------------------------------------------------------------
+const char* pt_kernel_policy();  // compile-time constants of the kernels as "name=value ..." (ptc_launch_policy)
 int pt_trace_block_threads();   // threads per block of the trace kernels (compile-time constant of pt_kernels.hip)
 size_t pt_trace_lds_bytes(const LaunchCfg&, const DevScene&);   // dynamic LDS of a trace block (the larger, closest-hit, figure)
 int pt_trace_blocks_per_cu(size_t lds_bytes);                    // resident trace blocks per CU at that LDS size (runtime occupancy query)

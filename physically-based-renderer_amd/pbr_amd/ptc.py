@@ -29,12 +29,12 @@ ABI_VERSION = 4
 
 # every symbol include/ptc.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
-    "ptc_create", "ptc_destroy", "ptc_last_error", "ptc_abi_version", "ptc_build_info", "ptc_scene_begin", "ptc_add_material",
+    "ptc_create", "ptc_destroy", "ptc_last_error", "ptc_abi_version", "ptc_build_info", "ptc_launch_policy", "ptc_scene_begin", "ptc_add_material",
     "ptc_add_texture_rgba8", "ptc_add_mesh", "ptc_add_instance", "ptc_add_instance_matrix", "ptc_update_instance", "ptc_update_instance_matrix", "ptc_scene_refit", "ptc_scene_rebuild", "ptc_set_camera", "ptc_set_env_latlong_rgb32f", "ptc_set_texture_filter", "ptc_set_bvh_builder", "ptc_scene_commit", "ptc_render",
     "ptc_frame_begin", "ptc_frame_add_samples", "ptc_frame_reserve", "ptc_frame_resolve", "ptc_frame_checkpoint", "ptc_frame_restore", "ptc_frame_set_sample_range", "ptc_sync", "ptc_read_radiance_rgba32f",
     "ptc_radiance_device_ptr", "ptc_write_radiance_rgba32f", "ptc_tonemap_rgba8", "ptc_get_stats",
     "ptc_debug_trace_closest", "ptc_debug_trace_any", "ptc_debug_get_flat_scene", "ptc_debug_get_bvh", "ptc_debug_get_counters",
-    "ptc_debug_get_description", "ptc_debug_get_material", "ptc_debug_get_texture", "ptc_debug_get_internals", "ptc_debug_get_shading_tables", "ptc_debug_refit_host_parts",
+    "ptc_debug_get_description", "ptc_debug_get_material", "ptc_debug_get_texture", "ptc_debug_get_internals", "ptc_debug_host_build_id", "ptc_debug_get_shading_tables", "ptc_debug_refit_host_parts",
     "ptc_read_radiance_rgba16f", "ptc_radiance_rgba16f_device_ptr",
     "ptc_comm_unique_id", "ptc_comm_init", "ptc_comm_reduce_radiance", "ptc_comm_destroy",
     "ptc_group_create", "ptc_group_size", "ptc_group_scene_commit", "ptc_group_scene_refit", "ptc_group_ctx", "ptc_group_render", "ptc_group_last_error", "ptc_group_destroy",
@@ -83,6 +83,8 @@ def load_library():
     L.ptc_last_error.argtypes = [vp]
     L.ptc_abi_version.restype = C.c_int
     L.ptc_build_info.restype = C.c_char_p
+    L.ptc_launch_policy.restype = C.c_char_p
+    L.ptc_launch_policy.argtypes = [vp]
     L.ptc_scene_begin.argtypes = [vp]
     L.ptc_add_material.argtypes = [vp, fp, C.c_float, C.c_float, fp, C.c_int, C.c_int, C.c_int]
     L.ptc_add_texture_rgba8.argtypes = [vp, u8p, C.c_int, C.c_int]
@@ -122,6 +124,8 @@ def load_library():
     L.ptc_debug_get_material.argtypes = [vp, C.c_int, fp, C.POINTER(C.c_int)]
     L.ptc_debug_get_texture.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), vp]
     L.ptc_debug_get_internals.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.ptc_debug_host_build_id.argtypes = [vp]
+    L.ptc_debug_host_build_id.restype = C.c_uint64
     L.ptc_debug_get_shading_tables.argtypes = [vp, u32p, fp, u32p, fp, fp]
     L.ptc_debug_refit_host_parts.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.ptc_read_radiance_rgba16f.argtypes = [vp, C.POINTER(C.c_uint16)]
@@ -234,6 +238,13 @@ class PathTracer:
     def scene_refit(self):
         self._ck(self._L.ptc_scene_refit(self._h))
         return self
+
+    def host_build_id(self):
+        return int(self._L.ptc_debug_host_build_id(self._h))
+
+    def launch_policy(self):
+        """ptc_launch_policy of this context (after a commit: with the launch configuration that followed)."""
+        return self._L.ptc_launch_policy(self._h).decode()
 
     def scene_rebuild(self):
         """ptc_scene_rebuild: pending transforms + a new LBVH for the moved geometry, built on the device."""

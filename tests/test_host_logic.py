@@ -411,3 +411,38 @@ def test_refit_refuses_a_description_that_changed_since_the_commit(pbr):
     pt.scene_refit()
     assert pt.stats()["n_triangles"] > pbr.PathTracer(pbr.DEVICE_NONE).load_scene(d).stats()["n_triangles"]
 
+
+def test_a_group_builds_its_scene_once(pbr):
+    """ptc_group_scene_commit: device 0's context flattens and builds, the other contexts of the group take THAT build (one host build for N devices) — checked
+    without a GPU on a description-only group (every id PTC_DEVICE_NONE: no RCCL, nothing uploaded) through the identity of the host build each context holds.
+    A refit of the group leaves them sharing one (new) build again; a context that refits on its own gets its own copy."""
+    d = pbr.scenes.by_name("cornell")
+    g = pbr.ptc.Group([pbr.DEVICE_NONE, pbr.DEVICE_NONE, pbr.DEVICE_NONE]).load_scene(d)
+    ids = [g.ctx(i).host_build_id() for i in range(3)]
+    assert ids[0] != 0 and ids.count(ids[0]) == 3, ids
+    assert [g.ctx(i).stats()["n_triangles"] for i in range(3)] == [12, 12, 12]
+    u0 = g.ctx(0).bvh()[0].view(np.uint32).copy()
+    g.ctx(0).update_instance(0, (0.1, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
+    g.scene_refit()
+    ids2 = [g.ctx(i).host_build_id() for i in range(3)]
+    assert ids2.count(ids2[0]) == 3 and ids2[0] != 0
+    assert not np.array_equal(g.ctx(2).bvh()[0].view(np.uint32), u0) and np.array_equal(g.ctx(2).bvh()[0].view(np.uint32), g.ctx(0).bvh()[0].view(np.uint32))
+    g.ctx(1).scene_refit()                          # on its own: copy-on-write
+    assert g.ctx(1).host_build_id() != g.ctx(0).host_build_id() == g.ctx(2).host_build_id()
+    with pytest.raises(pbr.PtcError):
+        g.render(8, 8, 1)                           # no device
+
+
+def test_launch_policy_is_reported_without_a_device(pbr):
+    """ptc_launch_policy(NULL): the kernels' compile-time constants and the built-in defaults, as one string; a context's string starts with the same constants and
+    carries its own knobs (here: the builder).  tests/test_profiles.py holds the committed kernel model against the first."""
+    L = pbr.load_library()
+    dflt = L.ptc_launch_policy(None).decode()
+    for key in ("trace_block=", "ring=", "refill_idle=", "node_min=", "chunk=", "shade_block=", "nodelets=", "lanes=", "batch_paths=", "trace_overlap=", "bvh=sah"):
+        assert key in dflt, (key, dflt)
+    import copy
+    d = copy.deepcopy(pbr.scenes.by_name("cornell")); d.bvh_builder = "lbvh"
+    pt = pbr.PathTracer(pbr.DEVICE_NONE).load_scene(d)
+    mine = pt.launch_policy()
+    assert mine.split(" | ")[0] == dflt.split(" | ")[0] and "bvh=lbvh" in mine and "trace_blocks_per_cu" not in mine      # nothing was configured for a device
+

@@ -10,9 +10,9 @@ PROF = os.path.join(ROOT, "profiles")
 
 
 def _kernel_source_sha256():
-    """csrc/Makefile's KERNEL_SHA: sha256 over pt_kernels.hip, pt_device.h, ptc_internal.h in that order (what ptc_build_info reports)."""
+    """csrc/Makefile's KERNEL_SHA: sha256 over its KERNEL_SRC list in that order — every file that holds device code (what ptc_build_info reports)."""
     h = hashlib.sha256()
-    for f in ("pt_kernels.hip", "pt_device.h", "ptc_internal.h"):
+    for f in "pt_kernels.hip pt_device.h ptc_internal.h pt_refit.hip pt_refit.h pt_build.hip pt_build.h".split():
         h.update(open(os.path.join(ROOT, "physically-based-renderer_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 
@@ -22,18 +22,25 @@ def test_kernel_models_were_measured_on_the_kernels_in_the_tree():
     taken on (sha256 of the kernel sources, checked against the profiled library by tools/make_kernel_model.py): editing a kernel without
     profiling again fails HERE, instead of silently reporting a fraction that belongs to other code."""
     sha = _kernel_source_sha256()
-    for f in ("r03_kernel_model.json", "r03_textured_kernel_model.json"):
-        m = json.load(open(os.path.join(PROF, f)))
-        assert m["kernel_source_sha256"] == sha, f"{f} was measured on kernels {m['kernel_source_sha256'][:12]}, the tree holds {sha[:12]}: run tools/profile.sh + tools/make_kernel_model.py again"
-        assert len(m["git_commit"]) >= 40
     import sys
     sys.path.insert(0, os.path.join(ROOT, "physically-based-renderer_amd"))
     import pbr_amd
-    assert pbr_amd.load_library().ptc_build_info().decode().endswith(sha), "libptc.so was built from other kernel sources than the tree's: make -C physically-based-renderer_amd/csrc"
+    L = pbr_amd.load_library()
+    assert L.ptc_build_info().decode().endswith(sha), "libptc.so was built from other kernel sources than the tree's: make -C physically-based-renderer_amd/csrc"
+    defaults = L.ptc_launch_policy(None).decode()
+    for f in ("r04_kernel_model.json", "r04_textured_kernel_model.json"):
+        m = json.load(open(os.path.join(PROF, f)))
+        assert m["kernel_source_sha256"] == sha, f"{f} was measured on kernels {m['kernel_source_sha256'][:12]}, the tree holds {sha[:12]}: run tools/profile.sh + tools/make_kernel_model.py again"
+        assert len(m["git_commit"]) >= 40
+        # ... and under the launch policy the library still defaults to: block sizes, chunk, ring, thresholds, lanes, batch size, overlap mode, nodelets (ptc_launch_policy).
+        # Changing TRACE_MIN_WAVES, the overlap default or the batch size without profiling again fails here; what follows from them on a device (blocks per CU,
+        # stack entries in LDS) is in the model's full `launch_policy`, which bench.py compares with the running context's.
+        assert m["launch_policy_defaults"] == defaults, f"{f}: the library's launch defaults moved since the profile:\n  profile {m['launch_policy_defaults']}\n  library {defaults}"
+        assert m["launch_policy"].startswith(defaults.split(" | ")[0]) and "trace_blocks_per_cu=" in m["launch_policy"]
 
 
 def test_kernel_model_and_ceilings_are_committed():
-    model = json.load(open(os.path.join(PROF, "r03_kernel_model.json")))
+    model = json.load(open(os.path.join(PROF, "r04_kernel_model.json")))
     for k in ("k_trace_closest", "k_trace_any", "k_shade"):
         m = model[k]
         for key in ("valu_winstr_per_unit", "hbm_bytes_per_unit", "serialised_ms_per_launch", "serialised_units_per_launch", "dispatches", "unit"):
@@ -53,13 +60,13 @@ def test_kernel_model_and_ceilings_are_committed():
         m = model[k]
         frac = m["serialised_units_per_launch"] * m["valu_winstr_per_unit"] / (m["serialised_ms_per_launch"] * 1e-3) / 1e9 / peak
         assert lo < frac < hi, (k, frac)
-    for f in ("r03_kernel_stats.csv", "r03_pmc_summary.json", "r02_gather_bench.json", "r03_bench.json", "r03_textured_kernel_stats.csv", "r03_textured_pmc_summary.json",
-              "r03_valu_mix.json", "r03_fuzz_parity.txt"):
+    for f in ("r04_kernel_stats.csv", "r04_pmc_summary.json", "r02_gather_bench.json", "r04_bench.json", "r04_textured_kernel_stats.csv", "r04_textured_pmc_summary.json",
+              "r03_valu_mix.json", "r04_fuzz_parity.txt", "r04_refit_curve.txt", "r04_rebuild_kernel_stats.csv"):
         assert os.path.getsize(os.path.join(PROF, f)) > 100, f
 
 
 def test_bench_line_of_the_committed_run_has_the_contract_fields():
-    d = json.load(open(os.path.join(PROF, "r03_bench.json")))
+    d = json.load(open(os.path.join(PROF, "r04_bench.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
     assert d["unit"] == "Mpaths/s" and d["dtype"] == "f32" and d["scaling"] == "strong" and d["vs_baseline"] is None and d["data"] == "synthetic"
@@ -67,7 +74,8 @@ def test_bench_line_of_the_committed_run_has_the_contract_fields():
     assert r["bound"] == "valu_issue" and 0 < r["frac"] <= 1 and 0 < r["frac_exclusive"] <= 1 and r["traffic"] > 0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and abs(r["peak"] - 1228.8) < 1e-6       # against the guide's peak, the measured ceiling beside it
     assert r["frac"] < r["frac_of_measured_ceiling"] < 1 and 0 < r["issue_duty_per_cycle"] < 1
-    assert r["model_stale"] is False and r["model_kernel_sha256"] == r["library_kernel_sha256"] and len(r["model_commit"]) >= 40
+    assert r["model_stale"] is False and r["model_stale_why"] == [] and r["model_kernel_sha256"] == r["library_kernel_sha256"] and len(r["model_commit"]) >= 40
+    assert d["launch_policy"] == r["model_launch_policy"] and d["launch_policy"].startswith(d["launch_policy_defaults"].split(" | ")[0])
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
     assert abs(d["value"] - d["config"]["paths"] / (d["ms_per_step"] * 1e-3 * d["steps"]) / 1e6) / d["value"] < 1e-6
     ast.parse(open(os.path.join(ROOT, "bench.py")).read())

@@ -14,9 +14,9 @@ CSRC = os.path.join(ROOT, "physically-based-renderer_amd", "csrc")
 
 
 def kernel_source_sha256():
-    """The recipe of csrc/Makefile's KERNEL_SHA: sha256 over pt_kernels.hip, pt_device.h, ptc_internal.h in that order."""
+    """The recipe of csrc/Makefile's KERNEL_SHA: sha256 over its KERNEL_SRC list, in that order (every file that holds device code)."""
     h = hashlib.sha256()
-    for f in ("pt_kernels.hip", "pt_device.h", "ptc_internal.h"):
+    for f in "pt_kernels.hip pt_device.h ptc_internal.h pt_refit.hip pt_refit.h pt_build.hip pt_build.h".split():
         h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()
 
@@ -35,7 +35,11 @@ profiled_sha = bench.get("library", "").rsplit(" ", 1)[-1]                 # the
 assert profiled_sha == kernel_source_sha256(), f"the profile was taken on kernels {profiled_sha[:12]}, the tree holds {kernel_source_sha256()[:12]}: profile again"
 commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
 dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", CSRC], capture_output=True, text=True).stdout.strip()
+assert bench.get("launch_policy") and bench.get("launch_policy_defaults"), "the bench line carries no launch policy: old bench.py?"
 model = {"git_commit": commit + ("+uncommitted csrc changes" if dirty else ""), "kernel_source_sha256": profiled_sha,
+         # what the launches of the profiled run looked like (ptc_launch_policy): grid sizing, LDS split, batch size, overlap mode ... — bench.py reports
+         # model_stale when the library it runs launches differently, tests/test_profiles.py when the library's DEFAULTS have moved since
+         "launch_policy": bench["launch_policy"], "launch_policy_defaults": bench["launch_policy_defaults"],
          "source": f"{prof}: rocprofv3 --pmc passes of `bench.py --steps {K} --warmup {W}` ({bench['config']['workload']})",
          "fetch_note": "fetch bytes = FETCH_SIZE KiB x 1024 x 2 (gfx950 tallies 128-B requests at 64 B; calibrated for streaming reads, uncalibrated for 16-B gathers: true value between 0.5x and 1x)"}
 for kname, u in units.items():
