@@ -15,16 +15,54 @@ def _independent_cornell(pbr, w, h, spp, max_bounces, seed):
     return _independent(pbr.scenes.cornell_box(), w, h, spp, max_bounces, seed)
 
 
-def _independent(d, w, h, spp, max_bounces, seed):
+def _agree(ind, var, ref, ovar, w, h, block_tol=0.04):
+    """True when the two estimates agree: whole image to 1.5 % + 4 standard errors, 4x4 blocks per channel to block_tol + 4 standard errors."""
+    se = math.sqrt(var.sum() + ovar.sum()) / var.size
+    if abs(ind.mean() - ref.mean()) > 4 * se + 0.015 * ref.mean():
+        return False, se
+    B = 4
+    for c in range(3):
+        a = ind[..., c].reshape(h // B, B, w // B, B).mean((1, 3))
+        b = ref[..., c].reshape(h // B, B, w // B, B).mean((1, 3))
+        s = np.sqrt((var[..., c] + ovar[..., c]).reshape(h // B, B, w // B, B).sum((1, 3))) / (B * B)
+        if (np.abs(a - b) > 4 * s + block_tol * np.maximum(b, 0.02)).any():
+            return False, se
+    return True, se
+
+
+def _model_matrix(inst):
+    """The instance's model matrix from ITS definition (ModelPushConstant.hpp:40-46): translate(t) * toMat4(q) * scale(s), q = (w, x, y, z), the rotation matrix
+    of a unit quaternion from the textbook formula — float64, row-major 4x4 acting on column vectors.  (An instance given by a matrix: glm's column-major 16 floats.)"""
+    if getattr(inst, "matrix", None) is not None:
+        return np.asarray(inst.matrix, np.float64).reshape(4, 4).T
+    w_, x, y, z = (float(c) for c in inst.q_wxyz)
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w_), 2 * (x * z + y * w_)],
+                  [2 * (x * y + z * w_), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w_)],
+                  [2 * (x * z - y * w_), 2 * (y * z + x * w_), 1 - 2 * (x * x + y * y)]])
+    M = np.eye(4)
+    M[:3, :3] = R @ np.diag([float(c) for c in inst.s])
+    M[:3, 3] = [float(c) for c in inst.t]
+    return M
+
+
+def _independent(d, w, h, spp, max_bounces, seed, mutation=None):
+    """mutation: None, or one of the mistakes the transformed-scene test must catch — "normal_matrix_is_model" (normals transformed by the model matrix instead of
+    its inverse transpose), "no_renormalisation" (the transformed normal / tangent / bitangent left un-normalised)."""
     tris, alb, emi, met, rough, vattr, texid = [], [], [], [], [], [], []
-    for inst in d.instances:                                            # identity transforms in this scene: positions are world positions
+    for inst in d.instances:
         m = d.meshes[inst.mesh]
-        P = np.asarray(m.vertices["position"], np.float64)
+        M = _model_matrix(inst)                                         # vertex.glsl:26: worldPos = model * vec4(position, 1)
+        NM = np.linalg.inv(M[:3, :3]).T                                 # ModelPushConstant.hpp:36: normalModel = mat3(transpose(inverse(model)))
+        if mutation == "normal_matrix_is_model":
+            NM = M[:3, :3]
+        P = np.asarray(m.vertices["position"], np.float64) @ M[:3, :3].T + M[:3, 3]
         I = np.asarray(m.indices, np.int64).reshape(-1, 3)
         mat = d.materials[m.material]
-        Nv, Tv, UV = (np.asarray(m.vertices[k], np.float64) for k in ("normal", "tangent", "texCoords"))
-        Bv = np.cross(Nv, Tv[:, :3]) * Tv[:, 3:4]                       # vertex.glsl:25-36: B = cross(N, T.xyz) * T.w, per vertex, normalised
-        Bv /= np.maximum(np.linalg.norm(Bv, axis=1, keepdims=True), 1e-30)
+        N0, T0, UV = (np.asarray(m.vertices[k], np.float64) for k in ("normal", "tangent", "texCoords"))
+        unit = (lambda v: v) if mutation == "no_renormalisation" else (lambda v: v / np.maximum(np.linalg.norm(v, axis=1, keepdims=True), 1e-30))
+        Nv = unit(N0 @ NM.T)                                            # vertex.glsl:33-35: each of N, T, B = normalize(normalModel * ...),
+        Tv = np.concatenate([unit(T0[:, :3] @ NM.T), T0[:, 3:4]], 1)    # B from the OBJECT-space cross(N, T.xyz) * T.w
+        Bv = unit((np.cross(N0, T0[:, :3]) * T0[:, 3:4]) @ NM.T)
         for a, b, c in I:
             tris.append((P[a], P[b], P[c])); alb.append(mat.base_color[:3]); emi.append(mat.emissive); met.append(mat.metallic); rough.append(mat.roughness)
             vattr.append([np.concatenate([UV[i], Nv[i], Tv[i, :3], Bv[i]]) for i in (a, b, c)])
@@ -291,3 +329,69 @@ def test_an_independent_estimator_agrees_on_a_textured_normal_mapped_surface(ora
         bad = np.abs(a - b) > 4 * s + 0.04 * np.maximum(b, 0.02)
         assert not bad.any(), (c, a[bad], b[bad], s[bad])
     print("textured: independent %.4f oracle %.4f (se %.4f)" % (ind.mean(), ref.mean(), se))
+
+
+def test_an_independent_estimator_agrees_on_a_rotated_non_uniformly_scaled_normal_mapped_instance(ora, pbr):
+    """R3 / R4 by evidence the oracle did not write: the textured, normal-mapped floor of the previous test is now an INSTANCE with a rotation and a non-uniform
+    scale (and the light a rotated, scaled instance too), so that world normals, tangents and bitangents only come out right through
+    normalModel = transpose(inverse(model)) and the re-normalisation of vertex.glsl:33-35 — the independent estimator forms both from their definitions
+    (numpy's inverse, the textbook quaternion matrix).  The same scene after ptc_update_instance + a refit (oracle: ora_scene_refit) must agree as well.
+    And the two classic mistakes — normals through the model matrix itself, no re-normalisation — must NOT agree."""
+    import copy
+    sc = pbr.scene
+    quad = pbr.scenes._quad
+    rng = np.random.default_rng(21)
+    T_ = 8
+    albedo = np.concatenate([rng.integers(60, 256, (T_, T_, 3)), np.full((T_, T_, 1), 255)], 2).astype(np.uint8)
+    albedo[:, : T_ // 2, 0] //= 3
+    mr = np.zeros((T_, T_, 4), np.uint8); mr[..., 3] = 255
+    mr[..., 1] = rng.integers(90, 256, (T_, T_)); mr[..., 2] = rng.integers(0, 2, (T_, T_)) * 200
+    yy, xx = np.mgrid[0:T_, 0:T_]
+    nx, ny = 0.55 * np.sin(2 * math.pi * xx / T_), 0.45 * np.cos(2 * math.pi * yy / T_) + 0.2        # a strong map: the frame's errors show
+    nz = np.sqrt(1 - nx * nx - ny * ny)
+    nmap = np.stack([np.round((nx * 0.5 + 0.5) * 255), np.round((ny * 0.5 + 0.5) * 255), np.round((nz * 0.5 + 0.5) * 255), np.full((T_, T_), 255)], 2).astype(np.uint8)
+    mats = [sc.Material((0.9, 0.8, 0.7, 1.0), 1.0, 0.8, (0.0, 0.0, 0.0), 0, 1, 2), sc.Material((0.0, 0.0, 0.0, 1.0), 0.0, 1.0, (9.0, 8.0, 7.0)),
+            sc.Material((0.5, 0.6, 0.7, 1.0), 0.0, 1.0)]
+    fv, fi = quad((-1, -0.7, 1), (1, 0.7, 1), (1, 0.7, -1), (-1, -0.7, -1))             # a floor that is TILTED in object space (normal ~ (-0.57, 0.82, 0)) ...
+    fv["texCoords"] = np.array([(-0.3, -0.2), (1.9, -0.2), (1.9, 1.6), (-0.3, 1.6)], np.float32)
+    meshes = [sc.MeshDesc(fv, fi, 0), sc.MeshDesc(*quad((-1, 0, -1), (1, 0, -1), (1, 0, 1), (-1, 0, 1)), 1), sc.MeshDesc(*quad((-2, 0, -2), (2, 0, -2), (2, 2.5, -2), (-2, 2.5, -2)), 2)]
+    a1, a2 = -0.263, -0.35                                                             # ... stretched 2.6 x 1 x 1.7 and turned back to about level: its normal is not an axis of the
+                                                                                        # scale, so model * n (45 degrees off) and transpose(inverse(model)) * n part ways
+    inst = [sc.InstanceDesc(0, (0.1, 0.15, 0.0), (math.cos(a1 / 2), 0.0, 0.0, math.sin(a1 / 2)), (2.6, 1.0, 1.7)),
+            sc.InstanceDesc(1, (0.0, 1.9, 0.0), (math.cos(a2 / 2), math.sin(a2 / 2), 0.0, 0.0), (0.9, 1.0, 0.6)),
+            sc.InstanceDesc(2, (0.0, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0), (1.0, 1.0, 1.0))]
+    d = sc.SceneDesc(mats, meshes, inst, sc.CameraDesc((0.4, 1.3, 3.4), (0.0, 0.3, 0.0), math.radians(50.0), 1.0), "tilted_textured_floor", textures=[albedo, nmap, mr])
+    w = h = 16
+    mb = 3
+
+    def oracle_estimate(o):
+        r1 = o.render(w, h, 512, seed=35, max_bounces=mb)[..., :3].astype(np.float64)
+        r2 = o.render(w, h, 512, seed=36, max_bounces=mb)[..., :3].astype(np.float64)
+        return 0.5 * (r1 + r2), ((r1 - r2) ** 2) / 4
+
+    o = ora.Oracle().load_scene(d)
+    ref, ovar = oracle_estimate(o)
+    assert ref.mean() > 0.05
+    ind, var = _independent(d, w, h, 3000, mb, seed=31)
+    ok, se = _agree(ind, var, ref, ovar, w, h)
+    assert ok, (ind.mean(), ref.mean(), se)
+    print("transformed: independent %.4f oracle %.4f (se %.4f)" % (ind.mean(), ref.mean(), se))
+    for mutation in ("normal_matrix_is_model", "no_renormalisation"):
+        bad, bvar = _independent(d, w, h, 3000, mb, seed=31, mutation=mutation)
+        ok_bad, _ = _agree(bad, bvar, ref, ovar, w, h)
+        assert not ok_bad, f"the mutation {mutation} passes: the test does not see the normal matrix ({bad.mean():.4f} vs {ref.mean():.4f})"
+    # the same through the dynamics path: new transforms for the committed instances, then a refit (R3 / R4 run again inside it)
+    d2 = copy.deepcopy(d)
+    b1 = -0.4
+    d2.instances[0].q_wxyz = (math.cos(b1 / 2), math.sin(b1 / 2) * 0.6, 0.0, math.sin(b1 / 2) * 0.8)
+    d2.instances[0].s = (1.5, 1.0, 2.8)
+    d2.instances[0].t = (-0.1, 0.2, 0.1)
+    o.update_instance(0, d2.instances[0].t, d2.instances[0].q_wxyz, d2.instances[0].s)
+    o.scene_refit()
+    ref2, ovar2 = oracle_estimate(o)
+    ind2, var2 = _independent(d2, w, h, 3000, mb, seed=32)
+    ok2, se2 = _agree(ind2, var2, ref2, ovar2, w, h)
+    assert ok2, (ind2.mean(), ref2.mean(), se2)
+    assert not _agree(ind, var, ref2, ovar2, w, h)[0], "the refitted scene's image equals the unmoved scene's: the move was not applied"
+    print("transformed + refit: independent %.4f oracle %.4f (se %.4f)" % (ind2.mean(), ref2.mean(), se2))
+
