@@ -29,6 +29,9 @@
 #ifndef TRACE_CHUNK
 #define TRACE_CHUNK 512u          // rays per work-fetch atomic
 #endif
+#ifndef TRACE_CHUNK_SHORT
+#define TRACE_CHUNK_SHORT 64u     // rays per chunk of a SHORT queue (less than TRACE_CHUNK rays per wave of the grid): dealt round-robin, no atomics (struct Reservoir)
+#endif
 #ifndef TRACE_REFILL_IDLE
 #define TRACE_REFILL_IDLE 1       // idle lanes that make the wave hand out prepared rays (round 4: a hand-out is ~25 vector instructions; the round-3 refill cost ~85 at 0.27 lane utilisation and waited for 12)
 #endif
@@ -92,11 +95,13 @@ PT_DEV void scan_chunks(const uint32_t* seg, uint32_t n_seg, uint32_t* pre, uint
   uint32_t mine = 0, dummy;
   for (uint32_t sg = s0; sg < s1; ++sg) mine += seg[sg];
   const uint32_t total = block_sum_1024(mine, s_w, dummy);
-  // One chunk per wave of the grid when the queue is short (all of them static: no atomic at all), TRACE_CHUNK rays when it is long.  Round 3a aimed at two
-  // chunks per wave, which for a queue of 2 M rays means 32 k chunks of 64: the one work counter serves ~88 atomics per us, the kernel needs a chunk every
-  // 6 ns — such launches ran at the speed of the counter (0.8 ms instead of 0.2).  From 256 rays per chunk on the counter is not the limit.
+  // TRACE_CHUNK rays per chunk when the queue is long (a wave's first chunk is static, the rest go through the work counter), TRACE_CHUNK_SHORT when it holds
+  // less than TRACE_CHUNK rays per wave of the grid: those are dealt round-robin (wave w owns chunks w, w + W, w + 2W, ...: no atomic at all).  Round 3 cut a
+  // short queue into ONE chunk per wave — 512 consecutive rays of a 1080p x 1 spp frame are one 32x16-pixel patch, patches differ by 3x in cost and nothing
+  // balanced them: a launch took as long as its most expensive patch (0.74 ms for 2 M camera rays, 0.38 ms for the 100 k rays of the last bounce).  Eight chunks
+  // of 64 from eight places of the image average out.  (Round 3a's two chunks per wave THROUGH the counter cost 32 k atomics at 88 per us.)
   const uint32_t per_wave = (total + trace_waves - 1u) / trace_waves;
-  const uint32_t chunk = per_wave >= TRACE_CHUNK ? TRACE_CHUNK : (per_wave <= 64u ? 64u : ((per_wave + 63u) & ~63u));
+  const uint32_t chunk = per_wave >= TRACE_CHUNK ? TRACE_CHUNK : TRACE_CHUNK_SHORT;
   uint32_t chunks = 0;
   for (uint32_t sg = s0; sg < s1; ++sg) chunks += (seg[sg] + chunk - 1u) / chunk;
   uint32_t run;
@@ -384,7 +389,10 @@ struct Reservoir {
   // the next (at most `want`) consecutive slots of the wave's current chunk: [first, first + n); n = 0: the queue is exhausted
   PT_DEV uint32_t take(const DevQueues& q, const uint32_t* pre, const uint32_t* seg, uint32_t* ctr, uint32_t lane, uint32_t want, uint32_t& first) {
     if (next >= end && !exhausted) {
-      if (static_left) { static_left = false; open_chunk(q, pre, seg, my_static, lane); }
+      if (chunk < TRACE_CHUNK) {                                      // a short queue: this wave's next chunk of the round-robin deal
+        if (my_static < n_chunks) { open_chunk(q, pre, seg, my_static, lane); my_static += gridDim.x * TRACE_WAVES; }
+        else exhausted = true;
+      } else if (static_left) { static_left = false; open_chunk(q, pre, seg, my_static, lane); }
       else {
         const uint32_t waves = gridDim.x * TRACE_WAVES;
         if (n_chunks <= waves) exhausted = true;                     // the static round covered the queue: no atomic at all
@@ -737,19 +745,26 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_closest(
       STAMP(t_fin);
     }
   }
-  const unsigned long long c_tris = wave_sum(nt);
-  if (lane == 0 && nr) {
-    atomicAdd(&q.stats[ST_NODES_C], nv); atomicAdd(&q.stats[ST_TRIS_C], c_tris);
-    atomicAdd(&q.stats[ST_SEGMENTS], nr); atomicAdd(&q.stats[ST_HITS], nh);
+  {   // counters: summed over the block first, then one atomic per counter, each counter on its own line (ptc_internal.h, ST_STRIDE)
+    __shared__ unsigned long long s_stat[TRACE_WAVES][4];
+    const unsigned long long c_tris = wave_sum(nt);
+    if (lane == 0) { s_stat[wave][0] = nv; s_stat[wave][1] = c_tris; s_stat[wave][2] = nr; s_stat[wave][3] = nh; }
+    __syncthreads();
+    if (threadIdx.x < 4u) {
+      unsigned long long v = 0;
+      for (int w = 0; w < TRACE_WAVES; ++w) v += s_stat[w][threadIdx.x];
+      const int at = threadIdx.x == 0u ? ST_NODES_C : threadIdx.x == 1u ? ST_TRIS_C : threadIdx.x == 2u ? ST_SEGMENTS : ST_HITS;
+      if (v) atomicAdd(&q.stats[at * ST_STRIDE], v);
+    }
   }
 #ifdef PT_STAMP
-  if (lane == 0) { atomicAdd(&q.stats[ST_DIAG_NODE_ITERS], t_node); atomicAdd(&q.stats[ST_DIAG_TRI_ITERS], t_leaf); atomicAdd(&q.stats[ST_DIAG_LEAF_VISITS], t_fin); atomicAdd(&q.stats[ST_DIAG_ROUNDS], t_refill); }
+  if (lane == 0) { atomicAdd(&q.stats[ST_DIAG_NODE_ITERS * ST_STRIDE], t_node); atomicAdd(&q.stats[ST_DIAG_TRI_ITERS * ST_STRIDE], t_leaf); atomicAdd(&q.stats[ST_DIAG_LEAF_VISITS * ST_STRIDE], t_fin); atomicAdd(&q.stats[ST_DIAG_ROUNDS * ST_STRIDE], t_refill); }
 #endif
 #ifdef PT_DIAG
   {
     unsigned long long a0 = wave_sum(d_node), a1 = wave_sum(d_tri), a3 = wave_sum(d_round), a4 = wave_sum(d_leftpass), a5 = wave_sum(d_left);
-    if (lane == 0) { atomicAdd(&q.stats[ST_DIAG_NODE_ITERS], a0); atomicAdd(&q.stats[ST_DIAG_TRI_ITERS], a1); atomicAdd(&q.stats[ST_DIAG_ROUNDS], a3);
-                     atomicAdd(&q.stats[ST_DIAG_LEAF_VISITS], a4); atomicAdd(&q.stats[ST_DIAG_REFILLED], a5); }
+    if (lane == 0) { atomicAdd(&q.stats[ST_DIAG_NODE_ITERS * ST_STRIDE], a0); atomicAdd(&q.stats[ST_DIAG_TRI_ITERS * ST_STRIDE], a1); atomicAdd(&q.stats[ST_DIAG_ROUNDS * ST_STRIDE], a3);
+                     atomicAdd(&q.stats[ST_DIAG_LEAF_VISITS * ST_STRIDE], a4); atomicAdd(&q.stats[ST_DIAG_REFILLED * ST_STRIDE], a5); }
   }
 #endif
 }
@@ -958,9 +973,17 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_any(DevS
       }
     }
   }
-  const unsigned long long c_tris = wave_sum(nt);
-  if (lane == 0 && nr) {
-    atomicAdd(&q.stats[ST_NODES_A], nv); atomicAdd(&q.stats[ST_TRIS_A], c_tris); atomicAdd(&q.stats[ST_SHADOW], nr);
+  {
+    __shared__ unsigned long long s_stat[TRACE_WAVES][3];
+    const unsigned long long c_tris = wave_sum(nt);
+    if (lane == 0) { s_stat[wave][0] = nv; s_stat[wave][1] = c_tris; s_stat[wave][2] = nr; }
+    __syncthreads();
+    if (threadIdx.x < 3u) {
+      unsigned long long v = 0;
+      for (int w = 0; w < TRACE_WAVES; ++w) v += s_stat[w][threadIdx.x];
+      const int at = threadIdx.x == 0u ? ST_NODES_A : threadIdx.x == 1u ? ST_TRIS_A : ST_SHADOW;
+      if (v) atomicAdd(&q.stats[at * ST_STRIDE], v);
+    }
   }
 }
 
@@ -1461,8 +1484,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(const De
   }
   if (lane == 0) { q.seg_ray[qi ^ 1][seg] = out_a; q.seg_sh[seg] = out_s; }
 #ifdef PT_STAMP_SHADE
-  if (lane == 0) { atomicAdd(&q.stats[ST_DIAG_NODE_ITERS], t_front); atomicAdd(&q.stats[ST_DIAG_TRI_ITERS], t_load); atomicAdd(&q.stats[ST_DIAG_LEAF_VISITS], t_math);
-                   atomicAdd(&q.stats[ST_DIAG_ROUNDS], t_back); }
+  if (lane == 0) { atomicAdd(&q.stats[ST_DIAG_NODE_ITERS * ST_STRIDE], t_front); atomicAdd(&q.stats[ST_DIAG_TRI_ITERS * ST_STRIDE], t_load); atomicAdd(&q.stats[ST_DIAG_LEAF_VISITS * ST_STRIDE], t_math);
+                   atomicAdd(&q.stats[ST_DIAG_ROUNDS * ST_STRIDE], t_back); }
 #endif
 }
 

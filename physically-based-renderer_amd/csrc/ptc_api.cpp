@@ -462,9 +462,9 @@ int sum_lane_stats(ptc_ctx* c, unsigned long long st[ST_N]) {
   for (int i = 0; i < ST_N; ++i) st[i] = 0;
   for (auto& ln : c->lanes) {
     if (!ln.q.stats) continue;
-    unsigned long long one[ST_N];
+    unsigned long long one[ST_N * ST_STRIDE];
     HIP_TRY(c, hipMemcpy(one, ln.q.stats, sizeof one, hipMemcpyDeviceToHost));
-    for (int i = 0; i < ST_N; ++i) st[i] += one[i];
+    for (int i = 0; i < ST_N; ++i) st[i] += one[i * ST_STRIDE];
   }
   return PTC_OK;
 }
@@ -488,7 +488,7 @@ int debug_prepare(ptc_ctx* c, uint32_t n, const char* who) {
   c->in_frame = false; c->pending = 0;
   int rc = ensure_lane_queues(c, n);
   if (rc) return rc;
-  for (auto& ln : c->lanes) HIP_TRY(c, hipMemset(ln.q.stats, 0, ST_N * sizeof(unsigned long long)));
+  for (auto& ln : c->lanes) HIP_TRY(c, hipMemset(ln.q.stats, 0, ST_N * ST_STRIDE * sizeof(unsigned long long)));
   return PTC_OK;
 }
 
@@ -568,8 +568,8 @@ ptc_ctx* ptc_create(int device_id) {
   bool ok = true;
   for (auto& ln : c->lanes) {
     ok = ok && hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ln.acc_done, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipMalloc((void**)&ln.q.cnt, CNT_N * sizeof(uint32_t)) == hipSuccess && hipMalloc((void**)&ln.q.stats, ST_N * sizeof(unsigned long long)) == hipSuccess;
-    ok = ok && hipMemset(ln.q.cnt, 0, CNT_N * sizeof(uint32_t)) == hipSuccess && hipMemset(ln.q.stats, 0, ST_N * sizeof(unsigned long long)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&ln.q.cnt, CNT_N * sizeof(uint32_t)) == hipSuccess && hipMalloc((void**)&ln.q.stats, ST_N * ST_STRIDE * sizeof(unsigned long long)) == hipSuccess;
+    ok = ok && hipMemset(ln.q.cnt, 0, CNT_N * sizeof(uint32_t)) == hipSuccess && hipMemset(ln.q.stats, 0, ST_N * ST_STRIDE * sizeof(unsigned long long)) == hipSuccess;
     uint32_t* segs = nullptr;                                     // seg_ray[2], seg_sh, pre_ray, pre_sh: one allocation
     const size_t per = PTC_MAX_SEGMENTS + 64;
     ok = ok && hipMalloc((void**)&segs, 5 * per * sizeof(uint32_t)) == hipSuccess && hipMemset(segs, 0, 5 * per * sizeof(uint32_t)) == hipSuccess;
@@ -1175,7 +1175,7 @@ int ptc_frame_begin(ptc_ctx* c, int w, int h, int spp_total, uint64_t seed, int 
     if (per < 1) per = 1;
   }
   c->per_batch = (uint32_t)per;
-  for (auto& ln : c->lanes) HIP_TRY(c, hipMemsetAsync(ln.q.stats, 0, ST_N * sizeof(unsigned long long), ln.stream));
+  for (auto& ln : c->lanes) HIP_TRY(c, hipMemsetAsync(ln.q.stats, 0, ST_N * ST_STRIDE * sizeof(unsigned long long), ln.stream));
   { int rs = sync_all_lanes(c); if (rs) return rs; }     // accum/radiance/statistics are cleared before any lane starts
   c->batches_issued = 0;
   collect_times(c, true);      // all lanes are idle: every span is complete; the previous frame's times are dropped below

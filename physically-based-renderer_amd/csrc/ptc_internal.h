@@ -91,6 +91,10 @@ enum { CNT_RAY_TOTAL = 0, CNT_RAY_CHUNK, CNT_RAY_NCHUNKS, CNT_SH_TOTAL, CNT_SH_C
 #define PTC_MAX_SEGMENTS 16384u     // upper bound of n_seg (sizes the per-segment arrays)
 #define PTC_ENV_GUIDE 256u          // buckets of the environment cdf guide tables (a power of two: r * PTC_ENV_GUIDE is exact)
 #define PTC_MATERIAL_CLASSES 8      // classes a hit word can carry (3 bits above the 28-bit primitive id); class 7 = miss under an environment
+// Every statistic word has a 128-byte line of its own (index i lies at stats[i * ST_STRIDE]): atomics on ONE line are served one at a time (~11 ns each), and until
+// round 4 the trace kernels ended with four per WAVE on one line — 16-32 k atomics, 0.2-0.35 ms at the end of EVERY launch, which was most of a small launch
+// (tools/viewer_loop.py).  Now: one per counter and BLOCK, four lines.
+#define ST_STRIDE 16
 enum { ST_SEGMENTS = 0, ST_SHADOW, ST_HITS, ST_NODES_C, ST_TRIS_C, ST_NODES_A, ST_TRIS_A,
        // wave-level iteration counts of the trace kernels' loops (filled only by a -DPT_DIAG build): lane
        // utilisation of a phase = lane-level count / (64 x wave-level count)
