@@ -47,6 +47,7 @@ public:
       new (&q.m_) std::mutex();
       new (&q.run_mutex_) std::mutex();
       q.n_threads_ = 1;
+      q.cur_ = nullptr;
     });
     (void)once;
     return p;
@@ -58,15 +59,17 @@ public:
     if (n_threads_ <= 1 || n_chunks == 1) { for (size_t i = 0; i < n_chunks; ++i) fn(i); return; }
     std::unique_lock<std::mutex> one(run_mutex_);          // one loop at a time (contexts on several host threads may commit concurrently)
     std::function<void(size_t)> job = [&fn](size_t i) { fn(i); };
+    Run r;                                                  // the loop's own tickets and counts: a worker that wakes late for an EARLIER loop holds that loop's Run, or none
+    r.job = &job; r.n_chunks = n_chunks;
     {
       std::lock_guard<std::mutex> g(m_);
-      job_ = &job; n_chunks_ = n_chunks; next_.store(0); done_ = 0; ++epoch_;
+      cur_ = &r; ++epoch_;
     }
     cv_.notify_all();
-    work();
+    work(r, false);
     std::unique_lock<std::mutex> g(m_);
-    finished_.wait(g, [&] { return done_ == n_chunks_; });
-    job_ = nullptr;
+    finished_.wait(g, [&] { return r.done == r.n_chunks && r.inside == 0; });     // every chunk done AND every worker that took this Run has left it: `r` and `job` may go
+    cur_ = nullptr;
   }
 private:
   HostPool() {
@@ -98,35 +101,40 @@ private:
     cv_.notify_all();
     for (auto& w : workers_) w.join();
   }
-  void work() {
+  struct Run { const std::function<void(size_t)>* job = nullptr; size_t n_chunks = 0, done = 0; unsigned inside = 0; std::atomic<size_t> next{0}; };
+  void work(Run& r, bool worker) {
     size_t mine = 0;
     for (;;) {
-      const size_t i = next_.fetch_add(1);
-      if (i >= n_chunks_) break;
-      (*job_)(i);
+      const size_t i = r.next.fetch_add(1);
+      if (i >= r.n_chunks) break;
+      (*r.job)(i);
       ++mine;
     }
-    if (mine) { std::lock_guard<std::mutex> g(m_); done_ += mine; if (done_ == n_chunks_) finished_.notify_all(); }
+    std::lock_guard<std::mutex> g(m_);
+    r.done += mine;
+    if (worker) --r.inside;
+    if (r.done == r.n_chunks && r.inside == 0) finished_.notify_all();
   }
   void loop() {
     uint64_t seen = 0;
     for (;;) {
+      Run* r;
       {
         std::unique_lock<std::mutex> g(m_);
         cv_.wait(g, [&] { return stop_ || epoch_ != seen; });
         if (stop_) return;
         seen = epoch_;
+        r = cur_;                       // under the lock: either the loop that is running (it cannot return before `inside` is back to 0) or none
+        if (r) ++r->inside;
       }
-      work();
+      if (r) work(*r, true);
     }
   }
   unsigned n_threads_ = 1;
   std::vector<std::thread> workers_;
   std::mutex m_, run_mutex_;
   std::condition_variable cv_, finished_;
-  const std::function<void(size_t)>* job_ = nullptr;
-  size_t n_chunks_ = 0, done_ = 0;
-  std::atomic<size_t> next_{0};
+  Run* cur_ = nullptr;
   uint64_t epoch_ = 0;
   bool stop_ = false;
 };
@@ -602,8 +610,13 @@ std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vec
     topo = std::make_shared<Topology>();
     topo->toplet_budget = toplet_budget;
   }
-  B.wverts.resize(nv);
-  std::vector<float>& wbt = topo->wbt;   // world bitangent per vertex (vertex.glsl:35)
+  // A refit flattens into temporaries and takes them over only when every position is finite: a refused refit leaves the host build as it was (the device
+  // path restores its scratch vertices likewise), so the debug getters keep describing what is being rendered.
+  std::vector<HostVertex> wverts_new;
+  std::vector<float> wbt_new;
+  std::vector<HostVertex>& wverts = refit ? wverts_new : B.wverts;
+  std::vector<float>& wbt = refit ? wbt_new : topo->wbt;   // world bitangent per vertex (vertex.glsl:35)
+  wverts.resize(nv);
   wbt.resize(nv * 3);
   B.widx.resize(nt * 3);
   B.tri_mat.resize(nt);
@@ -633,7 +646,7 @@ std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vec
     const uint32_t vb = inst_vb[vslices[si].inst];
     for (size_t k = vslices[si].lo; k < vslices[si].hi; ++k) {
       const HostVertex& s = m.v[k];
-      HostVertex& d = B.wverts[vb + k];
+      HostVertex& d = wverts[vb + k];
       for (int r = 0; r < 3; ++r)   // m[0]*x + m[1]*y + m[2]*z + m[3]
         d.position[r] = M.m[0 + r] * s.position[0] + M.m[4 + r] * s.position[1] + M.m[8 + r] * s.position[2] + M.m[12 + r];
       mul_n(M.n, s.normal, d.normal);
@@ -670,8 +683,9 @@ std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vec
   B.n_tris = n;
   // NaN / Inf anywhere in the flattened positions (bad vertices or a bad instance matrix) is an error: the builder
   // computes bin indices from them
-  for (const auto& v : B.wverts)
+  for (const auto& v : wverts)
     if (!(std::isfinite(v.position[0]) && std::isfinite(v.position[1]) && std::isfinite(v.position[2]))) return "scene_commit: non-finite vertex position after the instance transform";
+  if (refit) { B.wverts.swap(wverts_new); topo->wbt.swap(wbt_new); }
   // ---- triangle boxes, scene bounds ------------------------------------------------------------------
   std::vector<Box> tbox(n);
   Box sb = empty_box();
@@ -1123,7 +1137,7 @@ std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vec
         const uint32_t vi = B.widx[p * 3 + (uint32_t)k];
         const HostVertex& v = B.wverts[vi];
         t[k * 2 + 0] = v.texcoord[0]; t[k * 2 + 1] = v.texcoord[1];
-        for (int j = 0; j < 3; ++j) { t[6 + k * 3 + j] = v.tangent[j]; t[15 + k * 3 + j] = wbt[(size_t)vi * 3 + (size_t)j]; }
+        for (int j = 0; j < 3; ++j) { t[6 + k * 3 + j] = v.tangent[j]; t[15 + k * 3 + j] = topo->wbt[(size_t)vi * 3 + (size_t)j]; }
       }
     }
   }

@@ -446,3 +446,27 @@ def test_launch_policy_is_reported_without_a_device(pbr):
     mine = pt.launch_policy()
     assert mine.split(" | ")[0] == dflt.split(" | ")[0] and "bvh=lbvh" in mine and "trace_blocks_per_cu" not in mine      # nothing was configured for a device
 
+
+
+def test_a_refused_host_refit_leaves_the_host_build_as_it_was(pbr):
+    """A transform that overflows to non-finite positions is refused by ptc_scene_refit; the host build (what the debug getters describe, and what a later
+    refit starts from) must still be the committed one — vertices, tree and tables."""
+    d = pbr.scenes.by_name("textured_objects")
+    pt = pbr.PathTracer(pbr.DEVICE_NONE).load_scene(d)
+    v0, i0, m0 = pt.flat_scene()
+    u0 = pt.bvh()[0].view(np.uint32).copy()
+    s0 = pt.shading_tables()[0].view(np.uint32).copy()
+    big = np.eye(4, dtype=np.float32); big[0, 0] = 3e38; big[3, 0] = 3e38
+    pt.update_instance(0, matrix=big.reshape(16))
+    with pytest.raises(pbr.PtcError, match="non-finite"):
+        pt.scene_refit()
+    v1, _, _ = pt.flat_scene()
+    assert np.array_equal(v0.view(np.uint32), v1.view(np.uint32)) and np.array_equal(pt.bvh()[0].view(np.uint32), u0)
+    assert np.array_equal(pt.shading_tables()[0].view(np.uint32), s0)
+    it = d.instances[0]
+    if getattr(it, "matrix", None) is not None:
+        pt.update_instance(0, matrix=it.matrix)
+    else:
+        pt.update_instance(0, it.t, it.q_wxyz, it.s)
+    pt.scene_refit()                                   # the original transform again: the committed bytes
+    assert np.array_equal(pt.bvh()[0].view(np.uint32), u0) and np.array_equal(pt.flat_scene()[0].view(np.uint32), v0.view(np.uint32))
