@@ -1264,6 +1264,9 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(const De
         const uint32_t i = i0 + lane;
         int cls = -1;
         if (i < n) cls = w_pref >= 0 ? ((w_pref >> HIT_CLASS_SHIFT) & (PTC_MATERIAL_CLASSES - 1)) : (has_env ? PTC_MATERIAL_CLASSES - 1 : -1);
+#ifdef SHADE_TWO_RING     // experiment (profiles/r04_shade_variants.txt): two rings only — textured hits / everything else — the split the hit word's class >= 2 gives
+        if (cls >= 0) cls = (cls >= 2 && cls != PTC_MATERIAL_CLASSES - 1) ? 1 : 0;
+#endif
         i0 += 64u;
         w_pref = i0 + lane < n ? __float_as_int(q.hit[base + i0 + lane].y) : -1;
         uint64_t rem = __ballot(cls >= 0);
@@ -1347,7 +1350,11 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_shade(const De
       bool use_env = false;
       if ((int)b < fr.max_bounces && env_nee) use_env = sc.n_lights == 0u || rng_f(key, rb, 7) < p_env;
       v3 wi_env = V3(0, 0, 0);
+#ifdef SHADE_ENV_ALWAYS    // experiment (profiles/r04_shade_variants.txt): the environment sample's chain of loads issued by every lane, so that the env / area choice diverges in arithmetic only
+      if ((int)b < fr.max_bounces && env_nee) wi_env = env_sample(sc, env_marg, env_marg_guide, rng_f(key, rb, 1), rng_f(key, rb, 2));
+#else
       if (use_env) wi_env = env_sample(sc, env_marg, env_marg_guide, rng_f(key, rb, 1), rng_f(key, rb, 2));
+#endif
       SSTAMP_LOADS(t_load);
       const v3 Pa = V3(r0.x, r0.y, r0.z), Pb = V3(r1.x, r1.y, r1.z), Pc = V3(r2.x, r2.y, r2.z);
       const v3 Na = V3(r2.w, r3.x, r3.y), Nb = V3(r3.z, r3.w, r4.x), Nc = V3(r4.y, r4.z, r4.w);

@@ -2,7 +2,8 @@
 """The reference viewer's frame loop over the C-ABI (src/gltf_viewer/App.cpp:306-313 turns the nodes, :384-393 renders): per frame a third of the
 instances get a new rotation (ptc_update_instance), the scene is refitted (ptc_scene_refit, on the device), the frame is path-traced at `spp` samples
 per pixel and resolved into the RGBA16F image the viewer's tonemapper reads (ptc_radiance_rgba16f_device_ptr: no copy to the host).  Wall time per
-frame over `frames` frames, and where it goes.  usage: python3 tools/viewer_loop.py [atrium|textured] [spp] [frames] [w h]"""
+frame over `frames` frames, and where it goes.  VIEWER_REBUILD_RATIO=r in the environment adds the policy of examples/viewer_shim.cpp: after the refit, a rebuild on the
+device (ptc_scene_rebuild) when ptc_stats.bvh_sa_cost has grown past r times bvh_sa_cost_built.  usage: python3 tools/viewer_loop.py [atrium|textured] [spp] [frames] [w h]"""
 import json, math, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "physically-based-renderer_amd"))
@@ -17,12 +18,18 @@ d = pbr.scenes.by_name("textured_atrium" if name == "textured" else "atrium")
 pt = pbr.PathTracer(0).load_scene(d)
 moving = [i for i, it in enumerate(d.instances) if i % 3 == 0 and getattr(it, "matrix", None) is None]
 t_refit, t_frame = [], []
+ratio = float(os.environ.get("VIEWER_REBUILD_RATIO", "0"))
+rebuilds = 0
 for k in range(frames + 5):
     t0 = time.perf_counter()
     a = 0.01 * (k + 1)
     for i in moving:
         pt.update_instance(i, d.instances[i].t, (math.cos(a / 2), 0.0, math.sin(a / 2), 0.0), d.instances[i].s)
     pt.scene_refit()
+    if ratio > 0.0:
+        st_ = pt.stats()
+        if st_["bvh_sa_cost"] > ratio * st_["bvh_sa_cost_built"]:
+            pt.scene_rebuild(); rebuilds += 1
     t1 = time.perf_counter()
     pt.frame_begin(w, h, spp, seed=k, max_bounces=8)
     pt.frame_add_samples(spp)
@@ -37,5 +44,6 @@ out = {"scene": d.name, "triangles": st["n_triangles"], "moving_instances": len(
        "ms_per_frame": {"median": 1e3 * float(np.median(t_frame)), "min": 1e3 * float(np.min(t_frame)), "max": 1e3 * float(np.max(t_frame))},
        "fps": 1.0 / float(np.median(t_frame)),
        "ms_update_and_refit": 1e3 * float(np.median(t_refit)), "ms_refit_device_side": 1e3 * st["seconds_refit"],
-       "Mpaths_per_s": w * h * spp / float(np.median(t_frame)) / 1e6, "half_image_device_ptr": hex(ptr)}
+       "Mpaths_per_s": w * h * spp / float(np.median(t_frame)) / 1e6, "half_image_device_ptr": hex(ptr),
+       "rebuild_ratio": ratio, "rebuilds": rebuilds, "sa_cost_ratio_at_end": st["bvh_sa_cost"] / st["bvh_sa_cost_built"]}
 print(json.dumps(out))
