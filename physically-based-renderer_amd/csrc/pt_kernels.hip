@@ -42,6 +42,9 @@
 #ifndef TRACE_NODE_MIN
 #define TRACE_NODE_MIN 40         // leave the node loop when fewer lanes than this are still at interior nodes
 #endif                            // while others wait at a leaf (keeps both phases well populated; 24: -6 %, 32: -1.5 %, 48: -3 %, 56: -18 %)
+#ifndef TRACE_NODE_MIN_ANY
+#define TRACE_NODE_MIN_ANY TRACE_NODE_MIN      // the same threshold in k_trace_any (swept separately in round 4: profiles/r04_trace_variants.txt)
+#endif
 #ifndef SHADE_BLOCK
 #define SHADE_BLOCK 256           // a block only shares the staged light / material / row-cdf tables; its waves never synchronise after that.  Round 3a (FLAT gathers): 64: +19 % kernel
                                   // time, 128: +1 %, 256: 0, 512: -2 %; round 3b (global gathers, 64 segments per CU): 128 / 256 / 512 = 0.1208 / 0.1180 / 0.1178 s per 6 steps on the atrium,
@@ -828,7 +831,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_any(DevS
       for (;;) {
         const uint64_t mn = __ballot(cur >= 0);
         if (!mn) break;
-        if (__popcll(mn) < TRACE_NODE_MIN && __ballot(cur == CUR_LEAF)) break;
+        if (__popcll(mn) < TRACE_NODE_MIN_ANY && __ballot(cur == CUR_LEAF)) break;
         nv += (unsigned long long)__popcll(mn);
         if (cur >= 0) {
           uint32_t nb, masks;

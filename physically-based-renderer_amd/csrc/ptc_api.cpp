@@ -90,10 +90,10 @@ struct ptc_ctx {
   std::string err;
   LaunchCfg cfg{};
   uint32_t toplet_budget = 73;   // 64-byte records staged in LDS: the top three levels (1+8+64 nodes) of the tree = 4.6 KB
-  size_t max_batch_paths = (size_t)1 << 29;   // paths in flight over all lanes.  Large batches amortise what a launch costs regardless of its size
-                                              // (drain of the persistent waves, small late-bounce launches): 2^29 is 1.5 % faster than 2^28, 2^27 3 % and
-                                              // 2^25 24 % slower.  176 B per path = 94 GB of queues when a 1080p frame is rendered at >= 258 spp — sized
-                                              // for 288 GB of HBM; frame_begin lowers it to what 60 % of the free memory holds.
+  size_t max_batch_paths = (size_t)7 << 27;   // paths in flight over all lanes (939,524,096).  Large batches amortise what a launch costs regardless of its size
+                                              // (drain of the persistent waves, small late-bounce launches): round 2 measured 2^29 1.5 % faster than 2^28, 2^27 3 % and
+                                              // 2^25 24 % slower; round 4 7 x 2^27 another 0.8 % faster than 2^29 (profiles/r04_trace_variants.txt).  176 B per path = 165 GB of
+                                              // queues when a 1080p frame is rendered at >= 453 spp — sized for 288 GB of HBM; frame_begin lowers it to what 60 % of the free memory holds.
   bool timing = true;
   // description
   std::vector<HostMaterial> mats;
