@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Differential fuzzing of GPU vs oracle on random scenes (the generator of tests/test_gpu_parity.py): image bits and all traversal counters; every third
 scene through the LBVH builder, every other scene moved and refitted afterwards (ptc_update_instance + ptc_scene_refit against the oracle's; the refit runs on
-the device, csrc/pt_refit.hip, and its BVH units and shading tables are also held byte for byte against a host refit of the same moves on a description-only context).
+the device, csrc/pt_refit.hip, and its BVH units and shading tables are also held byte for byte against a host refit of the same moves on a description-only context);
+every scene with two triangles or more is finally REBUILT on the device (ptc_scene_rebuild, csrc/pt_build.hip) and held, byte for byte, against a fresh host commit of the scene
+as it then stands with the LBVH builder, and its image and counters against the oracle's LBVH of it.
 usage: python tools/fuzz_parity.py [n] [seed]"""
 import importlib.util, os, sys
 import numpy as np
@@ -14,6 +16,7 @@ n, seed = (int(sys.argv[1]) if len(sys.argv) > 1 else 200), (int(sys.argv[2]) if
 rng = np.random.default_rng(seed)
 bad = 0
 n_dev_refits = 0
+n_rebuilds = 0
 for k in range(n):
     if k % 50 == 0: print("scene", k, flush=True)
     d = tg._random_scene(pbr.scene, rng, k)
@@ -26,6 +29,7 @@ for k in range(n):
     if not ok:
         bad += 1
         print("MISMATCH scene", k, d.bvh_builder, "pixels", int((g != c).any(-1).sum()), flush=True)
+    moves = []
     if k % 2 == 0:          # every other scene is then moved (random new transforms for a third of its instances) and refitted on both sides
         moved = False
         host = pbr.PathTracer(pbr.DEVICE_NONE).load_scene(d)
@@ -35,12 +39,13 @@ for k in range(n):
             if getattr(it, "matrix", None) is not None:
                 m = np.asarray(it.matrix, np.float32).reshape(16).copy()
                 m[12:15] += rng.normal(0, 0.3, 3).astype(np.float32)
-                pt.update_instance(i, matrix=m); o.update_instance(i, matrix=m); host.update_instance(i, matrix=m)
+                pt.update_instance(i, matrix=m); o.update_instance(i, matrix=m); host.update_instance(i, matrix=m); moves.append((i, ("m", m)))
             else:
                 q = rng.normal(0, 1, 4); q /= np.linalg.norm(q)
                 t = tuple(float(x) for x in np.asarray(it.t) + rng.normal(0, 0.3, 3))
                 sc = tuple(float(x) for x in np.asarray(it.s) * rng.uniform(0.7, 1.4, 3))
                 pt.update_instance(i, t, tuple(float(x) for x in q), sc); o.update_instance(i, t, tuple(float(x) for x in q), sc); host.update_instance(i, t, tuple(float(x) for x in q), sc)
+                moves.append((i, ("t", t, tuple(float(x) for x in q), sc)))
             moved = True
         if moved:
             pt.scene_refit(); o.scene_refit()
@@ -55,5 +60,33 @@ for k in range(n):
             if not ok:
                 bad += 1
                 print("MISMATCH after refit, scene", k, d.bvh_builder, "pixels", int((g != c).any(-1).sum()), flush=True)
-print(f"{n} scenes, {n_dev_refits} refits on the device, {bad} mismatches")
+    # the tree rebuilt on the device = the host's LBVH build of the scene as it now stands (moved or not), to the byte; image and counters = the oracle's LBVH
+    if pt.stats()["n_triangles"] >= 2:
+        import copy
+        d2 = copy.deepcopy(d)
+        d2.bvh_builder = "lbvh"
+        try:
+            pt.scene_rebuild()
+        except pbr.PtcError as e:
+            bad += 1
+            print("REBUILD FAILED scene", k, e, flush=True)
+            continue
+        n_rebuilds += 1
+        for i, m in moves:                      # the moves, written into the description: a commit of THAT is what the rebuilt tree must equal
+            if m[0] == "m":
+                d2.instances[i].matrix = m[1]
+            else:
+                d2.instances[i].t, d2.instances[i].q_wxyz, d2.instances[i].s = m[1], m[2], m[3]
+        fresh = pbr.PathTracer(pbr.DEVICE_NONE).load_scene(d2)
+        o2 = ora.Oracle().load_scene(d2)
+        a, b = tg._scene_bytes(pt), tg._scene_bytes(fresh)
+        if not all(a[x].shape == b[x].shape and np.array_equal(a[x], b[x]) for x in a):
+            bad += 1
+            print("MISMATCH device rebuild vs host LBVH commit, scene", k, [x for x in a if not (a[x].shape == b[x].shape and np.array_equal(a[x], b[x]))], flush=True)
+        g, c = pt.render(w, h, spp, seed=s, max_bounces=mb), o2.render(w, h, spp, seed=s, max_bounces=mb)
+        ok = np.array_equal(g.view(np.uint32), c.view(np.uint32)) and all(pt.stats()[x] == o2.stats()[x] for x in tg.COUNTERS)
+        if not ok:
+            bad += 1
+            print("MISMATCH after rebuild, scene", k, "pixels", int((g != c).any(-1).sum()), flush=True)
+print(f"{n} scenes, {n_dev_refits} refits on the device, {n_rebuilds} rebuilds on the device, {bad} mismatches")
 sys.exit(1 if bad else 0)
