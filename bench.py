@@ -238,7 +238,8 @@ def main():
 
     # PTC_TRACE_OVERLAP: 2 = every batch, 1 = batches of <= 2^26 paths: closest(b + 1) and any(b) then run beside each other and their event times include each other
     ov = int(os.environ.get("PTC_TRACE_OVERLAP", "1"))
-    kernel_overlap = bool(ov == 2 or (ov == 1 and pt.internals()["per_batch"] * (args.width * args.height // max(1, tile_count)) <= (1 << 26)))
+    batch_samples = min(pt.internals()["per_batch"], K * S)                   # the deferred batching issues full batches, and what is left at the resolve as one more
+    kernel_overlap = bool(ov == 2 or (ov == 1 and batch_samples * (args.width * args.height // max(1, tile_count)) <= (1 << 26)))
     # per-rank times, so that a poor scaling point can be attributed: tile imbalance (spread of the kernel sums), the collective
     # (reduce_ms: the collective as each rank's stream sees it, i.e. including the wait for the slowest rank) or launch tails
     per_rank = None

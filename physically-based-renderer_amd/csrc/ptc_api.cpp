@@ -934,6 +934,7 @@ int host_build_and_upload(ptc_ctx* c, std::chrono::steady_clock::time_point t0, 
   c->built = built;
   const int rc = commit_upload(c, t0);
   if (rc) return rc;
+  c->last_refit_on_device = false;
   const double dt = c->stats.seconds_commit;
   c->stats.seconds_commit = keep.seconds_commit; c->stats.seconds_refit = keep.seconds_refit; c->stats.seconds_rebuild = keep.seconds_rebuild;
   (as_refit ? c->stats.seconds_refit : c->stats.seconds_rebuild) = dt;

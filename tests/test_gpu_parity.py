@@ -385,6 +385,8 @@ def test_bench_two_rank_rehearsal(gpu):
     pr = d["per_rank"]                                                             # what makes a scaling point readable: per-rank kernel sums, wall, paths
     assert len(pr["wall"]["ranks"]) == 2 and 0 < pr["wall"]["min"] <= pr["wall"]["max"] and sum(pr["paths"]["ranks"]) == d["config"]["paths"]
     assert pr["seconds_trace_closest"]["min"] > 0 and "reduce_ms" in pr and "written from the generator by rank 0" in d["config"]["scene_source"]
+    assert pr["reduce_impl"] == "torch.distributed.reduce" and pr["batches_per_rank"] >= 1 and pr["kernel_seconds_overlap"] is True      # small batches: closest(b + 1) beside any(b)
+    assert "trace_blocks_per_cu=" in d["launch_policy"] and d["launch_policy"].startswith(d["launch_policy_defaults"].split(" | ")[0])
     r = run_torchrun(2, args + ["--scaling", "weak"], cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
@@ -768,6 +770,27 @@ def test_rebuild_on_the_device_writes_the_bytes_of_the_host_lbvh_build(gpu, ora,
     dev.scene_refit()
     assert dev.internals()["refit_on_device"] == 1
     assert _bits_equal(dev.render(w, h, 2, seed=7, max_bounces=4), ref)
+    # the host has no topology of a tree the device built: a host-path refit builds from scratch (with the description's builder), PTC_REBUILD=host likewise (LBVH)
+    os.environ["PTC_REFIT"] = "host"
+    try:
+        dev.scene_refit()
+    finally:
+        del os.environ["PTC_REFIT"]
+    assert dev.internals()["refit_on_device"] == 0
+    assert _bits_equal(dev.render(w, h, 2, seed=7, max_bounces=4), ref)
+    os.environ["PTC_REBUILD"] = "host"
+    try:
+        dev.scene_rebuild()
+    finally:
+        del os.environ["PTC_REBUILD"]
+    got = _scene_bytes(dev)
+    for key in want:
+        assert want[key].shape == got[key].shape and np.array_equal(want[key], got[key]), f"PTC_REBUILD=host: {key} differs"
+    assert _bits_equal(dev.render(w, h, 2, seed=7, max_bounces=4), ref)
+    dev.scene_rebuild()                                      # and the device again, over the host's build
+    got = _scene_bytes(dev)
+    for key in want:
+        assert want[key].shape == got[key].shape and np.array_equal(want[key], got[key]), f"device rebuild after a host build: {key} differs"
     print(f"{name}: {st['n_triangles']} triangles, rebuild on the device {dev.stats()['seconds_rebuild'] * 1e3:.2f} ms (commit on the host {st['seconds_commit'] * 1e3:.1f} ms); "
           f"SA cost built {built_cost:.2f}, refitted after the move {refit_cost:.2f}, rebuilt {sg['bvh_sa_cost_built']:.2f}")
 
