@@ -37,6 +37,13 @@ int ptc_png_decode_rgba8(const unsigned char* data, unsigned long long n, unsign
 int ptc_jpeg_decode_rgba8(const unsigned char* data, unsigned long long n, unsigned char* out, unsigned long long out_capacity,
                           int* w, int* h, char* err, int err_len);
 
+/* Radiance RGBE (.hdr) file image → w*h*3 floats, row 0 on top: what stbi_loadf(..., 3) gives for such a file (stb/stb_image.h, stbi__hdr_load: "-Y h +X w" layout,
+ * flat or new-style run-length scanlines, pixel = (r, g, b) * 2^(e - 136)) — bit for bit (tests/test_hdr.py against oracle/_ref).  The lat-long environment maps one
+ * finds in the wild are in this format: `ptc_render --env sky.hdr` reads them through it (ptc_set_env_latlong_rgb32f takes the floats).  out may be NULL to query the
+ * size only; out_capacity_floats counts floats. */
+int ptc_hdr_decode_rgb32f(const unsigned char* data, unsigned long long n, float* out, unsigned long long out_capacity_floats,
+                          int* w, int* h, char* err, int err_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -295,3 +295,20 @@ def ref_stb_decode(data: bytes) -> np.ndarray:
     out = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (h.value, w.value, 4)).copy()
     L.stbi_image_free(p)
     return out
+
+
+def ref_stb_decode_float(data: bytes) -> np.ndarray:
+    """stbi_loadf_from_memory(..., 3) of the reference's stb build: what its image path yields for a Radiance .hdr file.  Returns (h, w, 3) float32."""
+    L = C.CDLL(_REF_STB)
+    L.stbi_loadf_from_memory.restype = C.c_void_p
+    L.stbi_loadf_from_memory.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
+    L.stbi_failure_reason.restype = C.c_char_p
+    L.stbi_image_free.argtypes = [C.c_void_p]
+    w, h, ch = C.c_int(0), C.c_int(0), C.c_int(0)
+    p = L.stbi_loadf_from_memory(data, len(data), C.byref(w), C.byref(h), C.byref(ch), 3)
+    if not p:
+        raise ValueError((L.stbi_failure_reason() or b"stb_image failed").decode())
+    out = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), (h.value, w.value, 3)).copy()
+    L.stbi_image_free(p)
+    return out
+

@@ -2,7 +2,11 @@
 // buffer, PNG (8-bit RGBA, stored-deflate: no compression library needed) for the tonemapped output that the
 // reference only ever presents to a swapchain (src/gltf_viewer/App.cpp:384-393).
 #pragma once
+#include <cmath>
 #include <cstdint>
+#include <iterator>
+#include <cstring>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <stdexcept>
@@ -39,6 +43,88 @@ inline std::vector<float> read_pfm(const std::string& path, int& w, int& h) {
     for (int x = 0; x < w; ++x)
       for (int c = 0; c < 3; ++c) out[((std::size_t)y * w + x) * 3 + c] = raw[((std::size_t)(h - 1 - y) * w + x) * ch + (ch == 3 ? c : 0)];
   return out;
+}
+
+// Radiance RGBE (.hdr / .pic) from memory → w*h*3 floats, row 0 = top: the format the reference's image::loadImage2D would take through stb_image's HDR path
+// (src/pbr_engine/image/stb/stb_image.h: stbi__hdr_load).  Header: "#?RADIANCE" or "#?RGBE", lines up to an empty one, one of them "FORMAT=32-bit_rle_rgbe"; then
+// "-Y h +X w" (the only orientation stb reads); scanlines flat (4 bytes per pixel) or new-style run-length encoded (2 2 hi lo, then the four channels one after
+// the other: a count byte > 128 = a run of count - 128, else that many literal bytes).  Pixel: (r, g, b) * 2^(e - 136), e = 0 → black — ldexp, exact in float.
+inline std::vector<float> decode_hdr(const std::uint8_t* d, std::size_t n, int& w, int& h) {
+  std::size_t at = 0;
+  auto line = [&]() { std::string l; while (at < n && d[at] != '\n') l.push_back((char)d[at++]); if (at < n) ++at; return l; };
+  const std::string magic = line();
+  if (magic != "#?RADIANCE" && magic != "#?RGBE") throw std::runtime_error("not a Radiance HDR image");
+  bool fmt = false;
+  for (;;) {
+    if (at >= n) throw std::runtime_error("HDR: truncated header");
+    const std::string l = line();
+    if (l.empty()) break;
+    if (l == "FORMAT=32-bit_rle_rgbe") fmt = true;
+  }
+  if (!fmt) throw std::runtime_error("HDR: unsupported format (only 32-bit_rle_rgbe)");
+  const std::string dims = line();
+  long hh = 0, ww = 0;
+  {
+    if (dims.compare(0, 3, "-Y ") != 0) throw std::runtime_error("HDR: unsupported data layout (only -Y h +X w)");
+    char* end = nullptr;
+    hh = std::strtol(dims.c_str() + 3, &end, 10);
+    while (*end == ' ') ++end;
+    if (std::strncmp(end, "+X ", 3) != 0) throw std::runtime_error("HDR: unsupported data layout (only -Y h +X w)");
+    ww = std::strtol(end + 3, nullptr, 10);
+  }
+  if (hh <= 0 || ww <= 0 || hh > (1 << 24) || ww > (1 << 24) || (std::uint64_t)hh * (std::uint64_t)ww > (1u << 28)) throw std::runtime_error("HDR: bad size");
+  w = (int)ww; h = (int)hh;
+  std::vector<float> out((std::size_t)w * h * 3);
+  auto convert = [](const std::uint8_t* px, float* o) {
+    if (px[3] != 0) { const float f = std::ldexp(1.0f, (int)px[3] - (128 + 8)); o[0] = (float)px[0] * f; o[1] = (float)px[1] * f; o[2] = (float)px[2] * f; }
+    else o[0] = o[1] = o[2] = 0.0f;
+  };
+  auto need = [&](std::size_t k) { if (at + k > n) throw std::runtime_error("HDR: truncated data"); };
+  std::vector<std::uint8_t> scan((std::size_t)w * 4);
+  bool flat = w < 8 || w >= 32768;                               // the run-length form exists for these widths only
+  for (int y = 0; y < h; ++y) {
+    if (!flat) {
+      need(4);
+      const std::uint8_t c1 = d[at], c2 = d[at + 1], len = d[at + 2];
+      if (c1 != 2 || c2 != 2 || (len & 0x80)) {
+        if (y != 0) throw std::runtime_error("HDR: corrupt scanline header");
+        flat = true;                                             // an old, flat file: this was its first pixel
+      } else {
+        if ((((int)len << 8) | d[at + 3]) != w) throw std::runtime_error("HDR: scanline width does not match the header");
+        at += 4;
+        for (int k = 0; k < 4; ++k) {
+          int i = 0;
+          while (i < w) {
+            need(1);
+            int count = d[at++];
+            if (count > 128) {                                   // a run
+              count -= 128;
+              if (count == 0 || count > w - i) throw std::runtime_error("HDR: corrupt run");
+              need(1);
+              const std::uint8_t v = d[at++];
+              for (int z = 0; z < count; ++z) scan[(std::size_t)(i++) * 4 + k] = v;
+            } else {                                             // literals
+              if (count == 0 || count > w - i) throw std::runtime_error("HDR: corrupt literal block");
+              need((std::size_t)count);
+              for (int z = 0; z < count; ++z) scan[(std::size_t)(i++) * 4 + k] = d[at++];
+            }
+          }
+        }
+        for (int x = 0; x < w; ++x) convert(&scan[(std::size_t)x * 4], &out[((std::size_t)y * w + x) * 3]);
+        continue;
+      }
+    }
+    need((std::size_t)w * 4);                                    // flat: the rest of the file is 4 bytes per pixel, row after row
+    for (int x = 0; x < w; ++x) convert(d + at + (std::size_t)x * 4, &out[((std::size_t)y * w + x) * 3]);
+    at += (std::size_t)w * 4;
+  }
+  return out;
+}
+inline std::vector<float> read_hdr(const std::string& path, int& w, int& h) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) throw std::runtime_error("cannot read " + path);
+  const std::vector<std::uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  return decode_hdr(bytes.data(), bytes.size(), w, h);
 }
 
 namespace detail {

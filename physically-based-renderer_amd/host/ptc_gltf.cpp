@@ -1,5 +1,6 @@
 // ptc_gltf.cpp — C-ABI wrapper of gltf_loader.hpp (include/ptc_gltf.h).
 #include "gltf_loader.hpp"
+#include "image_io.hpp"
 
 #include <ptc_gltf.h>
 
@@ -60,3 +61,20 @@ extern "C" int ptc_png_decode_rgba8(const unsigned char* data, unsigned long lon
     return PTC_E_ARG;
   }
 }
+
+extern "C" int ptc_hdr_decode_rgb32f(const unsigned char* data, unsigned long long n, float* out, unsigned long long out_capacity_floats, int* w, int* h, char* err, int err_len) {
+  auto say = [&](const std::string& m) { if (err && err_len > 0) std::snprintf(err, (size_t)err_len, "%s", m.c_str()); };
+  if (!data || !w || !h) { say("ptc_hdr_decode_rgb32f: null argument"); return PTC_E_ARG; }
+  try {
+    const std::vector<float> px = pbr::image::decode_hdr(data, (std::size_t)n, *w, *h);
+    if (out) {
+      if (out_capacity_floats < px.size()) { say("ptc_hdr_decode_rgb32f: output buffer too small"); return PTC_E_ARG; }
+      std::memcpy(out, px.data(), px.size() * sizeof(float));
+    }
+    return PTC_OK;
+  } catch (std::exception const& e) {
+    say(std::string("ptc_hdr_decode_rgb32f: ") + e.what());
+    return PTC_E_ARG;
+  }
+}
+

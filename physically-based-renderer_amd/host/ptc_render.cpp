@@ -1,10 +1,10 @@
 // ptc_render — dependency-free C++17 offline renderer over the C-ABI (include/ptc.h).
 //   ptc_render (--scene cornell|sphere | --gltf file.glb [--cam-pos x y z --cam-target x y z --fov deg | --viewer-camera]) --width W --height H
-//              --spp N --seed S --bounces B [--raster | --raster16] [--env latlong.pfm | --sky] [--filter nearest|linear] [--bvh sah|lbvh] [--device D] [--gpus N]
+//              --spp N --seed S --bounces B [--raster | --raster16] [--env latlong.pfm|latlong.hdr | --sky] [--filter nearest|linear] [--bvh sah|lbvh] [--device D] [--gpus N]
 //              --out image.pfm [--png image.png] [--ppm image.ppm] [--half image.f16]
 // --gpus N: devices D..D+N-1 share the frame by 32x32-pixel tiles, one RCCL reduce brings it to device D (ptc_group_*).
 // --raster16: the reference's Blinn-Phong pass lit from its G-buffer formats; --half writes the RGBA16F buffer (raw little-endian halves).
-// --env: ordinary lat-long RGB environment map (PFM, top row = up).  The reference's world is y-down (up = -y, CameraData.hpp:28) and
+// --env: ordinary lat-long RGB environment map (PFM or Radiance .hdr, top row = up).  The reference's world is y-down (up = -y, CameraData.hpp:28) and
 // ptc_set_env_latlong_rgb32f takes row 0 = +y, so the rows are flipped on the way in.  --sky: a built-in gradient sky with a sun, for
 // assets that carry no emitters.
 // Without --cam-* a glTF scene is framed from its bounding box (the reference ignores glTF cameras and injects its own).
@@ -157,7 +157,8 @@ int main(int argc, char** argv) {
       rs.setCamera({camPos[0], camPos[1], camPos[2]}, {camTarget[0], camTarget[1], camTarget[2]}, viewerFov > 0.0f ? viewerFov : fovDeg * 3.14159265f / 180.0f, (float)w / h);
       if (!envPath.empty()) {
         int ew = 0, eh = 0;
-        std::vector<float> env = pbr::image::read_pfm(envPath, ew, eh);
+        const bool isHdr = envPath.size() > 4 && (envPath.compare(envPath.size() - 4, 4, ".hdr") == 0 || envPath.compare(envPath.size() - 4, 4, ".pic") == 0);
+        std::vector<float> env = isHdr ? pbr::image::read_hdr(envPath, ew, eh) : pbr::image::read_pfm(envPath, ew, eh);     // Radiance RGBE or PFM, row 0 = top either way
         for (int y = 0; y < eh / 2; ++y)                 // top row = up = -y = the map's last row
           for (int k = 0; k < ew * 3; ++k) std::swap(env[(std::size_t)y * ew * 3 + k], env[(std::size_t)(eh - 1 - y) * ew * 3 + k]);
         if (ptc_set_env_latlong_rgb32f(rs.handle(), env.data(), ew, eh) < 0) throw std::runtime_error(ptc_last_error(rs.handle()));

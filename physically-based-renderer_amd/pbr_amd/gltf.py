@@ -89,6 +89,59 @@ def jpeg_decode(data: bytes) -> np.ndarray:
     return _decode("ptc_jpeg_decode_rgba8", data)
 
 
+def hdr_decode(data: bytes) -> np.ndarray:
+    """Radiance RGBE file image → (h, w, 3) float32 through the library's decoder (ptc_hdr_decode_rgb32f)."""
+    L = _load()
+    L.ptc_hdr_decode_rgb32f.argtypes = [C.c_char_p, C.c_ulonglong, C.POINTER(C.c_float), C.c_ulonglong, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]
+    w, h = C.c_int(0), C.c_int(0)
+    err = C.create_string_buffer(256)
+    if L.ptc_hdr_decode_rgb32f(data, len(data), None, 0, C.byref(w), C.byref(h), err, 256) < 0:
+        raise ValueError(err.value.decode())
+    out = np.zeros((h.value, w.value, 3), np.float32)
+    if L.ptc_hdr_decode_rgb32f(data, len(data), out.ctypes.data_as(C.POINTER(C.c_float)), out.size, C.byref(w), C.byref(h), err, 256) < 0:
+        raise ValueError(err.value.decode())
+    return out
+
+
+def hdr_encode(rgb: np.ndarray, rle: bool = True, magic: str = "#?RADIANCE") -> bytes:
+    """Small Radiance RGBE writer for tests and assets: (h, w, 3) float → shared-exponent pixels (mantissas by truncation, as Ward's float2rgbe), "-Y h +X w",
+    new-style run-length scanlines when `rle` and 8 <= w < 32768 (runs of >= 3 equal bytes, literal blocks otherwise), flat pixels else."""
+    a = np.asarray(rgb, np.float64)
+    h, w = a.shape[:2]
+    v = a.max(2)
+    m, e = np.frexp(np.where(v > 1e-32, v, 1.0))
+    scale = np.where(v > 1e-32, m * 256.0 / np.where(v > 1e-32, v, 1.0), 0.0)
+    px = np.zeros((h, w, 4), np.uint8)
+    px[..., :3] = np.clip((a * scale[..., None]).astype(np.int64), 0, 255)
+    px[..., 3] = np.where(v > 1e-32, e + 128, 0)
+    out = bytearray(f"{magic}\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=1.0\n\n-Y {h} +X {w}\n".encode())
+    if not rle or w < 8 or w >= 32768:
+        return bytes(out) + px.tobytes()
+    for y in range(h):
+        out += bytes((2, 2, w >> 8, w & 255))
+        for k in range(4):
+            row = px[y, :, k]
+            i = 0
+            while i < w:
+                run = 1
+                while i + run < w and run < 127 and row[i + run] == row[i]:
+                    run += 1
+                if run >= 3:
+                    out += bytes((128 + run, int(row[i])))
+                    i += run
+                    continue
+                j = i                                                  # a literal block: up to the next run of >= 3, at most 128 bytes
+                while j < w and j - i < 128:
+                    if j + 2 < w and row[j] == row[j + 1] == row[j + 2]:
+                        break
+                    j += 1
+                if j == i:
+                    j = i + 1
+                out += bytes((j - i,)) + row[i:j].tobytes()
+                i = j
+    return bytes(out)
+
+
 # ----------------------------------------------------------------------------------------------------
 _ADAM7 = ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2))
 
