@@ -139,6 +139,7 @@ int main(int argc, char** argv) {
   }
   try {
     if (gpus < 0) throw std::runtime_error("--gpus must be >= 1");
+    if (gltf.empty() && (!envPath.empty() || sky)) throw std::runtime_error("--env / --sky light a --gltf scene; the built-in scenes carry their own lights");
     auto buildScene = [&](pbr::PathTraceRenderSystem& rs) {
     if (!gltf.empty()) {
       const pbr::gltf::FlatScene fs = pbr::gltf::load(gltf);
