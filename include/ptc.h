@@ -348,8 +348,9 @@ int ptc_debug_get_bvh(ptc_ctx*, uint32_t* n_nodes, uint32_t* n_tris, uint32_t* n
 uint64_t ptc_debug_host_build_id(const ptc_ctx*);
 /* Context internals for tests of the host logic: [0] HIP events created so far, [1] timing spans waiting to be
  * collected, [2] queue capacity (paths) of a lane, [3] samples of one full batch, [4] samples accepted but not yet
- * issued, [5] trace blocks per CU, [6] stack entries per lane kept in LDS, [7] 1 if the last ptc_scene_refit ran on the
- * device (csrc/pt_refit.hip), 0 if on the host. */
+ * issued, [5] trace blocks per CU, [6] stack entries per lane kept in LDS, [7] bit 0: the last ptc_scene_refit ran on the
+ * device (csrc/pt_refit.hip), not on the host; bit 1: the last ptc_scene_commit flattened and built on the device
+ * (csrc/pt_refit.hip + csrc/pt_build.hip: the LBVH builder on a device context). */
 int ptc_debug_get_internals(ptc_ctx*, uint64_t out[8]);
 
 /* The tables shading reads besides the BVH, as they lie in HBM: the per-primitive shading records (4 * stride floats each,

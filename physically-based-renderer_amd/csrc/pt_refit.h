@@ -47,6 +47,8 @@ struct DevRefit {     // device copies of the plan and the scratch arrays; owned
   float4* recs; float4* shade;  // the scene's arrays, rewritten in place
   uint32_t n_verts, n_tris, shade_stride;
 };
+// a commit on the device: the material and emitter index of every primitive into its (zeroed) shading record, which k_refit_prims then completes
+void pt_launch_refit_seed(hipStream_t, const DevRefit&, const int32_t* tri_mat, const int32_t* prim_light);
 // flatten + per-primitive pass (shading records, scene box).  The caller reads `bounds` back before the node pass: the origin grid follows the box.
 void pt_launch_refit_geometry(hipStream_t, const DevRefit&);
 void pt_refit_decode_bounds(const uint32_t raw[8], float lo[3], float hi[3], bool* non_finite);

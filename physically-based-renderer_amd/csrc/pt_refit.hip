@@ -246,6 +246,20 @@ __global__ __launch_bounds__(kNodeBlock) void k_refit_nodes(const DevRefit r, ui
 }
 }  // namespace
 
+// A commit on the device starts from shading records that hold nothing but their two indices (k_refit_prims writes the rest around them).
+namespace {
+__global__ __launch_bounds__(kBlock) void k_refit_seed(float4* shade, uint32_t stride, const int32_t* tri_mat, const int32_t* prim_light, uint32_t n) {
+  const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= n) return;
+  float4* o = shade + (size_t)p * stride;
+  o[0].w = __int_as_float(tri_mat[p]);
+  o[1].w = __int_as_float(prim_light[p]);
+}
+}  // namespace
+void pt_launch_refit_seed(hipStream_t st, const DevRefit& r, const int32_t* tri_mat, const int32_t* prim_light) {
+  if (r.n_tris) hipLaunchKernelGGL(k_refit_seed, dim3((r.n_tris + kBlock - 1) / kBlock), dim3(kBlock), 0, st, r.shade, r.shade_stride, tri_mat, prim_light, r.n_tris);
+}
+
 void pt_launch_refit_geometry(hipStream_t st, const DevRefit& r) {
   hipLaunchKernelGGL(k_refit_init, dim3(1), dim3(64), 0, st, r.bounds);
   if (r.n_verts) hipLaunchKernelGGL(k_refit_flatten, dim3((r.n_verts + kBlock - 1) / kBlock), dim3(kBlock), 0, st, r);

@@ -120,6 +120,7 @@ struct ptc_ctx {
   DevRefit drf{};
   bool host_stale = false;          // the device refitted in place: built's vertex-dependent arrays are those of an earlier state until refresh_host_copy
   bool last_refit_on_device = false;
+  bool commit_on_device = false;      // the last ptc_scene_commit flattened and built on the device (device_commit)
   int trace_rays_per_lane = 8;      // PTC_TRACE_RAYS_PER_LANE: rays per lane of the trace kernels' grid a batch should offer before the grid is made smaller (run_batch)
   int trace_overlap = 1;            // PTC_TRACE_OVERLAP: the shadow rays of bounce b are traced on the lane's second stream beside the closest-hit launch of bounce b + 1 (they are
                                     // independent; k_shade(b + 1) waits for both).  1 (default) = batches of up to 2^26 paths, whose launches do not keep the chip full for long:
@@ -683,7 +684,7 @@ int ptc_add_instance_matrix(ptc_ctx* c, int mesh, const float model[16]) {
 }
 
 namespace {
-int commit_upload(ptc_ctx* c, std::chrono::steady_clock::time_point t0);
+int commit_upload(ptc_ctx* c, std::chrono::steady_clock::time_point t0, bool skeleton = false);
 // Device half of a refit: c->built holds the refitted arrays.  same_sizes: overwrite in place what depends on the vertex positions (textures,
 // environment and materials stay where they are); else (an emitter appeared or vanished under a degenerate scale) upload everything.
 int refit_upload(ptc_ctx* c, bool same_sizes, std::chrono::steady_clock::time_point t0) {
@@ -811,7 +812,8 @@ void scene_free(ptc_ctx* c, const void* p) {
 
 // ptc_scene_rebuild on the device: a refit's geometry pass, then a NEW tree for the vertices as they now lie in HBM (pt_build.hip), then the refit's node pass over
 // it.  Returns PTC_OK, an error, or +1: "not this way" (the set of emitters changed, fewer than two triangles): the caller builds on the host.
-int device_rebuild(ptc_ctx* c) {
+// fresh: the device half of a COMMIT on the device (device_commit): there is no tree yet, the launch configuration follows the tree and is the caller's.
+int device_rebuild(ptc_ctx* c, bool fresh = false) {
   { int rc = ensure_refit_plan(c); if (rc) return rc; }
   if (c->built->n_tris < 2u) return 1;
   std::vector<float> xf, lights, cdf;
@@ -876,11 +878,11 @@ int device_rebuild(ptc_ctx* c) {
   // refit needs is gone — the next host-path refit builds from scratch
   B.n_nodes = out.n_nodes; B.n_units = out.n_units; B.max_depth = out.max_depth; B.n_tri_records = out.n_tri_records;
   B.n_lds_units = B.n_units < c->toplet_budget * 4u ? B.n_units : c->toplet_budget * 4u;
-  B.recs.assign((size_t)B.n_units * 4, 0.0f);
+  B.recs.clear();                       // refresh_host_copy sizes and fills them when somebody asks
   B.topology.reset();
   c->dsc.recs = out.recs; c->dsc.n_lds_units = B.n_lds_units; c->dsc.ray_eps = B.ray_eps;
   for (int k = 0; k < 3; ++k) { c->dsc.grid_lo[k] = B.grid_lo[k]; c->dsc.grid_step[k] = B.grid_step[k]; }
-  {   // a deeper tree needs a deeper overflow slab behind the stack entries kept in LDS
+  if (!fresh) {   // a deeper tree needs a deeper overflow slab behind the stack entries kept in LDS
     const int need = (int)B.max_depth + 2;
     const uint32_t ovf = (uint32_t)(need - c->cfg.stack_lds > 0 ? need - c->cfg.stack_lds : 1);
     if (ovf > c->dsc.ovf_depth) {
@@ -900,10 +902,11 @@ int device_rebuild(ptc_ctx* c) {
       c->dsc.ovf_depth = ovf;
     }
   }
-  for (int l = 0; l < c->n_lanes; ++l) {
-    const DevScene ds = lane_scene(c, l);
-    HIP_TRY(c, hipMemcpyAsync(c->lanes[(size_t)l].d_scene, &ds, sizeof ds, hipMemcpyHostToDevice, st));
-  }
+  if (!fresh)
+    for (int l = 0; l < c->n_lanes; ++l) {
+      const DevScene ds = lane_scene(c, l);
+      HIP_TRY(c, hipMemcpyAsync(c->lanes[(size_t)l].d_scene, &ds, sizeof ds, hipMemcpyHostToDevice, st));
+    }
   HIP_TRY(c, hipStreamSynchronize(st));
   B.sa_cost_fixed = cost_fixed;
   c->stats.bvh_sa_cost = c->stats.bvh_sa_cost_built = (double)cost_fixed / (double)PTC_SA_COST_ONE;
@@ -919,6 +922,8 @@ int refresh_host_copy(ptc_ctx* c) {
   HIP_TRY(c, hipSetDevice(c->device));
   { int rs = sync_all_lanes(c); if (rs) return rs; }
   HostBuilt& B = *c->built;
+  B.recs.resize((size_t)B.n_units * 4);                                     // a tree or a commit made on the device left the host arrays unsized
+  B.shade.resize((size_t)B.n_tris * B.shade_stride * 4);
   HIP_TRY(c, hipMemcpy(B.recs.data(), c->dsc.recs, B.recs.size() * 4, hipMemcpyDeviceToHost));
   HIP_TRY(c, hipMemcpy(B.shade.data(), c->dsc.shade, B.shade.size() * 4, hipMemcpyDeviceToHost));
   HIP_TRY(c, hipMemcpy(B.wverts.data(), c->drf.wverts, B.wverts.size() * sizeof(HostVertex), hipMemcpyDeviceToHost));
@@ -1041,8 +1046,10 @@ int ptc_set_env_latlong_rgb32f(ptc_ctx* c, const float* rgb, int w, int h) {
 }
 
 namespace {
+int commit_finish(ptc_ctx* c, std::chrono::steady_clock::time_point t0);
 // Device half of a commit: upload c->built, size the launches.  The caller has set c->built, the camera and seconds_commit's start.
-int commit_upload(ptc_ctx* c, std::chrono::steady_clock::time_point t0) {
+// skeleton: c->built is ptc_build_skeleton's — the tables are uploaded, the shading records allocated and zeroed, there is no tree yet: device_commit goes on from here.
+int commit_upload(ptc_ctx* c, std::chrono::steady_clock::time_point t0, bool skeleton) {
   ptc_make_camera(c->cam_pos, c->cam_target, c->cam_fov, c->cam_aspect, c->cam);
   c->in_frame = false; c->pending = 0;
   c->committed_insts = c->insts.size();
@@ -1055,7 +1062,7 @@ int commit_upload(ptc_ctx* c, std::chrono::steady_clock::time_point t0) {
     c->stats.bvh_sa_cost = c->stats.bvh_sa_cost_built = (double)c->built->sa_cost_fixed / (double)PTC_SA_COST_ONE;
     return PTC_OK;
   }
-  c->committed = false;
+  c->committed = false; c->commit_on_device = false;
   free_all(c->scene_allocs);
   free_rebuild_spare(c);
   c->refit_ready = false; c->host_stale = false; c->plan = RefitPlan(); c->drf = DevRefit{}; c->xf_live.clear();
@@ -1066,9 +1073,17 @@ int commit_upload(ptc_ctx* c, std::chrono::steady_clock::time_point t0) {
   {
     const float* p = nullptr;
     auto up = [&](const std::vector<float>& v, const float4** out) { if (!rc) { rc = dev_upload(c, c->scene_allocs, &p, v); *out = (const float4*)p; } };
-    up(B.recs, &d.recs); up(B.mats, &d.mats); up(B.lights, &d.lights);
+    if (!skeleton) up(B.recs, &d.recs);
+    up(B.mats, &d.mats); up(B.lights, &d.lights);
     if (!rc) rc = dev_upload(c, c->scene_allocs, &d.cdf, B.cdf);
-    up(B.shade, &d.shade);
+    if (!skeleton) up(B.shade, &d.shade);
+    else if (!rc) {
+      float4* sh = nullptr;
+      const size_t units = (size_t)B.n_tris * B.shade_stride;
+      rc = dev_alloc(c, c->scene_allocs, &sh, units);
+      if (!rc && hipMemsetAsync(sh, 0, units * sizeof(float4), c->lanes[0].stream) != hipSuccess) rc = fail(c, PTC_E_DEVICE, "scene_commit: hipMemset failed");
+      d.shade = sh;
+    }
     if (!rc) rc = dev_upload(c, c->scene_allocs, &d.texels, B.texels);
     if (!rc) { const int32_t* ti = nullptr; rc = dev_upload(c, c->scene_allocs, &ti, B.tex_info); d.tex_info = (const int4*)ti; }
     if (!rc) { const uint32_t* st = nullptr; rc = dev_upload(c, c->scene_allocs, &st, B.set_texels); d.set_texels = (const uint4*)st; }
@@ -1086,6 +1101,12 @@ int commit_upload(ptc_ctx* c, std::chrono::steady_clock::time_point t0) {
   d.n_lights = B.n_lights; d.n_mats = (uint32_t)c->mats.size(); d.n_lds_units = B.n_lds_units; d.ray_eps = B.ray_eps;
   for (int k = 0; k < 3; ++k) { d.grid_lo[k] = B.grid_lo[k]; d.grid_step[k] = B.grid_step[k]; }
   c->dsc = d;
+  if (skeleton) return PTC_OK;
+  return commit_finish(c, t0);
+}
+// the launches follow the tree (its depth, the staged top): configuration, the lanes' copies of the scene, the statistics of a commit
+int commit_finish(ptc_ctx* c, std::chrono::steady_clock::time_point t0) {
+  const HostBuilt& B = *c->built;
   { int rc2 = configure_launch(c); if (rc2) { free_all(c->scene_allocs); return rc2; } }
   c->cfg.shade_tables_lds = pt_shade_tables_fit(c->dsc) ? 1 : 0;
   for (int l = 0; l < c->n_lanes; ++l) {
@@ -1099,6 +1120,31 @@ int commit_upload(ptc_ctx* c, std::chrono::steady_clock::time_point t0) {
   c->stats.bvh_sa_cost = c->stats.bvh_sa_cost_built = (double)B.sa_cost_fixed / (double)PTC_SA_COST_ONE;
   return PTC_OK;
 }
+
+// ptc_scene_commit with the LBVH builder on a device context: the host describes (ptc_build_skeleton: indices, materials, emitters, textures), the DEVICE flattens the
+// vertices, writes the shading records and builds the tree (pt_refit.hip, pt_build.hip) — the arrays in HBM are byte for byte those of the host's LBVH commit
+// (tests/test_gpu_parity.py).  Returns PTC_OK, an error, or +1: "not this way" (fewer than two triangles): the caller commits on the host.
+int device_commit(ptc_ctx* c, std::chrono::steady_clock::time_point t0) {
+  auto built = std::make_shared<HostBuilt>();
+  const std::string e = ptc_build_skeleton(c->mats, c->meshes, c->insts, c->texs, c->env, c->toplet_budget, *built);
+  if (!e.empty()) return fail(c, PTC_E_STATE, e);
+  if (built->n_tris < 2u) return 1;
+  c->built = built;
+  { int rc = commit_upload(c, t0, /*skeleton=*/true); if (rc) return rc; }
+  { int rc = ensure_refit_plan(c); if (rc) { free_all(c->scene_allocs); return rc; } }
+  {
+    const int32_t *d_mat = nullptr, *d_light = nullptr;
+    int rc = dev_upload(c, c->scene_allocs, &d_mat, built->tri_mat);
+    if (!rc) rc = dev_upload(c, c->scene_allocs, &d_light, built->prim_light);
+    if (rc) { free_all(c->scene_allocs); return rc; }
+    pt_launch_refit_seed(c->lanes[0].stream, c->drf, d_mat, d_light);
+  }
+  const int rd = device_rebuild(c, /*fresh=*/true);
+  if (rd) { free_all(c->scene_allocs); c->refit_ready = false; return rd; }
+  const int rf = commit_finish(c, t0);
+  c->commit_on_device = rf == PTC_OK;
+  return rf;
+}
 }  // namespace
 
 int ptc_scene_commit(ptc_ctx* c) {
@@ -1109,6 +1155,13 @@ int ptc_scene_commit(ptc_ctx* c) {
     { int rs = sync_all_lanes(c); if (rs) return rs; }
   }
   const auto t0 = std::chrono::steady_clock::now();
+  if (c->device >= 0 && c->bvh_builder == PTC_BVH_LBVH) {      // north_star's tree is the one that builds on the device: PTC_COMMIT=host keeps the host's build of it (the cross-check path)
+    const char* how = std::getenv("PTC_COMMIT");
+    if (!(how && std::strcmp(how, "host") == 0)) {
+      const int rd = device_commit(c, t0);
+      if (rd <= 0) return rd;
+    }
+  }
   auto built = std::make_shared<HostBuilt>();
   const std::string e = ptc_build_scene(c->mats, c->meshes, c->insts, c->texs, c->env, c->toplet_budget, c->bvh_builder, *built);
   if (!e.empty()) return fail(c, PTC_E_STATE, e);
@@ -1651,7 +1704,7 @@ int ptc_debug_get_internals(ptc_ctx* c, uint64_t out[8]) {
   if (!c || !out) return PTC_E_ARG;
   for (int i = 0; i < 8; ++i) out[i] = 0;
   out[0] = c->events_created; out[1] = c->spans.size(); out[2] = c->lanes.empty() ? 0 : c->lanes[0].q.cap; out[3] = c->per_batch; out[4] = c->pending;
-  out[5] = (uint64_t)c->cfg.trace_blocks_per_cu; out[6] = (uint64_t)c->cfg.stack_lds; out[7] = c->last_refit_on_device ? 1u : 0u;
+  out[5] = (uint64_t)c->cfg.trace_blocks_per_cu; out[6] = (uint64_t)c->cfg.stack_lds; out[7] = (c->last_refit_on_device ? 1u : 0u) | (c->commit_on_device ? 2u : 0u);
   return PTC_OK;
 }
 

@@ -178,6 +178,9 @@ struct HostBuilt {
 std::string ptc_build_scene(const std::vector<HostMaterial>&, const std::vector<HostMesh>&, const std::vector<HostInstance>&,
                             const std::vector<HostTexture>&, const HostEnv&, uint32_t toplet_budget, int bvh_builder /* PTC_BVH_* */,
                             HostBuilt& out);
+// a commit whose flatten, shading records and tree are made on the device: the host's share (ptc_scene.cpp)
+std::string ptc_build_skeleton(const std::vector<HostMaterial>&, const std::vector<HostMesh>&, const std::vector<HostInstance>&,
+                               const std::vector<HostTexture>&, const HostEnv&, uint32_t toplet_budget, HostBuilt& out);
 // the instances' matrices changed since ptc_build_scene filled `out`: same tree, new boxes / records (ptc_scene.cpp)
 std::string ptc_refit_scene(const std::vector<HostMaterial>&, const std::vector<HostMesh>&, const std::vector<HostInstance>&,
                             const std::vector<HostTexture>&, const HostEnv&, HostBuilt& out);

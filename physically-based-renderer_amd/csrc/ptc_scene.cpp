@@ -585,6 +585,125 @@ void ptc_owned_pixels(int w, int h, int tile_rank, int tile_count, std::vector<u
 }
 
 namespace {
+// A texture SET is a distinct (colour, normal, metal-rough) triple of texture ids among the materials that have a texture, numbered in material order.
+void material_sets(const std::vector<HostMaterial>& mats, std::vector<int32_t>& mat_set, std::vector<int32_t>& set_tex) {
+  mat_set.assign(mats.size(), -1); set_tex.clear();
+  for (size_t i = 0; i < mats.size(); ++i) {
+    const HostMaterial& m = mats[i];
+    if (m.tex_color < 0 && m.tex_normal < 0 && m.tex_mr < 0) continue;
+    int32_t found = -1;
+    for (size_t k = 0; k * 3 < set_tex.size(); ++k)
+      if (set_tex[k * 3] == m.tex_color && set_tex[k * 3 + 1] == m.tex_normal && set_tex[k * 3 + 2] == m.tex_mr) { found = (int32_t)k; break; }
+    if (found < 0) { found = (int32_t)(set_tex.size() / 3); set_tex.push_back(m.tex_color); set_tex.push_back(m.tex_normal); set_tex.push_back(m.tex_mr); }
+    mat_set[i] = found;
+  }
+}
+void fill_materials(const std::vector<HostMaterial>& mats, const std::vector<int32_t>& mat_set, HostBuilt& B) {
+  B.mats.assign(mats.size() * 16, 0.0f);
+  for (size_t i = 0; i < mats.size(); ++i) {
+    float* o = &B.mats[i * 16];
+    std::memcpy(&o[12], &mat_set[i], 4);
+    const HostMaterial& m = mats[i];
+    o[0] = m.base[0]; o[1] = m.base[1]; o[2] = m.base[2]; o[3] = m.metallic;
+    o[4] = m.emissive[0]; o[5] = m.emissive[1]; o[6] = m.emissive[2]; o[7] = m.roughness;
+    o[8] = m.base[3]; std::memcpy(&o[9], &m.tex_color, 4); std::memcpy(&o[10], &m.tex_normal, 4); std::memcpy(&o[11], &m.tex_mr, 4);
+  }
+}
+// textures, texture sets and the environment light of a commit (they do not depend on the instances' transforms)
+void fill_textures_env(const std::vector<HostTexture>& texs, const HostEnv& env, const std::vector<int32_t>& set_tex, HostBuilt& B) {
+  for (const auto& t : texs) {
+    const int32_t info[4] = {(int32_t)B.texels.size(), t.w, t.h, 0};
+    B.tex_info.insert(B.tex_info.end(), info, info + 4);
+    const size_t np = (size_t)t.w * (size_t)t.h;
+    for (size_t i = 0; i < np; ++i) {
+      uint32_t u; std::memcpy(&u, &t.px[i * 4], 4);
+      B.texels.push_back(u);
+    }
+  }
+  if (B.texels.empty()) B.texels.push_back(0u);
+  if (B.tex_info.empty()) B.tex_info.assign(4, 0);
+  // texture sets: the set's textures interleaved per texel (absent texture: 0), 8x8 tiles row-major over the image (width and height
+  // padded to multiples of 8), Morton order inside a tile
+  for (size_t k = 0; k * 3 < set_tex.size(); ++k) {
+    int w = -1, h = -1; bool same = true;
+    for (int j = 0; j < 3; ++j) {
+      const int32_t t = set_tex[k * 3 + (size_t)j];
+      if (t < 0) continue;
+      if (w < 0) { w = texs[(size_t)t].w; h = texs[(size_t)t].h; }
+      else if (texs[(size_t)t].w != w || texs[(size_t)t].h != h) same = false;
+    }
+    if (!same || w <= 0) { const int32_t info[4] = {-1, 0, 0, 0}; B.set_info.insert(B.set_info.end(), info, info + 4); continue; }
+    const uint32_t tw = ((uint32_t)w + 7u) / 8u, th = ((uint32_t)h + 7u) / 8u;
+    const size_t off = B.set_texels.size() / 4;
+    if (off + (size_t)tw * th * 64 > 0x7fffffffull) { const int32_t info[4] = {-1, 0, 0, 0}; B.set_info.insert(B.set_info.end(), info, info + 4); continue; }
+    const int32_t info[4] = {(int32_t)off, w, h, (int32_t)tw};
+    B.set_info.insert(B.set_info.end(), info, info + 4);
+    B.set_texels.resize((off + (size_t)tw * th * 64) * 4, 0u);
+    for (int y = 0; y < h; ++y)
+      for (int x = 0; x < w; ++x) {
+        const uint32_t lx = (uint32_t)x & 7u, ly = (uint32_t)y & 7u;
+        const uint32_t mo = (lx & 1u) | ((ly & 1u) << 1) | ((lx & 2u) << 1) | ((ly & 2u) << 2) | ((lx & 4u) << 2) | ((ly & 4u) << 3);
+        const size_t at = off + ((size_t)((uint32_t)y >> 3) * tw + ((uint32_t)x >> 3)) * 64 + mo;
+        for (int j = 0; j < 3; ++j) {
+          const int32_t t = set_tex[k * 3 + (size_t)j];
+          if (t < 0) continue;
+          uint32_t u; std::memcpy(&u, &texs[(size_t)t].px[((size_t)y * (size_t)w + (size_t)x) * 4], 4);
+          B.set_texels[at * 4 + (size_t)j] = u;
+        }
+      }
+  }
+  if (B.set_texels.empty()) B.set_texels.assign(4, 0u);
+  if (B.set_info.empty()) { const int32_t info[4] = {-1, 0, 0, 0}; B.set_info.assign(info, info + 4); }
+  // ---- environment light: radiance + pmf per texel, row-marginal and per-row conditional cdfs ---------------
+  B.env_w = env.w; B.env_h = env.h; B.env_ok = 0;
+  if (env.w > 0 && env.h > 0) {
+    const int w = env.w, hgt = env.h;
+    const size_t np = (size_t)w * (size_t)hgt;
+    B.env.resize(np * 4); B.env_cond.resize(np); B.env_marg.resize((size_t)hgt);
+    std::vector<float> rowsum((size_t)hgt);
+    float totalw = 0.0f;
+    for (int y = 0; y < hgt; ++y) {
+      const float sr = (float)std::sin(3.14159265358979323846 * ((double)y + 0.5) / (double)hgt);
+      float runw = 0.0f;
+      for (int x = 0; x < w; ++x) {
+        const float* t = &env.rgb[((size_t)y * w + x) * 3];
+        float f = fmaf(t[2], 0.0722f, fmaf(t[1], 0.7152f, t[0] * 0.2126f)) * sr;
+        if (!(f > 0.0f)) f = 0.0f;
+        float* o = &B.env[((size_t)y * w + x) * 4];
+        o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = f;
+        runw += f;
+        B.env_cond[(size_t)y * w + x] = runw;
+      }
+      rowsum[(size_t)y] = runw; totalw += runw;
+      for (int x = 0; x < w; ++x) B.env_cond[(size_t)y * w + x] = runw > 0.0f ? B.env_cond[(size_t)y * w + x] / runw : (float)(x + 1) / (float)w;
+      B.env_cond[(size_t)y * w + (size_t)(w - 1)] = 1.0f;
+    }
+    if (totalw > 0.0f) {
+      float runw = 0.0f;
+      for (int y = 0; y < hgt; ++y) { runw += rowsum[(size_t)y]; B.env_marg[(size_t)y] = runw / totalw; }
+      B.env_marg[(size_t)hgt - 1] = 1.0f;
+      for (size_t i = 0; i < np; ++i) B.env[i * 4 + 3] = B.env[i * 4 + 3] / totalw;
+      B.env_ok = 1;
+    } else {
+      for (size_t i = 0; i < np; ++i) B.env[i * 4 + 3] = 0.0f;
+    }
+  }
+  // guide tables of the two cdf searches of env_sample: guide[b] = the index the search returns for r = b / PTC_ENV_GUIDE (16 bits: maps up to 65536 texels wide and high)
+  {
+    auto search = [](const float* cdf, uint32_t n, float r) { uint32_t lo = 0, hi = n - 1u; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cdf[mid] > r) hi = mid; else lo = mid + 1u; } return lo; };
+    if (B.env_ok) {
+      const uint32_t G = PTC_ENV_GUIDE;
+      B.env_marg_guide.resize(G + 1);
+      for (uint32_t b = 0; b <= G; ++b) B.env_marg_guide[b] = (uint16_t)search(B.env_marg.data(), (uint32_t)B.env_h, (float)b / (float)G);
+      B.env_cond_guide.resize((size_t)B.env_h * (G + 1));
+      for (int y = 0; y < B.env_h; ++y)
+        for (uint32_t b = 0; b <= G; ++b) B.env_cond_guide[(size_t)y * (G + 1) + b] = (uint16_t)search(&B.env_cond[(size_t)y * (size_t)B.env_w], (uint32_t)B.env_w, (float)b / (float)G);
+    }
+    if (B.env_marg_guide.empty()) B.env_marg_guide.assign(PTC_ENV_GUIDE + 1, 0);
+    if (B.env_cond_guide.empty()) B.env_cond_guide.assign(PTC_ENV_GUIDE + 1, 0);
+  }
+}
+
 std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vector<HostMesh>& meshes,
                            const std::vector<HostInstance>& insts, const std::vector<HostTexture>& texs, const HostEnv& env,
                            uint32_t toplet_budget, int bvh_builder, HostBuilt& B, bool refit) {
@@ -718,17 +837,8 @@ std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vec
   // A texture SET is a distinct (colour, normal, metal-rough) triple of texture ids among the materials that have a texture, numbered in
   // material order.  The material CLASS travels in the triangle record and the hit word and is what k_shade sorts by (a wave shades 64
   // hits of one class): 0 = untextured Lambert, 1 = untextured GGX, 2..6 = textured, 2 + set % 5; 7 is reserved for environment misses.
-  std::vector<int32_t> mat_set(mats.size(), -1);
-  std::vector<int32_t> set_tex;     // 3 ids per set
-  for (size_t i = 0; i < mats.size(); ++i) {
-    const HostMaterial& m = mats[i];
-    if (m.tex_color < 0 && m.tex_normal < 0 && m.tex_mr < 0) continue;
-    int32_t found = -1;
-    for (size_t k = 0; k * 3 < set_tex.size(); ++k)
-      if (set_tex[k * 3] == m.tex_color && set_tex[k * 3 + 1] == m.tex_normal && set_tex[k * 3 + 2] == m.tex_mr) { found = (int32_t)k; break; }
-    if (found < 0) { found = (int32_t)(set_tex.size() / 3); set_tex.push_back(m.tex_color); set_tex.push_back(m.tex_normal); set_tex.push_back(m.tex_mr); }
-    mat_set[i] = found;
-  }
+  std::vector<int32_t> mat_set, set_tex;     // set of every material (-1: untextured); 3 texture ids per set
+  material_sets(mats, mat_set, set_tex);
   auto material_class = [&](int32_t mi) -> uint32_t {
     const HostMaterial& hm = mats[(size_t)mi];
     if (mat_set[(size_t)mi] >= 0) return 2u + (uint32_t)mat_set[(size_t)mi] % 5u;
@@ -1068,15 +1178,7 @@ std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vec
   B.n_tri_records = n_tri_records;
   B.n_lds_units = B.n_units < toplet_budget * 4u ? B.n_units : toplet_budget * 4u;
   // ---- materials --------------------------------------------------------------------------------------
-  B.mats.assign(mats.size() * 16, 0.0f);
-  for (size_t i = 0; i < mats.size(); ++i) {
-    float* o = &B.mats[i * 16];
-    std::memcpy(&o[12], &mat_set[i], 4);
-    const HostMaterial& m = mats[i];
-    o[0] = m.base[0]; o[1] = m.base[1]; o[2] = m.base[2]; o[3] = m.metallic;
-    o[4] = m.emissive[0]; o[5] = m.emissive[1]; o[6] = m.emissive[2]; o[7] = m.roughness;
-    o[8] = m.base[3]; std::memcpy(&o[9], &m.tex_color, 4); std::memcpy(&o[10], &m.tex_normal, 4); std::memcpy(&o[11], &m.tex_mr, 4);
-  }
+  fill_materials(mats, mat_set, B);
   // ---- emitters (original primitive order), power pmf / cdf ----------------------------------------------
   B.prim_light.assign(n, -1);
   B.lights.clear(); B.cdf.clear();
@@ -1143,99 +1245,7 @@ std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vec
   }
   });
   lap("shading records");
-  if (!refit) {      // textures and the environment do not depend on the instances' transforms
-  for (const auto& t : texs) {
-    const int32_t info[4] = {(int32_t)B.texels.size(), t.w, t.h, 0};
-    B.tex_info.insert(B.tex_info.end(), info, info + 4);
-    const size_t np = (size_t)t.w * (size_t)t.h;
-    for (size_t i = 0; i < np; ++i) {
-      uint32_t u; std::memcpy(&u, &t.px[i * 4], 4);
-      B.texels.push_back(u);
-    }
-  }
-  if (B.texels.empty()) B.texels.push_back(0u);
-  if (B.tex_info.empty()) B.tex_info.assign(4, 0);
-  // texture sets: the set's textures interleaved per texel (absent texture: 0), 8x8 tiles row-major over the image (width and height
-  // padded to multiples of 8), Morton order inside a tile
-  for (size_t k = 0; k * 3 < set_tex.size(); ++k) {
-    int w = -1, h = -1; bool same = true;
-    for (int j = 0; j < 3; ++j) {
-      const int32_t t = set_tex[k * 3 + (size_t)j];
-      if (t < 0) continue;
-      if (w < 0) { w = texs[(size_t)t].w; h = texs[(size_t)t].h; }
-      else if (texs[(size_t)t].w != w || texs[(size_t)t].h != h) same = false;
-    }
-    if (!same || w <= 0) { const int32_t info[4] = {-1, 0, 0, 0}; B.set_info.insert(B.set_info.end(), info, info + 4); continue; }
-    const uint32_t tw = ((uint32_t)w + 7u) / 8u, th = ((uint32_t)h + 7u) / 8u;
-    const size_t off = B.set_texels.size() / 4;
-    if (off + (size_t)tw * th * 64 > 0x7fffffffull) { const int32_t info[4] = {-1, 0, 0, 0}; B.set_info.insert(B.set_info.end(), info, info + 4); continue; }
-    const int32_t info[4] = {(int32_t)off, w, h, (int32_t)tw};
-    B.set_info.insert(B.set_info.end(), info, info + 4);
-    B.set_texels.resize((off + (size_t)tw * th * 64) * 4, 0u);
-    for (int y = 0; y < h; ++y)
-      for (int x = 0; x < w; ++x) {
-        const uint32_t lx = (uint32_t)x & 7u, ly = (uint32_t)y & 7u;
-        const uint32_t mo = (lx & 1u) | ((ly & 1u) << 1) | ((lx & 2u) << 1) | ((ly & 2u) << 2) | ((lx & 4u) << 2) | ((ly & 4u) << 3);
-        const size_t at = off + ((size_t)((uint32_t)y >> 3) * tw + ((uint32_t)x >> 3)) * 64 + mo;
-        for (int j = 0; j < 3; ++j) {
-          const int32_t t = set_tex[k * 3 + (size_t)j];
-          if (t < 0) continue;
-          uint32_t u; std::memcpy(&u, &texs[(size_t)t].px[((size_t)y * (size_t)w + (size_t)x) * 4], 4);
-          B.set_texels[at * 4 + (size_t)j] = u;
-        }
-      }
-  }
-  if (B.set_texels.empty()) B.set_texels.assign(4, 0u);
-  if (B.set_info.empty()) { const int32_t info[4] = {-1, 0, 0, 0}; B.set_info.assign(info, info + 4); }
-  // ---- environment light: radiance + pmf per texel, row-marginal and per-row conditional cdfs ---------------
-  B.env_w = env.w; B.env_h = env.h; B.env_ok = 0;
-  if (env.w > 0 && env.h > 0) {
-    const int w = env.w, hgt = env.h;
-    const size_t np = (size_t)w * (size_t)hgt;
-    B.env.resize(np * 4); B.env_cond.resize(np); B.env_marg.resize((size_t)hgt);
-    std::vector<float> rowsum((size_t)hgt);
-    float totalw = 0.0f;
-    for (int y = 0; y < hgt; ++y) {
-      const float sr = (float)std::sin(3.14159265358979323846 * ((double)y + 0.5) / (double)hgt);
-      float runw = 0.0f;
-      for (int x = 0; x < w; ++x) {
-        const float* t = &env.rgb[((size_t)y * w + x) * 3];
-        float f = fmaf(t[2], 0.0722f, fmaf(t[1], 0.7152f, t[0] * 0.2126f)) * sr;
-        if (!(f > 0.0f)) f = 0.0f;
-        float* o = &B.env[((size_t)y * w + x) * 4];
-        o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = f;
-        runw += f;
-        B.env_cond[(size_t)y * w + x] = runw;
-      }
-      rowsum[(size_t)y] = runw; totalw += runw;
-      for (int x = 0; x < w; ++x) B.env_cond[(size_t)y * w + x] = runw > 0.0f ? B.env_cond[(size_t)y * w + x] / runw : (float)(x + 1) / (float)w;
-      B.env_cond[(size_t)y * w + (size_t)(w - 1)] = 1.0f;
-    }
-    if (totalw > 0.0f) {
-      float runw = 0.0f;
-      for (int y = 0; y < hgt; ++y) { runw += rowsum[(size_t)y]; B.env_marg[(size_t)y] = runw / totalw; }
-      B.env_marg[(size_t)hgt - 1] = 1.0f;
-      for (size_t i = 0; i < np; ++i) B.env[i * 4 + 3] = B.env[i * 4 + 3] / totalw;
-      B.env_ok = 1;
-    } else {
-      for (size_t i = 0; i < np; ++i) B.env[i * 4 + 3] = 0.0f;
-    }
-  }
-  // guide tables of the two cdf searches of env_sample: guide[b] = the index the search returns for r = b / PTC_ENV_GUIDE (16 bits: maps up to 65536 texels wide and high)
-  {
-    auto search = [](const float* cdf, uint32_t n, float r) { uint32_t lo = 0, hi = n - 1u; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cdf[mid] > r) hi = mid; else lo = mid + 1u; } return lo; };
-    if (B.env_ok) {
-      const uint32_t G = PTC_ENV_GUIDE;
-      B.env_marg_guide.resize(G + 1);
-      for (uint32_t b = 0; b <= G; ++b) B.env_marg_guide[b] = (uint16_t)search(B.env_marg.data(), (uint32_t)B.env_h, (float)b / (float)G);
-      B.env_cond_guide.resize((size_t)B.env_h * (G + 1));
-      for (int y = 0; y < B.env_h; ++y)
-        for (uint32_t b = 0; b <= G; ++b) B.env_cond_guide[(size_t)y * (G + 1) + b] = (uint16_t)search(&B.env_cond[(size_t)y * (size_t)B.env_w], (uint32_t)B.env_w, (float)b / (float)G);
-    }
-    if (B.env_marg_guide.empty()) B.env_marg_guide.assign(PTC_ENV_GUIDE + 1, 0);
-    if (B.env_cond_guide.empty()) B.env_cond_guide.assign(PTC_ENV_GUIDE + 1, 0);
-  }
-  }
+  if (!refit) fill_textures_env(texs, env, set_tex, B);
   if (!B.cdf.empty()) B.cdf.back() = 1.0f;
   if (B.cdf.empty()) B.cdf.push_back(1.0f);
   if (B.lights.empty()) B.lights.assign(20, 0.0f);
@@ -1249,6 +1259,62 @@ std::string ptc_build_scene(const std::vector<HostMaterial>& mats, const std::ve
                             const std::vector<HostInstance>& insts, const std::vector<HostTexture>& texs, const HostEnv& env,
                             uint32_t toplet_budget, int bvh_builder, HostBuilt& B) {
   return build_or_refit(mats, meshes, insts, texs, env, toplet_budget, bvh_builder, B, false);
+}
+
+namespace {
+// The emitter table from the emissive primitives alone (emit_prims: prim, instance, its 3 vertex indices inside the instance's mesh), each vertex taken through its instance's
+// matrix with the flatten's expression.  committed != nullptr: a refit — false when the set of emitters is not the committed one.  committed == nullptr: a commit without a host
+// flatten (ptc_build_skeleton) — the emitter index of every primitive is written to *prim_light (sized by the caller, -1 everywhere).
+bool emitters_from_prims(const std::vector<HostMaterial>& mats, const std::vector<HostMesh>& meshes, const std::vector<HostInstance>& insts, const std::vector<int32_t>& emit_prims,
+                         const HostBuilt* committed, std::vector<int32_t>* prim_light, std::vector<float>& lights, std::vector<float>& cdf);
+}
+// The host's share of a commit whose tree is built ON THE DEVICE (ptc_scene_commit with the LBVH builder on a device context): everything that does not need a flattened
+// vertex — world vertex indices and material per primitive, materials, texture sets, environment tables, and the emitter table (the emissive primitives alone, each vertex
+// through its instance's matrix with the flatten's expression).  The flatten, the shading records and the tree are the device's (pt_refit.hip, pt_build.hip): `out` keeps
+// their SIZES, its wverts / shade / recs come back from HBM when somebody asks, and it has no topology (as after ptc_scene_rebuild).
+std::string ptc_build_skeleton(const std::vector<HostMaterial>& mats, const std::vector<HostMesh>& meshes, const std::vector<HostInstance>& insts,
+                               const std::vector<HostTexture>& texs, const HostEnv& env, uint32_t toplet_budget, HostBuilt& B) {
+  if (insts.empty()) return "scene_commit: no instances";
+  uint64_t nv = 0, nt = 0;
+  for (const auto& in : insts) { nv += meshes[(size_t)in.mesh].v.size(); nt += meshes[(size_t)in.mesh].idx.size() / 3; }
+  if (nt >= (1u << 28)) return "scene_commit: too many triangles";
+  B = HostBuilt();
+  B.wverts.resize(nv);
+  B.widx.resize(nt * 3);
+  B.tri_mat.resize(nt);
+  B.n_tris = (uint32_t)nt;
+  std::vector<int32_t> emit_prims;
+  {
+    uint32_t vb = 0, tb = 0;
+    for (size_t i = 0; i < insts.size(); ++i) {
+      const HostMesh& m = meshes[(size_t)insts[i].mesh];
+      const size_t ntm = m.idx.size() / 3;
+      for (size_t k = 0; k < ntm; ++k) {
+        for (int c = 0; c < 3; ++c) B.widx[(tb + k) * 3 + c] = vb + m.idx[k * 3 + c];
+        B.tri_mat[tb + k] = m.material;
+      }
+      const HostMaterial& hm = mats[(size_t)m.material];
+      if (hm.emissive[0] > 0.0f || hm.emissive[1] > 0.0f || hm.emissive[2] > 0.0f)
+        for (size_t k = 0; k < ntm; ++k) {
+          const int32_t e[5] = {(int32_t)(tb + k), (int32_t)i, (int32_t)m.idx[k * 3], (int32_t)m.idx[k * 3 + 1], (int32_t)m.idx[k * 3 + 2]};
+          emit_prims.insert(emit_prims.end(), e, e + 5);
+        }
+      vb += (uint32_t)m.v.size(); tb += (uint32_t)ntm;
+    }
+  }
+  std::vector<int32_t> mat_set, set_tex;
+  material_sets(mats, mat_set, set_tex);
+  fill_materials(mats, mat_set, B);
+  B.prim_light.assign(nt, -1);
+  (void)emitters_from_prims(mats, meshes, insts, emit_prims, nullptr, &B.prim_light, B.lights, B.cdf);
+  B.n_lights = 0;
+  for (int32_t l : B.prim_light) B.n_lights += l >= 0 ? 1u : 0u;
+  bool any_tex = false;
+  for (const auto& m : mats) any_tex = any_tex || m.tex_color >= 0 || m.tex_normal >= 0 || m.tex_mr >= 0;
+  B.shade_stride = any_tex ? 12u : 5u;
+  fill_textures_env(texs, env, set_tex, B);
+  B.n_lds_units = toplet_budget * 4u;      // upper bound until the tree exists (it sizes the trace kernels' LDS)
+  return std::string();
 }
 
 // Refit: the instances' transforms changed (and nothing else).  Vertices are flattened again, every box of the committed tree is
@@ -1282,7 +1348,6 @@ void ptc_prim_classes(const std::vector<HostMaterial>& mats, const std::vector<i
 
 void ptc_refit_plan(const std::vector<HostMaterial>& mats, const std::vector<HostMesh>& meshes, const std::vector<HostInstance>& insts, const HostBuilt& B, RefitPlan& P) {
   P = RefitPlan();
-  const Topology& topo = *std::static_pointer_cast<Topology>(B.topology);
   std::vector<uint32_t> mesh_first(meshes.size());
   for (size_t m = 0; m < meshes.size(); ++m) { mesh_first[m] = (uint32_t)P.mesh_verts.size(); P.mesh_verts.insert(P.mesh_verts.end(), meshes[m].v.begin(), meshes[m].v.end()); }
   uint32_t vb = 0, tb = 0;
@@ -1300,6 +1365,8 @@ void ptc_refit_plan(const std::vector<HostMaterial>& mats, const std::vector<Hos
     vb += (uint32_t)m.v.size(); tb += (uint32_t)(m.idx.size() / 3);
   }
   P.n_verts = vb; P.n_tris = tb;
+  if (!B.topology) { P.level_first.assign(1, 0u); return; }      // a commit on the device (ptc_build_skeleton): the level lists come from the device build
+  const Topology& topo = *std::static_pointer_cast<Topology>(B.topology);
   uint32_t maxd = 0;
   for (const Slot& s : topo.order) maxd = s.depth > maxd ? s.depth : maxd;
   std::vector<uint32_t> count(maxd + 2, 0u);
@@ -1334,12 +1401,17 @@ void ptc_refit_grid(const float lo[3], const float hi[3], float grid_lo[3], floa
 
 bool ptc_refit_emitters(const std::vector<HostMaterial>& mats, const std::vector<HostMesh>& meshes, const std::vector<HostInstance>& insts, const RefitPlan& P,
                         const HostBuilt& B, std::vector<float>& lights, std::vector<float>& cdf) {
+  return emitters_from_prims(mats, meshes, insts, P.emit_prims, &B, nullptr, lights, cdf);
+}
+namespace {
+bool emitters_from_prims(const std::vector<HostMaterial>& mats, const std::vector<HostMesh>& meshes, const std::vector<HostInstance>& insts, const std::vector<int32_t>& emit_prims,
+                         const HostBuilt* committed, std::vector<int32_t>* prim_light, std::vector<float>& lights, std::vector<float>& cdf) {
   lights.clear(); cdf.clear();
   std::vector<float> weight;
   int32_t cached_inst = -1;
   Mat34 M{};
-  for (size_t j = 0; j * 5 < P.emit_prims.size(); ++j) {
-    const int32_t* e = &P.emit_prims[j * 5];
+  for (size_t j = 0; j * 5 < emit_prims.size(); ++j) {
+    const int32_t* e = &emit_prims[j * 5];
     const uint32_t p = (uint32_t)e[0];
     const HostMesh& mesh = meshes[(size_t)insts[(size_t)e[1]].mesh];
     const HostMaterial& m = mats[(size_t)mesh.material];
@@ -1358,16 +1430,17 @@ bool ptc_refit_emitters(const std::vector<HostMaterial>& mats, const std::vector
     const float lum = fmaf(m.emissive[2], 0.0722f, fmaf(m.emissive[1], 0.7152f, m.emissive[0] * 0.2126f));
     const float wgt = area * lum;
     const bool is_light = wgt > 0.0f;
-    if (is_light != (B.prim_light[p] >= 0)) return false;
+    if (committed && is_light != (committed->prim_light[p] >= 0)) return false;
     if (!is_light) continue;
-    if (B.prim_light[p] != (int32_t)weight.size()) return false;
+    if (committed && committed->prim_light[p] != (int32_t)weight.size()) return false;
+    if (prim_light) (*prim_light)[p] = (int32_t)weight.size();
     const float il = 1.0f / len;
     weight.push_back(wgt);
     const float rec[20] = {a[0], a[1], a[2], area, e1[0], e1[1], e1[2], 0.0f, e2[0], e2[1], e2[2], 0.0f,
                            cr[0] * il, cr[1] * il, cr[2] * il, 0.0f, m.emissive[0], m.emissive[1], m.emissive[2], 0.0f};
     lights.insert(lights.end(), rec, rec + 20);
   }
-  if (weight.size() != B.n_lights) return false;
+  if (committed && weight.size() != committed->n_lights) return false;
   float total = 0.0f;
   for (float wv : weight) total += wv;
   float run = 0.0f;
@@ -1382,3 +1455,4 @@ bool ptc_refit_emitters(const std::vector<HostMaterial>& mats, const std::vector
   if (lights.empty()) lights.assign(20, 0.0f);
   return true;
 }
+}  // namespace

@@ -395,7 +395,10 @@ class PathTracer:
         buf = (C.c_uint64 * 8)()
         self._ck(self._L.ptc_debug_get_internals(self._h, buf))
         keys = ("events_created", "spans_waiting", "queue_cap", "per_batch", "pending", "trace_blocks_per_cu", "stack_lds", "refit_on_device")
-        return {k: int(buf[i]) for i, k in enumerate(keys)}
+        d = {k: int(buf[i]) for i, k in enumerate(keys)}
+        d["commit_on_device"] = (d["refit_on_device"] >> 1) & 1
+        d["refit_on_device"] &= 1
+        return d
 
     def refit_host_parts(self):
         """The host's share of a refit on the device, checked against the host build (ptc_debug_refit_host_parts)."""

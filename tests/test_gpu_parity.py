@@ -712,6 +712,68 @@ def _coincident_scene(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,kw", [("cornell", {}), ("sphere10k", {}), ("atrium", {"scale": 0.05}), ("textured_atrium", {"scale": 0.05, "tex_size": 64, "env_size": (64, 32)}),
+                                     ("textured_objects", {}), ("coincident", {}), ("atrium", {})])
+def test_commit_on_the_device_writes_the_bytes_of_the_host_lbvh_commit(gpu, ora, name, kw):
+    """ptc_scene_commit with the LBVH builder on a device context (csrc/ptc_api.cpp device_commit): the host only describes — indices, materials, the emitter table from
+    the emissive primitives, textures —, the device flattens the vertices, writes the shading records around their two seeded indices and builds the tree.  What then lies in
+    HBM — unit array, origin grid, shading records (padding included), emitters, cdf, world vertices — is byte for byte what the host's commit of the same description
+    (PTC_COMMIT=host on the same device, and a description-only context) computes; statistics, launch configuration, image and traversal counters agree, the counters with the
+    oracle's LBVH.  A refit of the device-committed scene runs on the device and writes the bytes of the host's refit.  The SAH builder commits on the host, as before."""
+    import copy
+    d = copy.deepcopy(_coincident_scene(gpu) if name == "coincident" else gpu.scenes.by_name(name, **kw))
+    d.bvh_builder = "lbvh"
+    dev = gpu.PathTracer(0).load_scene(d)
+    assert dev.internals()["commit_on_device"] == 1
+    os.environ["PTC_COMMIT"] = "host"
+    try:
+        host = gpu.PathTracer(0).load_scene(d)
+    finally:
+        del os.environ["PTC_COMMIT"]
+    assert host.internals()["commit_on_device"] == 0
+    sd, sh = dev.stats(), host.stats()
+    for key in ("n_triangles", "n_bvh_nodes", "n_emitters", "bvh_max_depth", "bvh_sa_cost", "bvh_sa_cost_built"):
+        assert sd[key] == sh[key], key
+    for key in ("trace_blocks_per_cu", "stack_lds"):
+        assert dev.internals()[key] == host.internals()[key], key
+    w, h = 96, 54
+    gd, gh = dev.render(w, h, 2, seed=7, max_bounces=4), host.render(w, h, 2, seed=7, max_bounces=4)      # rendered BEFORE the arrays are read back: the scene in HBM is what is judged
+    assert _bits_equal(gd, gh)
+    o = ora.Oracle().load_scene(d)
+    assert _bits_equal(gd, o.render(w, h, 2, seed=7, max_bounces=4))
+    sg, so = dev.stats(), o.stats()
+    for key in COUNTERS:
+        assert sg[key] == so[key], key
+    a, b, c = _scene_bytes(dev), _scene_bytes(host), _scene_bytes(gpu.PathTracer(gpu.DEVICE_NONE).load_scene(d))
+    for key in a:
+        assert a[key].shape == b[key].shape and np.array_equal(a[key], b[key]), f"{key} differs in {int((a[key] != b[key]).sum()) if a[key].shape == b[key].shape else -1} words"
+        assert np.array_equal(a[key], c[key]), key
+    print(f"{name}: commit on the device {sd['seconds_commit'] * 1e3:.2f} ms, on the host {sh['seconds_commit'] * 1e3:.2f} ms")
+    # a second commit of the same context (everything of the first is released), then moves + refit: on the device, the bytes of the host path's refit
+    dev.load_scene(d)
+    assert dev.internals()["commit_on_device"] == 1
+    print(f"{name}: second commit on the device {dev.stats()['seconds_commit'] * 1e3:.2f} ms")
+    for i, it in enumerate(d.instances):
+        if i % 2 == 0 and getattr(it, "matrix", None) is None:
+            a_ = 0.4 + 0.05 * i
+            q = (math.cos(a_ / 2), 0.0, math.sin(a_ / 2), 0.0)
+            dev.update_instance(i, it.t, q, it.s); host.update_instance(i, it.t, q, it.s)
+    dev.scene_refit()
+    os.environ["PTC_REFIT"] = "host"
+    try:
+        host.scene_refit()
+    finally:
+        del os.environ["PTC_REFIT"]
+    assert dev.internals()["refit_on_device"] == 1 and host.internals()["refit_on_device"] == 0
+    assert _bits_equal(dev.render(w, h, 2, seed=7, max_bounces=4), host.render(w, h, 2, seed=7, max_bounces=4))
+    a, b = _scene_bytes(dev), _scene_bytes(host)
+    for key in a:
+        assert a[key].shape == b[key].shape and np.array_equal(a[key], b[key]), f"after the refit: {key} differs"
+    d.bvh_builder = "sah"
+    assert gpu.PathTracer(0).load_scene(d).internals()["commit_on_device"] == 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,kw,commit_builder", [("cornell", {}, "lbvh"), ("sphere10k", {}, "lbvh"), ("atrium", {"scale": 0.05}, "lbvh"), ("atrium", {"scale": 0.05}, "sah"),
                                                      ("textured_atrium", {"scale": 0.05, "tex_size": 64, "env_size": (64, 32)}, "lbvh"), ("textured_objects", {}, "sah"),
                                                      ("coincident", {}, "lbvh"), ("atrium", {}, "lbvh")])
@@ -791,7 +853,7 @@ def test_rebuild_on_the_device_writes_the_bytes_of_the_host_lbvh_build(gpu, ora,
     got = _scene_bytes(dev)
     for key in want:
         assert want[key].shape == got[key].shape and np.array_equal(want[key], got[key]), f"device rebuild after a host build: {key} differs"
-    print(f"{name}: {st['n_triangles']} triangles, rebuild on the device {dev.stats()['seconds_rebuild'] * 1e3:.2f} ms (commit on the host {st['seconds_commit'] * 1e3:.1f} ms); "
+    print(f"{name}: {st['n_triangles']} triangles, rebuild on the device {dev.stats()['seconds_rebuild'] * 1e3:.2f} ms (commit, {'on the device' if commit_builder == 'lbvh' else 'SAH on the host'}, {st['seconds_commit'] * 1e3:.1f} ms); "
           f"SA cost built {built_cost:.2f}, refitted after the move {refit_cost:.2f}, rebuilt {sg['bvh_sa_cost_built']:.2f}")
 
 
