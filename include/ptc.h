@@ -94,7 +94,7 @@ typedef struct ptc_stats {
   /* ABI 4 (round 4): what a moved scene's tree costs, so that a caller can decide when a refit is no longer enough.
    * bvh_sa_cost = the surface-area cost of the 8-wide tree as it lies in HBM: sum over the nodes' child slots of half_area(child box) /
    * half_area(scene box when the tree's topology was made), a two-triangle leaf counted twice — the expected number of node visits + triangle
-   * tests of a random long ray, up to a constant; the unit stays through refits, so the figures of a moving scene can be compared.  Written by ptc_scene_commit (host build), by every ptc_scene_refit and ptc_scene_rebuild (one reduction inside the node pass, in
+   * tests of a random long ray, up to a constant; the unit stays through refits, so the figures of a moving scene can be compared.  Written by ptc_scene_commit, by every ptc_scene_refit and ptc_scene_rebuild (one reduction inside the node pass, in
    * fixed point: the same bits whatever the order).  bvh_sa_cost_built = its value when the tree's TOPOLOGY was made (commit or rebuild): the ratio
    * of the two is what examples/viewer_shim.cpp watches. */
   double bvh_sa_cost;
@@ -211,7 +211,11 @@ enum { PTC_BVH_SAH = 0, PTC_BVH_LBVH = 1 };
 int ptc_set_bvh_builder(ptc_ctx*, int builder);
 
 /* Flatten instances to world space (geometry_pass/vertex.glsl:25-36), build + flatten the BVH,
- * build the emitter CDF, upload everything to HBM. */
+ * build the emitter CDF, upload everything to HBM.  With PTC_BVH_SAH (the default) flatten and build run on the host's
+ * thread pool (75 ms at 250 k triangles).  With PTC_BVH_LBVH on a device context the host only describes (indices,
+ * materials, emitter table, textures) and the DEVICE flattens the vertices, writes the shading records and builds the
+ * tree (csrc/pt_refit.hip, csrc/pt_build.hip): 4-8 ms at 250 k triangles, the arrays in HBM byte for byte those of the
+ * host's LBVH commit (PTC_COMMIT=host in the environment keeps that path; ptc_debug_get_internals [7] bit 1 says which ran). */
 int ptc_scene_commit(ptc_ctx*);
 
 /* ---- rendering ----------------------------------------------------------------------------
