@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Differential fuzzing of GPU vs oracle on random scenes (the generator of tests/test_gpu_parity.py): image bits and all traversal counters; every third
-scene through the LBVH builder, every other scene moved and refitted afterwards (ptc_update_instance + ptc_scene_refit against the oracle's; the refit runs on
+scene through the LBVH builder (committed ON THE DEVICE — flatten, shading records, tree — and held byte for byte against the host's commit of the same description), every other scene moved and refitted afterwards (ptc_update_instance + ptc_scene_refit against the oracle's; the refit runs on
 the device, csrc/pt_refit.hip, and its BVH units and shading tables are also held byte for byte against a host refit of the same moves on a description-only context);
 every scene with two triangles or more is finally REBUILT on the device (ptc_scene_rebuild, csrc/pt_build.hip) and held, byte for byte, against a fresh host commit of the scene
 as it then stands with the LBVH builder, and its image and counters against the oracle's LBVH of it.
@@ -17,6 +17,7 @@ rng = np.random.default_rng(seed)
 bad = 0
 n_dev_refits = 0
 n_rebuilds = 0
+n_dev_commits = 0
 for k in range(n):
     if k % 50 == 0: print("scene", k, flush=True)
     d = tg._random_scene(pbr.scene, rng, k)
@@ -29,6 +30,12 @@ for k in range(n):
     if not ok:
         bad += 1
         print("MISMATCH scene", k, d.bvh_builder, "pixels", int((g != c).any(-1).sum()), flush=True)
+    if pt.internals()["commit_on_device"]:       # an LBVH scene on a device context flattens and builds ON THE DEVICE: the bytes of the host's commit of the same description
+        n_dev_commits += 1
+        a, b = tg._scene_bytes(pt), tg._scene_bytes(pbr.PathTracer(pbr.DEVICE_NONE).load_scene(d))
+        if not all(a[key].shape == b[key].shape and np.array_equal(a[key], b[key]) for key in a):
+            bad += 1
+            print("COMMIT MISMATCH scene", k, [key for key in a if a[key].shape != b[key].shape or not np.array_equal(a[key], b[key])], flush=True)
     moves = []
     if k % 2 == 0:          # every other scene is then moved (random new transforms for a third of its instances) and refitted on both sides
         moved = False
@@ -88,5 +95,5 @@ for k in range(n):
         if not ok:
             bad += 1
             print("MISMATCH after rebuild, scene", k, "pixels", int((g != c).any(-1).sum()), flush=True)
-print(f"{n} scenes, {n_dev_refits} refits on the device, {n_rebuilds} rebuilds on the device, {bad} mismatches")
+print(f"{n} scenes, {n_dev_commits} commits on the device, {n_dev_refits} refits on the device, {n_rebuilds} rebuilds on the device, {bad} mismatches")
 sys.exit(1 if bad else 0)
