@@ -79,7 +79,10 @@ typedef struct ptc_stats {
   uint64_t tri_tests_any;
   uint64_t algorithmic_bytes; /* SURVEY §8d byte formula evaluated on the counters above */
   double seconds_render;      /* device time of the frame's kernels (HIP events)         */
-  double seconds_trace_closest; /* HIP-event time of the dominant kernel (sum over launches) */
+  double seconds_trace_closest; /* HIP-event time of the dominant kernel (sum over launches).  The three per-kernel sums cover the batches whose
+                                 * kernels run one after the other; a small batch (<= 2^26 paths) runs k_trace_any(b) beside k_trace_closest(b + 1) and
+                                 * carries the batch's span only (seconds_render) — PTC_TIMING=2 records per-kernel spans for those too (they then
+                                 * include each other), PTC_TIMING=0 records nothing */
   double seconds_trace_any;
   double seconds_shade;
   double seconds_commit;      /* flatten + BVH build + upload                               */

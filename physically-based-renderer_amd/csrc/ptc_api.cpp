@@ -94,7 +94,8 @@ struct ptc_ctx {
                                               // (drain of the persistent waves, small late-bounce launches): round 2 measured 2^29 1.5 % faster than 2^28, 2^27 3 % and
                                               // 2^25 24 % slower; round 4 7 x 2^27 another 0.8 % faster than 2^29 (profiles/r04_trace_variants.txt).  176 B per path = 165 GB of
                                               // queues when a 1080p frame is rendered at >= 453 spp — sized for 288 GB of HBM; frame_begin lowers it to what 60 % of the free memory holds.
-  bool timing = true;
+  int timing = 1;                     // PTC_TIMING: 0 no events at all; 1 (default) a span per batch, and a span per kernel where the kernels of a batch run one after the other
+                                      // (a small batch runs its trace kernels beside each other: their spans would include each other, and 54 event records are 0.2 ms of a 3-ms frame); 2 a span per kernel always
   // description
   std::vector<HostMaterial> mats;
   std::vector<HostMesh> meshes;
@@ -285,7 +286,7 @@ void collect_times(ptc_ctx* c, bool all_done) {
 }
 struct ScopedSpan {   // records a start/stop event pair around launches on one of the context's streams
   ptc_ctx* c; hipStream_t st; Span s{}; bool on;
-  ScopedSpan(ptc_ctx* c_, hipStream_t st_, int kind) : c(c_), st(st_), on(c_->timing) {
+  ScopedSpan(ptc_ctx* c_, hipStream_t st_, int kind, bool enable = true) : c(c_), st(st_), on(c_->timing != 0 && enable) {
     if (!on) return;
     s.kind = kind; s.a = next_event(c); s.b = next_event(c);
     if (!s.a || !s.b) { if (s.a) c->free_events.push_back(s.a); on = false; return; }
@@ -382,17 +383,18 @@ int run_batch(ptc_ctx* c, int l, uint32_t first_sample, uint32_t n_samples) {
     }
     DevScene sc_any = sc;
     if (overlap) sc_any.stack_ovf = ln.stack_ovf2;
+    const bool per_kernel = !overlap || c->timing >= 2;       // overlapped launches: the batch's span only (ptc_stats.seconds_render); seconds_trace_* / seconds_shade stay 0
     for (int b = 0; b <= c->fr.max_bounces; ++b) {
-      { ScopedSpan t(c, st, 0); pt_launch_trace_closest(st, cfg, sc, q, b & 1, false); c->stats.launches_trace_closest++; }
+      { ScopedSpan t(c, st, 0, per_kernel); pt_launch_trace_closest(st, cfg, sc, q, b & 1, false); c->stats.launches_trace_closest++; }
       // k_shade(b) overwrites the shadow queue any(b - 1) reads and adds to the path radiance it adds to
       if (overlap && b > 0) HIP_TRY(c, hipStreamWaitEvent(st, ln.ev_any[(size_t)b - 1], 0));
-      { ScopedSpan t(c, st, 2); pt_launch_shade(st, cfg, ln.d_scene, c->fr, q, b & 1, (uint32_t)b); }
+      { ScopedSpan t(c, st, 2, per_kernel); pt_launch_shade(st, cfg, ln.d_scene, c->fr, q, b & 1, (uint32_t)b); }
       if (b == c->fr.max_bounces) break;                         // the last bounce's shade produces no rays
       pt_launch_scan(st, cfg, q, (b + 1) & 1);
       if (overlap) {      // any(b) on the second stream, beside closest(b + 1)
         HIP_TRY(c, hipEventRecord(ln.ev_scan[(size_t)b], st));
         HIP_TRY(c, hipStreamWaitEvent(ln.stream2, ln.ev_scan[(size_t)b], 0));
-        { ScopedSpan t(c, ln.stream2, 1); pt_launch_trace_any(ln.stream2, cfg, sc_any, q, nullptr); c->stats.launches_trace_any++; }
+        { ScopedSpan t(c, ln.stream2, 1, per_kernel); pt_launch_trace_any(ln.stream2, cfg, sc_any, q, nullptr); c->stats.launches_trace_any++; }
         HIP_TRY(c, hipEventRecord(ln.ev_any[(size_t)b], ln.stream2));
       } else if (shadows) {
         ScopedSpan t(c, st, 1); pt_launch_trace_any(st, cfg, sc, q, nullptr); c->stats.launches_trace_any++;
@@ -562,7 +564,7 @@ ptc_ctx* ptc_create(int device_id) {
   if (const char* s = std::getenv("PTC_TRACE_OVERLAP")) { int v = std::atoi(s); if (v >= 0 && v <= 2) c->trace_overlap = v; }
   if (const char* s = std::getenv("PTC_NODELETS")) c->toplet_budget = (uint32_t)std::strtoul(s, nullptr, 10);
   if (const char* s = std::getenv("PTC_BATCH_PATHS")) { size_t v = std::strtoull(s, nullptr, 10); if (v >= 1024) c->max_batch_paths = v; }
-  if (const char* s = std::getenv("PTC_TIMING")) c->timing = std::atoi(s) != 0;
+  if (const char* s = std::getenv("PTC_TIMING")) { const int v = std::atoi(s); c->timing = v < 0 ? 0 : (v > 2 ? 2 : v); }
   if (const char* s = std::getenv("PTC_BVH")) { if (std::strcmp(s, "lbvh") == 0) c->bvh_default = c->bvh_builder = PTC_BVH_LBVH; }
   if (const char* s = std::getenv("PTC_LANES")) { int v = std::atoi(s); if (v >= 1 && v <= 8) c->n_lanes = v; }
   c->lanes.resize((size_t)c->n_lanes);

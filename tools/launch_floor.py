@@ -1,4 +1,6 @@
 """Fixed cost of a launch of each kernel: event time per launch when the queues hold next to nothing (a 32x32x1 frame) and at a few sizes."""
+import os
+os.environ.setdefault("PTC_TIMING", "2")      # a span per kernel also where a batch's trace kernels run beside each other (small frames)
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "physically-based-renderer_amd"))
