@@ -43,6 +43,10 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this pool needs dmabuf IPC (the host driver has no legacy IPC: RCCL's hipIpcGetMemHandle fails without it); the driver's environment
+# exports it already — set here, before anything touches HIP, for a launch from a bare shell
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "physically-based-renderer_amd"))
