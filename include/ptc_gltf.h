@@ -5,7 +5,7 @@
  * ptc_add_texture_rgba8 / ptc_add_material / ptc_add_mesh / ptc_add_instance_matrix calls of include/ptc.h on `ctx`.
  * Images (Asset::loadImage2D, Asset.cpp:121-133; bufferView, file URI or base64 data URI) are decoded to RGBA8 like
  * image::loadImage2D does (LoadImage.cpp:56-73: 4 channels of 8 bits whatever the file holds) by the library's own PNG
- * and JPEG decoders, which reproduce the output of the reference's vendored stb_image bit for bit (tests/test_jpeg.py,
+ * and JPEG decoders (and BMP, TGA, PGM / PPM: ptc_image_decode_rgba8 below), which reproduce the output of the reference's vendored stb_image bit for bit (tests/test_jpeg.py,
  * tests/test_png.py against oracle/_ref).  Samplers are ignored: the reference creates
  * default samplers (NEAREST, REPEAT) whatever the asset says (Asset.cpp:116-117).
  * Call between ptc_scene_begin and ptc_scene_commit; the camera stays the caller's (the reference ignores glTF
@@ -43,6 +43,14 @@ int ptc_jpeg_decode_rgba8(const unsigned char* data, unsigned long long n, unsig
  * size only; out_capacity_floats counts floats. */
 int ptc_hdr_decode_rgb32f(const unsigned char* data, unsigned long long n, float* out, unsigned long long out_capacity_floats,
                           int* w, int* h, char* err, int err_len);
+
+/* The other still-image formats the reference's image path decodes besides PNG and JPEG and that this loader takes too: Windows BMP (palettes, 16 / 24 / 32 bits,
+ * bit fields; no run-length forms), Truevision TGA (types 1 / 2 / 3 / 9 / 10 / 11) and binary PGM / PPM ("P5" / "P6", 8- or 16-bit) → w*h*4 bytes RGBA8, row 0 on
+ * top: what stbi_load_from_memory(..., 4) gives (stb/stb_image.h stbi__bmp_load, stbi__tga_load, stbi__pnm_load), byte for byte (tests/test_misc_images.py against
+ * oracle/_ref).  kind: 0 = by content, in the reference's order (BMP, PNM, TGA — TGA has no signature and is tried last), 1 = BMP, 2 = TGA, 3 = PNM.  GIF, PSD, PIC and
+ * Radiance-as-texture are not decoded.  Same calling convention as ptc_png_decode_rgba8. */
+int ptc_image_decode_rgba8(int kind, const unsigned char* data, unsigned long long n, unsigned char* out, unsigned long long out_capacity,
+                           int* w, int* h, char* err, int err_len);
 
 #ifdef __cplusplus
 }

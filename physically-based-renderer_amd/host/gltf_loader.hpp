@@ -17,6 +17,7 @@
 #include <ptc.h>
 
 #include "jpeg_decode.hpp"
+#include "misc_decode.hpp"
 #include "png_decode.hpp"
 
 #include <array>
@@ -467,9 +468,14 @@ inline FlatScene load(const std::string& path, int scene_index = -1, bool compos
       bytes = owned.data(); nbytes = owned.size();
     }
     Texture t;
+    // the order in which the reference's decoder tries the formats it knows (stb_image.h, stbi__load_main); GIF, PSD, PIC and Radiance-as-texture are not decoded here
     if (pbr::image::is_png(bytes, nbytes)) t.rgba = pbr::image::decode_png(bytes, nbytes, t.w, t.h);
+    else if (pbr::image::is_bmp(bytes, nbytes)) t.rgba = pbr::image::decode_bmp(bytes, nbytes, t.w, t.h);
     else if (pbr::image::is_jpeg(bytes, nbytes)) t.rgba = pbr::image::decode_jpeg(bytes, nbytes, t.w, t.h);
-    else throw std::runtime_error("image " + std::to_string(ii) + " is neither PNG nor JPEG");
+    else if (pbr::image::is_pnm(bytes, nbytes)) t.rgba = pbr::image::decode_pnm(bytes, nbytes, t.w, t.h);
+    else if (pbr::image::is_tga(bytes, nbytes)) t.rgba = pbr::image::decode_tga(bytes, nbytes, t.w, t.h);
+    else throw std::runtime_error("image " + std::to_string(ii) + " is none of PNG, BMP, JPEG, PGM / PPM, TGA");
+    if (t.w <= 0 || t.h <= 0) throw std::runtime_error("image " + std::to_string(ii) + " is empty");
     out.textures.push_back(std::move(t));
     return image_slot[(size_t)ii] = (int)out.textures.size() - 1;
   };

@@ -89,6 +89,22 @@ def jpeg_decode(data: bytes) -> np.ndarray:
     return _decode("ptc_jpeg_decode_rgba8", data)
 
 
+def image_decode(data: bytes, kind: int = 0) -> np.ndarray:
+    """BMP / TGA / binary PGM-PPM file image → (h, w, 4) uint8 through the loader's decoders (ptc_image_decode_rgba8; kind 0 = by content, 1 BMP, 2 TGA, 3 PNM)."""
+    L = _load()
+    fn = L.ptc_image_decode_rgba8
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.c_char_p, C.c_ulonglong, C.c_void_p, C.c_ulonglong, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]
+    w, h = C.c_int(0), C.c_int(0)
+    err = C.create_string_buffer(256)
+    if fn(kind, data, len(data), None, 0, C.byref(w), C.byref(h), err, 256):
+        raise ValueError(err.value.decode())
+    out = np.empty((h.value, w.value, 4), np.uint8)
+    if fn(kind, data, len(data), out.ctypes.data, out.nbytes, C.byref(w), C.byref(h), err, 256):
+        raise ValueError(err.value.decode())
+    return out
+
+
 def hdr_decode(data: bytes) -> np.ndarray:
     """Radiance RGBE file image → (h, w, 3) float32 through the library's decoder (ptc_hdr_decode_rgb32f)."""
     L = _load()

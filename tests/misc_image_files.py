@@ -1,0 +1,198 @@
+"""Writers of BMP / TGA / PGM / PPM test files (numpy): every header kind, pixel layout and row order the decoders of host/misc_decode.hpp take.
+Used by tests/test_misc_images.py and tests/golden/make_misc_golden.py."""
+import struct
+
+import numpy as np
+
+
+def _pad4(row: bytes) -> bytes:
+    return row + b"\0" * ((-len(row)) & 3)
+
+
+def bmp(img, kind="24", header=40, top_down=False, masks=None, palette_pad=0, extra_gap=0):
+    """img: (h, w, 4) uint8 RGBA.  kind: '24' | '32' (default masks, alpha byte written) | '32zero' (alpha byte 0) | '555' | 'fields16' | 'fields32' |
+    'pal8' | 'pal4' | 'pal1' (img is then (h, w) indices, `palette` = masks: (n, 3) RGB).  header: 12 | 40 | 56 | 108 | 124."""
+    h, w = img.shape[:2]
+    rows = []
+    pal = b""
+    compress = 0
+    fields = b""
+    if kind in ("pal8", "pal4", "pal1"):
+        bpp = {"pal8": 8, "pal4": 4, "pal1": 1}[kind]
+        for y in range(h):
+            idx = img[y].astype(np.uint32)
+            if bpp == 8:
+                row = bytes(idx.astype(np.uint8))
+            elif bpp == 4:
+                v = np.zeros((w + 1) // 2 * 2, np.uint32); v[:w] = idx
+                row = bytes(((v[0::2] << 4) | v[1::2]).astype(np.uint8))
+            else:
+                v = np.zeros((w + 7) // 8 * 8, np.uint32); v[:w] = idx
+                row = bytes(np.packbits(v.astype(np.uint8)).tobytes())
+            rows.append(_pad4(row))
+        for r, g, b in masks:
+            pal += bytes((int(b), int(g), int(r))) + (b"" if header == 12 else b"\0")
+        pal += b"\0" * palette_pad
+    elif kind == "24":
+        bpp = 24
+        for y in range(h):
+            rows.append(_pad4(bytes(img[y, :, [2, 1, 0]].T.reshape(-1).astype(np.uint8))))
+    elif kind in ("32", "32zero"):
+        bpp = 32
+        for y in range(h):
+            px = img[y][:, [2, 1, 0, 3]].copy()
+            if kind == "32zero":
+                px[:, 3] = 0
+            rows.append(bytes(px.reshape(-1)))
+    elif kind == "555":
+        bpp = 16
+        for y in range(h):
+            c = img[y].astype(np.uint32) >> 3
+            rows.append(_pad4(((c[:, 0] << 10) | (c[:, 1] << 5) | c[:, 2]).astype("<u2").tobytes()))
+    elif kind in ("fields16", "fields32"):
+        bpp = 16 if kind == "fields16" else 32
+        compress = 3
+        mr, mg, mb, ma = masks
+        def put(c, m):
+            if m == 0:
+                return np.zeros(len(c), np.uint32)
+            nb = bin(m).count("1"); sh = (m & -m).bit_length() - 1
+            return ((c.astype(np.uint32) >> max(8 - nb, 0)) << sh) & m
+        for y in range(h):
+            v = put(img[y, :, 0], mr) | put(img[y, :, 1], mg) | put(img[y, :, 2], mb) | put(img[y, :, 3], ma)
+            rows.append(_pad4(v.astype("<u2" if bpp == 16 else "<u4").tobytes()))
+        fields = struct.pack("<III", mr, mg, mb)
+    else:
+        raise ValueError(kind)
+    if not top_down:
+        rows = rows[::-1]
+    body = b"".join(rows)
+    if header == 12:
+        info = struct.pack("<IHHHH", 12, w, h, 1, bpp)
+    else:
+        info = struct.pack("<IiiHHIIiiII", header, w, -h if top_down else h, 1, bpp, compress, len(body), 2835, 2835, 0, 0)
+        if header == 56:
+            info += b"\0" * 16                 # the reference skips these 16 bytes and takes bit fields from what FOLLOWS them
+        if header in (40, 56):
+            info += fields if compress == 3 else b""
+        else:
+            mr, mg, mb, ma = masks if compress == 3 else (0, 0, 0, 0)
+            info += struct.pack("<IIII", mr, mg, mb, ma) + b"sRGB"[::-1] + b"\0" * 48
+            if header == 124:
+                info += b"\0" * 16
+    gap = b"\xaa" * extra_gap
+    off = 14 + len(info) + len(pal) + len(gap)
+    return b"BM" + struct.pack("<IHHI", off + len(body), 0, 0, off) + info + pal + gap + body
+
+
+def tga(img, kind="24", rle=False, top_down=False, ident=b"", palette=None, index_bits=8, map_first=0):
+    """img: (h, w, 4) uint8 RGBA, or (h, w) indices for kind 'map*'.  kind: '8' grey | '16ga' grey + alpha | '15' | '16' (5-5-5) | '24' | '32' |
+    'map15' | 'map16' | 'map24' | 'map32' (palette: (n, 4) RGBA)."""
+    h, w = img.shape[:2]
+    mapped = kind.startswith("map")
+
+    def colour(px, bits):            # RGBA rows → file bytes of one pixel each
+        px = np.asarray(px, np.uint32).reshape(-1, 4)
+        if bits == 8:
+            return [bytes([int(p[0])]) for p in px]
+        if bits == "16ga":
+            return [bytes([int(p[0]), int(p[3])]) for p in px]
+        if bits in (15, 16):
+            return [struct.pack("<H", ((int(p[0]) >> 3) << 10) | ((int(p[1]) >> 3) << 5) | (int(p[2]) >> 3)) for p in px]
+        if bits == 24:
+            return [bytes([int(p[2]), int(p[1]), int(p[0])]) for p in px]
+        return [bytes([int(p[2]), int(p[1]), int(p[0]), int(p[3])]) for p in px]
+
+    if mapped:
+        ebits = int(kind[3:])
+        cmap = b"".join(colour(palette, ebits))
+        pixels = [struct.pack("<B" if index_bits == 8 else "<H", int(i)) for i in img.reshape(-1)]
+        itype, bpp, map_len, map_bits = 1, index_bits, len(palette), ebits
+    else:
+        bits = {"8": 8, "16ga": "16ga", "15": 15, "16": 16, "24": 24, "32": 32}[kind]
+        pixels = colour(img.reshape(-1, 4), bits)
+        cmap, map_len, map_bits = b"", 0, 0
+        itype = 3 if kind in ("8", "16ga") else 2
+        bpp = {"8": 8, "16ga": 16, "15": 15, "16": 16, "24": 24, "32": 32}[kind]
+    if not top_down:                 # the file's first row is the image's bottom one
+        pixels = [p for y in range(h - 1, -1, -1) for p in pixels[y * w:(y + 1) * w]]
+    if rle:
+        itype += 8
+        out, i = [], 0
+        while i < len(pixels):
+            j = i
+            while j + 1 < len(pixels) and pixels[j + 1] == pixels[i] and j - i < 127:
+                j += 1
+            if j > i:
+                out.append(bytes([0x80 | (j - i)]) + pixels[i]); i = j + 1
+            else:
+                k = i
+                while k + 1 < len(pixels) and pixels[k + 1] != pixels[k] and k - i < 127:
+                    k += 1
+                out.append(bytes([k - i]) + b"".join(pixels[i:k + 1])); i = k + 1
+        body = b"".join(out)
+    else:
+        body = b"".join(pixels)
+    head = struct.pack("<BBBHHBHHHHBB", len(ident), 1 if mapped else 0, itype, map_first, map_len, map_bits, 0, 0, w, h, bpp, 0x20 if top_down else 0)
+    return head + ident + cmap + body
+
+
+def pnm(img, colour=True, maxv=255, comment=False):
+    """img: (h, w, 3 or 1) integers <= maxv; 16-bit samples are written big-endian as the format says."""
+    h, w = img.shape[:2]
+    head = (b"P6" if colour else b"P5") + (b"\n# made by the test suite\n" if comment else b"\n") + f"{w} {h}".encode() + (b"\n#second comment\r" if comment else b"\n") + f"{maxv}\n".encode()
+    a = np.asarray(img).reshape(h, w, -1)[:, :, : (3 if colour else 1)]
+    return head + (a.astype(">u2").tobytes() if maxv > 255 else a.astype(np.uint8).tobytes())
+
+
+def corpus(seed=11):
+    """(name, bytes) of every variant, deterministic."""
+    rng = np.random.default_rng(seed)
+    out = []
+    img = rng.integers(0, 256, (7, 13, 4), dtype=np.uint8)
+    img[:, :, 3] |= 1                                                            # a non-zero alpha somewhere
+    for hd in (40, 56, 108, 124):
+        out.append((f"bmp24_h{hd}", bmp(img, "24", hd)))
+        out.append((f"bmp32_h{hd}", bmp(img, "32", hd)))
+    out.append(("bmp24_core", bmp(img, "24", 12)))
+    out.append(("bmp24_topdown", bmp(img, "24", 40, top_down=True)))
+    out.append(("bmp32_zero_alpha", bmp(img, "32zero", 40)))
+    out.append(("bmp555", bmp(img, "555", 40)))
+    out.append(("bmp24_gap", bmp(img, "24", 40, extra_gap=20)))
+    for name, m in (("565", (0xf800, 0x07e0, 0x001f, 0)), ("4444", (0x0f00, 0x00f0, 0x000f, 0xf000)), ("1555", (0x7c00, 0x03e0, 0x001f, 0x8000))):
+        out.append((f"bmp_fields16_{name}_h108", bmp(img, "fields16", 108, masks=m)))
+    out.append(("bmp_fields16_565_h40", bmp(img, "fields16", 40, masks=(0xf800, 0x07e0, 0x001f, 0))))
+    out.append(("bmp_fields16_565_h56", bmp(img, "fields16", 56, masks=(0xf800, 0x07e0, 0x001f, 0))))
+    for name, m in (("8888", (0x00ff0000, 0x0000ff00, 0x000000ff, 0xff000000)), ("rgba", (0xff000000, 0x00ff0000, 0x0000ff00, 0x000000ff)), ("a2", (0x0ff00000, 0x000ff000, 0x00000ff0, 0xc0000000)),
+                    ("x765", (0x0001fc00, 0x000003f0, 0x0000001f, 0))):
+        out.append((f"bmp_fields32_{name}_h124", bmp(img, "fields32", 124, masks=m)))
+    out.append(("bmp_fields32_rgbx_h40", bmp(img, "fields32", 40, masks=(0xff000000, 0x00ff0000, 0x0000ff00, 0))))
+    for bits, n in ((8, 256), (8, 37), (4, 16), (4, 5), (1, 2)):
+        pal = rng.integers(0, 256, (n, 3), dtype=np.uint8)
+        for wv in (13, 16, 1):
+            idx = rng.integers(0, n, (6, wv))
+            out.append((f"bmp_pal{bits}_{n}_w{wv}", bmp(idx, f"pal{bits}", 40, masks=pal)))
+        # a 12-byte header: the reference counts the palette as (offset - 14 - 24) / 3 entries — four fewer than the file holds — and reads undefined memory for the rest:
+        # the indices stay below that count (a decoder cannot be held against undefined values; host/misc_decode.hpp gives black there)
+        if n > 4:
+            out.append((f"bmp_pal{bits}_{n}_core", bmp(rng.integers(0, n - 4, (5, 9)), f"pal{bits}", 12, masks=pal)))
+        out.append((f"bmp_pal{bits}_{n}_topdown_gap", bmp(rng.integers(0, n, (5, 9)), f"pal{bits}", 40, masks=pal, top_down=True, palette_pad=8 if n < 200 else 0)))
+    run = img.copy(); run[:, 3:9] = run[:, 3:4]; run[2:5] = run[2:3]           # runs, also across rows
+    for kind in ("8", "16ga", "15", "16", "24", "32"):
+        for rle in (False, True):
+            for td in (False, True):
+                out.append((f"tga{kind}{'_rle' if rle else ''}{'_topdown' if td else ''}", tga(run, kind, rle, td, ident=b"id!" if td else b"")))
+    for ebits in (15, 16, 24, 32):
+        pal = rng.integers(0, 256, (40, 4), dtype=np.uint8)
+        idx = rng.integers(0, 40, (6, 11)); idx[:, 2:7] = idx[:, 2:3]
+        for rle in (False, True):
+            out.append((f"tga_map{ebits}{'_rle' if rle else ''}", tga(idx, f"map{ebits}", rle, False, palette=pal)))
+        out.append((f"tga_map{ebits}_idx16", tga(idx, f"map{ebits}", True, True, palette=pal, index_bits=16)))
+    idx = rng.integers(0, 60, (4, 4))
+    out.append(("tga_map24_index_out_of_range", tga(idx, "map24", False, False, palette=rng.integers(0, 256, (40, 4), dtype=np.uint8))))
+    for colour in (True, False):
+        for maxv in (255, 65535, 1000, 15):
+            a = rng.integers(0, maxv + 1, (5, 9, 3))
+            out.append((f"pnm_{'p6' if colour else 'p5'}_{maxv}", pnm(a, colour, maxv)))
+        out.append((f"pnm_{'p6' if colour else 'p5'}_comments", pnm(rng.integers(0, 256, (3, 4, 3)), colour, 255, comment=True)))
+    return out
