@@ -1,7 +1,9 @@
 """Header mutations of the BMP / TGA / PNM corpus (tests/misc_image_files.py): the decoders of host/misc_decode.hpp against the reference's stb build (oracle/_ref) — what differs is printed
 (expected: files whose raw TGA rows pass the end of the file, which stb leaves undefined and this decoder refuses; palette indices beyond the entries stb reads, which are undefined there and black here)."""
-import sys, numpy as np
-sys.path.insert(0,__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))); sys.path.insert(0,__import__('os').path.join(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))), 'tests')); sys.path.insert(0,__import__('os').path.join(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))), 'physically-based-renderer_amd'))
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "physically-based-renderer_amd"))
 import pbr_amd as pbr
 from oracle import ora
 import misc_image_files as mif
