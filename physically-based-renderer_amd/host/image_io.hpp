@@ -120,6 +120,28 @@ inline std::vector<float> decode_hdr(const std::uint8_t* d, std::size_t n, int& 
   }
   return out;
 }
+// A Radiance image used as an 8-bit TEXTURE: what the reference's stbi_load_from_memory(..., 4) makes of one (stb_image.h stbi__hdr_to_ldr with its default gamma 2.2 and
+// scale 1): channel → (float) pow(v, 1 / 2.2f) * 255 + 0.5f, clamped to [0, 255] and truncated; alpha 255.  pow is the C library's double pow, as there.
+inline bool is_hdr(const std::uint8_t* d, std::size_t n) {
+  auto starts = [&](const char* sig) { const std::size_t k = std::strlen(sig); return n >= k && std::memcmp(d, sig, k) == 0; };
+  return starts("#?RADIANCE\n") || starts("#?RGBE\n");
+}
+inline std::vector<std::uint8_t> decode_hdr_rgba8(const std::uint8_t* d, std::size_t n, int& w, int& h) {
+  const std::vector<float> f = decode_hdr(d, n, w, h);
+  std::vector<std::uint8_t> out((std::size_t)w * (std::size_t)h * 4);
+  const float gamma_i = 1.0f / 2.2f, scale_i = 1.0f;
+  for (std::size_t p = 0; p < (std::size_t)w * (std::size_t)h; ++p) {
+    for (int k = 0; k < 3; ++k) {
+      float z = (float)std::pow((double)(f[p * 3 + (std::size_t)k] * scale_i), (double)gamma_i) * 255 + 0.5f;
+      if (z < 0) z = 0;
+      if (z > 255) z = 255;
+      out[p * 4 + (std::size_t)k] = (std::uint8_t)(int)z;
+    }
+    out[p * 4 + 3] = 255;
+  }
+  return out;
+}
+
 inline std::vector<float> read_hdr(const std::string& path, int& w, int& h) {
   std::ifstream f(path, std::ios::binary);
   if (!f) throw std::runtime_error("cannot read " + path);

@@ -195,4 +195,12 @@ def corpus(seed=11):
             a = rng.integers(0, maxv + 1, (5, 9, 3))
             out.append((f"pnm_{'p6' if colour else 'p5'}_{maxv}", pnm(a, colour, maxv)))
         out.append((f"pnm_{'p6' if colour else 'p5'}_comments", pnm(rng.integers(0, 256, (3, 4, 3)), colour, 255, comment=True)))
+    # Radiance files used as 8-bit textures (the writer is the library's own test helper: pbr_amd.gltf.hdr_encode)
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "physically-based-renderer_amd"))
+    from pbr_amd import gltf as _g
+    for k, rle in enumerate((False, True)):
+        hdr = rng.uniform(0, 2.5, (6, 17, 3)) ** (k + 1)
+        hdr[0, :4] = 0.0
+        out.append((f"hdr_as_texture_{'rle' if rle else 'flat'}", _g.hdr_encode(hdr, rle=rle)))
     return out

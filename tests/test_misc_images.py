@@ -51,7 +51,8 @@ def test_decoders_equal_reference_stb_on_random_files(g, ora):
                  mif.bmp(img, "24", 12),
                  mif.tga(img, str(rng.choice(["8", "16ga", "15", "16", "24", "32"])), rle=bool(k % 2), top_down=bool(k % 5 == 0), ident=bytes(rng.integers(0, 256, int(rng.integers(0, 9)), dtype=np.uint8))),
                  mif.pnm(rng.integers(0, 256, (h, w, 3)), bool(k % 2), 255, comment=bool(k % 4 == 0)),
-                 mif.pnm(rng.integers(0, 65536, (h, w, 3)), bool(k % 3), 65535)]
+                 mif.pnm(rng.integers(0, 65536, (h, w, 3)), bool(k % 3), 65535),
+                 g.hdr_encode(rng.uniform(0, 3, (h, w, 3)) ** int(rng.integers(1, 6)) * (1e-3 if k % 4 == 0 else 1.0), rle=bool(k % 2))]      # a Radiance file as an 8-bit texture
         # bit fields: three disjoint colour masks of 1..8 bits and an optional alpha mask, anywhere in the word
         bits = 32 if k % 2 else 16
         for _ in range(20):
@@ -80,7 +81,7 @@ def test_decoders_equal_reference_stb_on_random_files(g, ora):
             want, got = ora.ref_stb_decode(data), g.image_decode(data)
             assert got.shape == want.shape and np.array_equal(got, want), (k, data[:32])
             n += 1
-    assert n > 900
+    assert n > 1000
 
 
 def test_files_cut_short(g, ora):
