@@ -776,6 +776,58 @@ def test_commit_on_the_device_writes_the_bytes_of_the_host_lbvh_commit(gpu, ora,
 
 
 @pytest.mark.gpu
+def test_commit_on_the_device_edges(gpu, ora):
+    """What the device commit does not take, refuses, and keeps apart: a single triangle goes to the host builder (the device build needs two); a scene lit by its environment
+    alone (no emitter table) and a scene on two lanes commit on the device; an instance whose matrix overflows to non-finite positions is refused with the host path's words, after
+    which the context commits again; and a context that committed on the device can be re-described and committed with the SAH builder (everything of the device commit released)."""
+    import copy
+    sc = gpu.scene
+    one = copy.deepcopy(_single_triangle_scene(gpu)); one.bvh_builder = "lbvh"
+    pt, o = gpu.PathTracer(0).load_scene(one), ora.Oracle().load_scene(one)
+    assert pt.internals()["commit_on_device"] == 0
+    assert _bits_equal(pt.render(32, 32, 2, seed=1, max_bounces=2), o.render(32, 32, 2, seed=1, max_bounces=2))
+    d = copy.deepcopy(gpu.scenes.by_name("textured_objects")); d.bvh_builder = "lbvh"
+    d.materials = [copy.copy(m) for m in d.materials]
+    for m in d.materials:
+        m.emissive = (0.0, 0.0, 0.0)                                                # the environment is the only light
+    if getattr(d, "env", None) is None:
+        rng = np.random.default_rng(2)
+        d.env = rng.uniform(0.0, 2.0, (16, 32, 3)).astype(np.float32)
+    pt, o = gpu.PathTracer(0).load_scene(d), ora.Oracle().load_scene(d)
+    assert pt.internals()["commit_on_device"] == 1 and pt.stats()["n_emitters"] == 0
+    g, c = pt.render(64, 48, 2, seed=5, max_bounces=3), o.render(64, 48, 2, seed=5, max_bounces=3)
+    assert _bits_equal(g, c) and all(pt.stats()[k] == o.stats()[k] for k in COUNTERS)
+    os.environ["PTC_LANES"] = "2"
+    try:
+        two = gpu.PathTracer(0)
+    finally:
+        del os.environ["PTC_LANES"]
+    two.load_scene(d)
+    assert two.internals()["commit_on_device"] == 1 and _bits_equal(two.render(64, 48, 2, seed=5, max_bounces=3), c)
+    bad = copy.deepcopy(gpu.scenes.by_name("cornell")); bad.bvh_builder = "lbvh"
+    big = np.eye(4, dtype=np.float32); big[0, 0] = 3e38; big[3, 0] = 3e38          # finite entries, positions overflow in the flatten
+    good_matrix = getattr(bad.instances[2], "matrix", None)
+    bad.instances[2] = sc.InstanceDesc(bad.instances[2].mesh, matrix=big.reshape(16))
+    ctx = gpu.PathTracer(0)
+    with pytest.raises(gpu.PtcError, match="non-finite"):
+        ctx.load_scene(bad)
+    os.environ["PTC_COMMIT"] = "host"
+    try:
+        with pytest.raises(gpu.PtcError, match="non-finite"):
+            gpu.PathTracer(0).load_scene(bad)
+    finally:
+        del os.environ["PTC_COMMIT"]
+    ok = copy.deepcopy(gpu.scenes.by_name("cornell")); ok.bvh_builder = "lbvh"
+    oo = ora.Oracle().load_scene(ok)
+    ref = oo.render(48, 48, 2, seed=4, max_bounces=4)
+    assert _bits_equal(ctx.load_scene(ok).render(48, 48, 2, seed=4, max_bounces=4), ref) and ctx.internals()["commit_on_device"] == 1      # the refused commit left a usable context
+    ok.bvh_builder = "sah"
+    assert _bits_equal(ctx.load_scene(ok).render(48, 48, 2, seed=4, max_bounces=4), ref) and ctx.internals()["commit_on_device"] == 0
+    ok.bvh_builder = "lbvh"
+    assert _bits_equal(ctx.load_scene(ok).render(48, 48, 2, seed=4, max_bounces=4), ref) and ctx.internals()["commit_on_device"] == 1
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,kw,commit_builder", [("cornell", {}, "lbvh"), ("sphere10k", {}, "lbvh"), ("atrium", {"scale": 0.05}, "lbvh"), ("atrium", {"scale": 0.05}, "sah"),
                                                      ("textured_atrium", {"scale": 0.05, "tex_size": 64, "env_size": (64, 32)}, "lbvh"), ("textured_objects", {}, "sah"),
                                                      ("coincident", {}, "lbvh"), ("atrium", {}, "lbvh")])
