@@ -1,8 +1,8 @@
-// misc_decode.hpp — the other file images the reference's image path takes: Windows BMP, Truevision TGA, binary PGM / PPM.
+// misc_decode.hpp — the other file images the reference's image path takes: Windows BMP, Truevision TGA, binary PGM / PPM, Photoshop PSD, GIF.
 //
 // image::loadImage2D (src/pbr_engine/image/pbr/image/LoadImage.cpp:56-73) hands whatever bytes a glTF image holds to
 // stbi_load_from_memory(..., 4): besides PNG and JPEG (png_decode.hpp, jpeg_decode.hpp) that is BMP, GIF, PSD, PIC, PNM, HDR and TGA, tried
-// in that order (src/pbr_engine/image/stb/stb_image.h, stbi__load_main).  This header restates three of them — the formats' own rules, plus
+// in that order (src/pbr_engine/image/stb/stb_image.h, stbi__load_main).  This header restates five of them (Radiance-as-texture is in image_io.hpp; Softimage PIC is not decoded) — the formats' own rules, plus
 // the vendored decoder's choices where the formats leave room — so that the texels handed to ptc_add_texture_rgba8 are the reference's,
 // byte for byte (tests/test_misc_images.py against oracle/_ref, the reference's stb_image translation unit compiled in place, and against
 // fixtures generated from it):
@@ -19,6 +19,7 @@
 #pragma once
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -375,5 +376,183 @@ inline std::vector<std::uint8_t> decode_tga(const std::uint8_t* d, std::size_t n
   }
   w_out = w; h_out = h;
   return out;
+}
+// ---- Photoshop PSD: the merged image only (what the reference's decoder reads): "8BPS" version 1, RGB mode, 8 or 16 bits, raw or PackBits rows ---------------------------
+// Channels beyond the file's count are 0 (alpha: 255); 16-bit samples keep their high byte; a PackBits file is read as 8-bit whatever its depth says (the reference's
+// choice); with four channels or more the colour is un-matted from white: c' = c / a + 255 (1 - 1 / a), a = alpha / 255, in single precision, truncated to a byte.
+inline bool is_psd(const std::uint8_t* d, std::size_t n) { return n >= 4 && d[0] == '8' && d[1] == 'B' && d[2] == 'P' && d[3] == 'S'; }
+
+inline std::vector<std::uint8_t> decode_psd(const std::uint8_t* d, std::size_t n, int& w_out, int& h_out) {
+  using namespace misc_detail;
+  Bytes r(d, n);
+  auto be16 = [&]() { const int hi = r.u8(); return (hi << 8) | r.u8(); };
+  auto be32 = [&]() { const std::uint32_t hi = (std::uint32_t)be16(); return (std::int32_t)((hi << 16) | (std::uint32_t)be16()); };
+  if (be32() != 0x38425053) throw std::runtime_error("not a PSD image");
+  if (be16() != 1) throw std::runtime_error("PSD: unsupported version");
+  r.skip(6);
+  const int channels = be16();
+  if (channels < 0 || channels > 16) throw std::runtime_error("PSD: unsupported channel count");
+  const int h = be32(), w = be32();
+  if (h > kMaxDim || w > kMaxDim) throw std::runtime_error("PSD: image too large");
+  const int depth = be16();
+  if (depth != 8 && depth != 16) throw std::runtime_error("PSD: bit depth is not 8 or 16");
+  if (be16() != 3) throw std::runtime_error("PSD: not in RGB colour mode");
+  r.skip(be32()); r.skip(be32()); r.skip(be32());          // mode data, image resources, layer and mask information
+  const int compression = be16();
+  if (compression > 1) throw std::runtime_error("PSD: unknown compression");
+  check_area(w, h, 4);
+  const std::size_t np = (std::size_t)w * (std::size_t)h;
+  std::vector<std::uint8_t> out(np * 4);
+  if (compression) {
+    r.skip((long long)h * channels * 2);                   // the rows' byte counts
+    for (int c = 0; c < 4; ++c) {
+      if (c >= channels) { for (std::size_t i = 0; i < np; ++i) out[i * 4 + (std::size_t)c] = c == 3 ? 255 : 0; continue; }
+      std::size_t done = 0;
+      while (done < np) {
+        int len = r.u8();
+        if (len == 128) continue;                          // (at the end of the file the bytes read as 0: a literal of one byte)
+        if (len < 128) {
+          ++len;
+          if ((std::size_t)len > np - done) throw std::runtime_error("PSD: bad run-length data");
+          for (; len; --len) out[(done++) * 4 + (std::size_t)c] = (std::uint8_t)r.u8();
+        } else {
+          len = 257 - len;
+          if ((std::size_t)len > np - done) throw std::runtime_error("PSD: bad run-length data");
+          const std::uint8_t v = (std::uint8_t)r.u8();
+          for (; len; --len) out[(done++) * 4 + (std::size_t)c] = v;
+        }
+      }
+    }
+  } else {
+    for (int c = 0; c < 4; ++c)
+      for (std::size_t i = 0; i < np; ++i)
+        out[i * 4 + (std::size_t)c] = c >= channels ? (c == 3 ? 255 : 0) : (depth == 16 ? (std::uint8_t)(be16() >> 8) : (std::uint8_t)r.u8());
+  }
+  if (channels >= 4)
+    for (std::size_t i = 0; i < np; ++i) {
+      std::uint8_t* px = &out[i * 4];
+      if (px[3] != 0 && px[3] != 255) {
+        const float a = px[3] / 255.0f, ra = 1.0f / a, inv_a = 255.0f * (1 - ra);
+        for (int k = 0; k < 3; ++k) px[k] = (std::uint8_t)(int)(px[k] * ra + inv_a);
+      }
+    }
+  w_out = w; h_out = h;
+  return out;
+}
+
+// ---- GIF: the FIRST image of the file, as the reference's decoder composes it ------------------------------------------------------------------------------------------
+// Canvas of the logical screen, transparent black; the first image descriptor's rectangle is decoded (LZW, interlaced or not, local or global colour table) and drawn
+// through the table — an index marked transparent by a preceding graphic-control extension leaves the canvas as it is; then, when the header names a background index
+// above 0, every pixel the image did NOT touch takes that entry of the global table, opaque — written in the table's own byte order, blue first (the reference's memcpy).
+inline bool is_gif(const std::uint8_t* d, std::size_t n) {
+  return n >= 6 && d[0] == 'G' && d[1] == 'I' && d[2] == 'F' && d[3] == '8' && (d[4] == '7' || d[4] == '9') && d[5] == 'a';
+}
+
+inline std::vector<std::uint8_t> decode_gif(const std::uint8_t* d, std::size_t n, int& w_out, int& h_out) {
+  using namespace misc_detail;
+  if (!is_gif(d, n)) throw std::runtime_error("not a GIF image");
+  Bytes r(d, n);
+  r.skip(6);
+  const int W = r.u16(), H = r.u16(), flags = r.u8(), bgindex = r.u8();
+  r.u8();                                                  // aspect ratio
+  std::uint8_t pal[256][4] = {}, lpal[256][4] = {};        // entries as the file orders them reversed: (b, g, r, a)
+  auto table = [&](std::uint8_t t[256][4], int entries, int transparent) {
+    for (int i = 0; i < entries; ++i) { t[i][2] = (std::uint8_t)r.u8(); t[i][1] = (std::uint8_t)r.u8(); t[i][0] = (std::uint8_t)r.u8(); t[i][3] = transparent == i ? 0 : 255; }
+  };
+  if (flags & 0x80) table(pal, 2 << (flags & 7), -1);
+  check_area(W, H, 4);
+  const std::size_t np = (std::size_t)W * (std::size_t)H;
+  std::vector<std::uint8_t> out(np * 4, 0), touched(np, 0);
+  int eflags = 0, transparent = -1;
+  for (;;) {
+    const int tag = r.u8();
+    if (tag == 0x2C) {
+      const int x = r.u16(), y = r.u16(), w = r.u16(), h = r.u16();
+      if (x + w > W || y + h > H) throw std::runtime_error("GIF: bad image descriptor");
+      const long long line = (long long)W * 4;
+      const long long start_x = (long long)x * 4, start_y = (long long)y * line, max_x = start_x + (long long)w * 4, max_y = start_y + (long long)h * line;
+      long long cur_x = start_x, cur_y = w == 0 ? max_y : start_y, step;
+      const int lflags = r.u8();
+      int parse;
+      if (lflags & 0x40) { step = 8 * line; parse = 3; } else { step = line; parse = 0; }
+      const std::uint8_t (*ct)[4];
+      if (lflags & 0x80) { table(lpal, 2 << (lflags & 7), (eflags & 1) ? transparent : -1); ct = lpal; }
+      else if (flags & 0x80) ct = pal;
+      else throw std::runtime_error("GIF: missing colour table");
+      // ---- LZW raster ----
+      const int lzw_cs = r.u8();
+      if (lzw_cs > 12) throw std::runtime_error("GIF: bad code size");
+      struct Code { std::int16_t prefix; std::uint8_t first, suffix; };
+      std::vector<Code> codes(8193);
+      const int clear = 1 << lzw_cs;
+      for (int i = 0; i < clear; ++i) codes[(std::size_t)i] = {(std::int16_t)-1, (std::uint8_t)i, (std::uint8_t)i};
+      int codesize = lzw_cs + 1, codemask = (1 << codesize) - 1, avail = clear + 2, oldcode = -1, valid_bits = 0, len = 0;
+      std::int32_t bits = 0;
+      bool first = true;
+      std::vector<std::uint8_t> chain;
+      auto emit = [&](int code) {                          // the string of a code, first symbol first
+        chain.clear();
+        for (int c = code; c >= 0; c = codes[(std::size_t)c].prefix) chain.push_back(codes[(std::size_t)c].suffix);
+        for (std::size_t k = chain.size(); k-- > 0;) {
+          if (cur_y >= max_y) return;
+          const std::size_t idx = (std::size_t)(cur_x + cur_y);
+          touched[idx / 4] = 1;
+          const std::uint8_t* c = ct[chain[k]];
+          if (c[3] > 128) { out[idx] = c[2]; out[idx + 1] = c[1]; out[idx + 2] = c[0]; out[idx + 3] = c[3]; }
+          cur_x += 4;
+          if (cur_x >= max_x) {
+            cur_x = start_x; cur_y += step;
+            while (cur_y >= max_y && parse > 0) { step = (1LL << parse) * line; cur_y = start_y + (step >> 1); --parse; }
+          }
+        }
+      };
+      for (;;) {
+        if (valid_bits < codesize) {
+          if (len == 0) { len = r.u8(); if (len == 0) break; }
+          --len;
+          bits |= (std::int32_t)((std::uint32_t)r.u8() << valid_bits);
+          valid_bits += 8;
+        } else {
+          const int code = bits & codemask;
+          bits >>= codesize; valid_bits -= codesize;
+          if (code == clear) { codesize = lzw_cs + 1; codemask = (1 << codesize) - 1; avail = clear + 2; oldcode = -1; first = false; }
+          else if (code == clear + 1) break;               // end of the image's data (what follows it in the file is not looked at)
+          else if (code <= avail) {
+            if (first) throw std::runtime_error("GIF: no clear code");
+            if (oldcode >= 0) {
+              Code& p = codes[(std::size_t)avail++];
+              if (avail > 8192) throw std::runtime_error("GIF: too many codes");
+              p.prefix = (std::int16_t)oldcode;
+              p.first = codes[(std::size_t)oldcode].first;
+              p.suffix = code == avail ? p.first : codes[(std::size_t)code].first;
+            } else if (code == avail) throw std::runtime_error("GIF: illegal code");
+            emit(code);
+            if ((avail & codemask) == 0 && avail <= 0x0fff) { ++codesize; codemask = (1 << codesize) - 1; }
+            oldcode = code;
+          } else throw std::runtime_error("GIF: illegal code");
+        }
+      }
+      if (bgindex > 0)
+        for (std::size_t i = 0; i < np; ++i)
+          if (!touched[i]) { out[i * 4] = pal[bgindex][0]; out[i * 4 + 1] = pal[bgindex][1]; out[i * 4 + 2] = pal[bgindex][2]; out[i * 4 + 3] = 255; }
+      w_out = W; h_out = H;
+      return out;
+    } else if (tag == 0x21) {
+      const int ext = r.u8();
+      int len;
+      if (ext == 0xF9) {
+        len = r.u8();
+        if (len == 4) {
+          eflags = r.u8();
+          r.u16();                                         // delay
+          if (transparent >= 0) pal[transparent][3] = 255;
+          if (eflags & 1) { transparent = r.u8(); pal[transparent][3] = 0; }
+          else { r.skip(1); transparent = -1; }
+        } else { r.skip(len); continue; }
+      }
+      while ((len = r.u8()) != 0) r.skip(len);
+    } else if (tag == 0x3B) throw std::runtime_error("GIF: no image in the file");
+    else throw std::runtime_error("GIF: unknown block");
+  }
 }
 }  // namespace pbr::image

@@ -145,6 +145,96 @@ def pnm(img, colour=True, maxv=255, comment=False):
     return head + (a.astype(">u2").tobytes() if maxv > 255 else a.astype(np.uint8).tobytes())
 
 
+def _lzw(indices, min_code_size):
+    """GIF LZW: variable-width codes, clear code first, end code last, the table reset when it is full."""
+    clear, end = 1 << min_code_size, (1 << min_code_size) + 1
+    out, acc, nbits = bytearray(), 0, 0
+    size = min_code_size + 1
+
+    def put(code):
+        nonlocal acc, nbits
+        acc |= code << nbits; nbits += size
+        while nbits >= 8:
+            out.append(acc & 255); acc >>= 8; nbits -= 8
+    table = {(i,): i for i in range(clear)}
+    nxt = end + 1
+    put(clear)
+    cur = ()
+    for sym in indices:
+        k = cur + (int(sym),)
+        if k in table:
+            cur = k
+            continue
+        put(table[cur])
+        if nxt < 4096:
+            table[k] = nxt; nxt += 1
+            if nxt - 1 == (1 << size) and size < 12:
+                size += 1
+        else:
+            put(clear)
+            table = {(i,): i for i in range(clear)}; nxt = end + 1; size = min_code_size + 1
+        cur = (int(sym),)
+    if cur:
+        put(table[cur])
+    put(end)
+    if nbits:
+        out.append(acc & 255)
+    blocks = b"".join(bytes([len(out[i:i + 255])]) + bytes(out[i:i + 255]) for i in range(0, len(out), 255))
+    return bytes([min_code_size]) + blocks + b"\0"
+
+
+def gif(idx, palette, screen=None, at=(0, 0), interlace=False, local=False, transparent=None, bgindex=0, version=b"89a", comment=False, no_global=False):
+    """idx: (h, w) palette indices of the first image; palette: (2^k, 3) RGB; screen: (W, H) of the logical screen (default: the image's), `at`: its corner on it."""
+    h, w = idx.shape
+    W, H = screen if screen else (w, h)
+    k = max(int(np.ceil(np.log2(len(palette)))), 1)
+    pal = np.zeros((1 << k, 3), np.uint8); pal[: len(palette)] = palette
+    out = b"GIF" + version + struct.pack("<HHBBB", W, H, (0 if no_global else 0x80) | ((k - 1) << 4) | (k - 1), bgindex, 0)
+    if not no_global:
+        out += pal.tobytes()
+    if comment:
+        out += b"\x21\xfe" + bytes([5]) + b"hello" + b"\0"
+    if transparent is not None:
+        out += b"\x21\xf9\x04" + struct.pack("<BHB", 1, 7, transparent) + b"\0"
+    rows = idx
+    if interlace:
+        order = [y for s0, st in ((0, 8), (4, 8), (2, 4), (1, 2)) for y in range(s0, h, st)]
+        rows = idx[order]
+    out += b"\x2c" + struct.pack("<HHHHB", at[0], at[1], w, h, (0x40 if interlace else 0) | ((0x80 | (k - 1)) if (local or no_global) else 0))
+    if local or no_global:
+        out += (pal[::-1] if local and not no_global else pal).tobytes()
+    out += _lzw(rows.reshape(-1), max(k, 2)) + b"\x3b"
+    return out
+
+
+def psd(img, channels=4, depth=8, rle=False):
+    """img: (h, w, 4) uint8 RGBA; the merged image of an RGB-mode PSD with `channels` channels (3: no alpha, 4: alpha, 5: one extra channel)."""
+    h, w = img.shape[:2]
+    head = b"8BPS" + struct.pack(">H6xHIIHH", 1, channels, h, w, depth, 3) + struct.pack(">I", 0) + struct.pack(">I", 4) + b"\1\2\3\4" + struct.pack(">I", 0)
+    planes = [img[:, :, c] if c < 4 else (255 - img[:, :, 0]) for c in range(channels)]
+    if not rle:
+        body = b"".join((p.astype(np.uint16) * 257).astype(">u2").tobytes() if depth == 16 else p.astype(np.uint8).tobytes() for p in planes)
+        return head + struct.pack(">H", 0) + body
+    counts, data = [], []
+    for p in planes:
+        for row in p.astype(np.uint8):
+            o, i = bytearray(), 0
+            row = bytes(row)
+            while i < len(row):
+                j = i
+                while j + 1 < len(row) and row[j + 1] == row[i] and j - i < 127:
+                    j += 1
+                if j > i:
+                    o += bytes([257 - (j - i + 1), row[i]]); i = j + 1
+                else:
+                    k = i
+                    while k + 1 < len(row) and row[k + 1] != row[k] and k - i < 127:
+                        k += 1
+                    o += bytes([k - i]) + row[i:k + 1]; i = k + 1
+            counts.append(len(o)); data.append(bytes(o))
+    return head + struct.pack(">H", 1) + b"".join(struct.pack(">H", c) for c in counts) + b"".join(data)
+
+
 def corpus(seed=11):
     """(name, bytes) of every variant, deterministic."""
     rng = np.random.default_rng(seed)
@@ -195,6 +285,24 @@ def corpus(seed=11):
             a = rng.integers(0, maxv + 1, (5, 9, 3))
             out.append((f"pnm_{'p6' if colour else 'p5'}_{maxv}", pnm(a, colour, maxv)))
         out.append((f"pnm_{'p6' if colour else 'p5'}_comments", pnm(rng.integers(0, 256, (3, 4, 3)), colour, 255, comment=True)))
+    for npal in (2, 4, 16, 256):
+        pal = rng.integers(0, 256, (npal, 3), dtype=np.uint8)
+        big = rng.integers(0, npal, (19, 23)); big[:, 5:15] = big[:, 5:6]
+        out.append((f"gif_{npal}", gif(big, pal)))
+        out.append((f"gif_{npal}_interlaced", gif(big, pal, interlace=True, version=b"87a")))
+    pal = rng.integers(0, 256, (16, 3), dtype=np.uint8)
+    small = rng.integers(0, 16, (6, 7))
+    out.append(("gif_sub_image_background", gif(small, pal, screen=(12, 11), at=(3, 2), bgindex=5, comment=True)))
+    out.append(("gif_sub_image_no_background", gif(small, pal, screen=(12, 11), at=(3, 2), bgindex=0)))
+    out.append(("gif_transparent", gif(small, pal, transparent=3)))
+    out.append(("gif_transparent_local_table", gif(small, pal, transparent=3, local=True, screen=(9, 9), at=(1, 1), bgindex=2)))
+    out.append(("gif_no_global_table", gif(small, pal, no_global=True)))
+    out.append(("gif_noise_4096_codes", gif(rng.integers(0, 256, (80, 90)), rng.integers(0, 256, (256, 3), dtype=np.uint8))))      # fills the code table: a clear code in mid-stream
+    soft = img.copy(); soft[:, :, 3] = rng.integers(1, 255, soft.shape[:2]); soft[0, :3, 3] = (0, 255, 128)
+    for ch in (3, 4, 5, 1):
+        for depth in (8, 16):
+            out.append((f"psd_{ch}ch_{depth}bit", psd(soft, ch, depth)))
+        out.append((f"psd_{ch}ch_rle", psd(run if ch != 4 else soft, ch, 8, rle=True)))
     # Radiance files used as 8-bit textures (the writer is the library's own test helper: pbr_amd.gltf.hdr_encode)
     import os, sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "physically-based-renderer_amd"))

@@ -1,4 +1,4 @@
-"""The BMP / TGA / PGM / PPM decoders of the glTF loader (host/misc_decode.hpp, ptc_image_decode_rgba8) against the REFERENCE's own decoder: image::loadImage2D hands a glTF
+"""The BMP / TGA / PGM / PPM / GIF / PSD / Radiance-as-texture decoders of the glTF loader (host/misc_decode.hpp, ptc_image_decode_rgba8) against the REFERENCE's own decoder: image::loadImage2D hands a glTF
 image's bytes to stbi_load_from_memory(..., 4) whatever format they are in (src/pbr_engine/image/pbr/image/LoadImage.cpp:56-73); oracle/_ref is that vendored stb_image
 translation unit compiled where it lies.  The committed fixture tests/golden/misc_images.npz was generated from it (tests/golden/make_misc_golden.py) and pins the decoders where the
 reference checkout is absent (the GPU box); with the checkout present every file of the corpus, random files and cut-short files are held against it directly."""
@@ -52,7 +52,15 @@ def test_decoders_equal_reference_stb_on_random_files(g, ora):
                  mif.tga(img, str(rng.choice(["8", "16ga", "15", "16", "24", "32"])), rle=bool(k % 2), top_down=bool(k % 5 == 0), ident=bytes(rng.integers(0, 256, int(rng.integers(0, 9)), dtype=np.uint8))),
                  mif.pnm(rng.integers(0, 256, (h, w, 3)), bool(k % 2), 255, comment=bool(k % 4 == 0)),
                  mif.pnm(rng.integers(0, 65536, (h, w, 3)), bool(k % 3), 65535),
-                 g.hdr_encode(rng.uniform(0, 3, (h, w, 3)) ** int(rng.integers(1, 6)) * (1e-3 if k % 4 == 0 else 1.0), rle=bool(k % 2))]      # a Radiance file as an 8-bit texture
+                 g.hdr_encode(rng.uniform(0, 3, (h, w, 3)) ** int(rng.integers(1, 6)) * (1e-3 if k % 4 == 0 else 1.0), rle=bool(k % 2)),      # a Radiance file as an 8-bit texture
+                 mif.psd(img, int(rng.integers(0, 7)), int(rng.choice([8, 16])), rle=False), mif.psd(img, int(rng.integers(1, 6)), 8, rle=True)]
+        gp = rng.integers(0, 256, (int(rng.choice([2, 4, 8, 32, 256])), 3), dtype=np.uint8)
+        gi = rng.integers(0, len(gp), (h, w))
+        if k % 2:
+            gi[:, : w // 2] = gi[:, :1]
+        sw, sh = w + int(rng.integers(0, 5)), h + int(rng.integers(0, 5))
+        files.append(mif.gif(gi, gp, screen=(sw, sh), at=(int(rng.integers(0, sw - w + 1)), int(rng.integers(0, sh - h + 1))), interlace=bool(k % 3 == 0), local=bool(k % 5 == 0),
+                             transparent=int(rng.integers(0, len(gp))) if k % 4 == 0 else None, bgindex=int(rng.integers(0, len(gp))) if k % 2 else 0, comment=bool(k % 7 == 0)))
         # bit fields: three disjoint colour masks of 1..8 bits and an optional alpha mask, anywhere in the word
         bits = 32 if k % 2 else 16
         for _ in range(20):
@@ -81,7 +89,7 @@ def test_decoders_equal_reference_stb_on_random_files(g, ora):
             want, got = ora.ref_stb_decode(data), g.image_decode(data)
             assert got.shape == want.shape and np.array_equal(got, want), (k, data[:32])
             n += 1
-    assert n > 1000
+    assert n > 1300
 
 
 def test_files_cut_short(g, ora):
@@ -95,6 +103,12 @@ def test_files_cut_short(g, ora):
         for cut in (len(data) - 1, len(data) - 40, len(data) - 150):
             got = g.image_decode(data[:cut])
             assert got.shape == whole.shape and (cut > len(data) - 150 or not np.array_equal(got, whole))       # (the last bytes may be row padding)
+            if ora.have_ref_stb():
+                assert np.array_equal(got, ora.ref_stb_decode(data[:cut])), cut
+    # a GIF cut short ends its image where the data ends (a block length of 0 terminates it); a raw PSD reads zeros
+    for data in (mif.gif(rng.integers(0, 16, (30, 40)), rng.integers(0, 256, (16, 3), dtype=np.uint8), bgindex=3), mif.psd(img, 4, 8), mif.psd(img, 3, 16)):
+        for cut in (len(data) - 2, len(data) - 60, len(data) * 2 // 3):
+            got = g.image_decode(data[:cut])
             if ora.have_ref_stb():
                 assert np.array_equal(got, ora.ref_stb_decode(data[:cut])), cut
     for data in (mif.tga(img, "24"), mif.tga(img, "8"), mif.pnm(img[:, :, :3]), mif.pnm(img[:, :, :3].astype(np.uint32) * 200, True, 65535)):
@@ -120,6 +134,18 @@ def test_decoders_refuse_what_stb_refuses(g, ora):
            patched(mif.bmp(rng.integers(0, 2, (5, 9)), "pal1", 40, masks=pal256[:2]), 28, "<H", 2),
            b"P6\n0 4\n255\n", b"P6\n4 0\n255\n", b"P5\n4 4\n70000\n" + b"\0" * 64, b"P6\n99999999999 4\n255\n", b"P6\n4 4\n255\n" + b"\0" * 10,
            mif.tga(rng.integers(0, 4, (3, 3)), "map24", palette=np.zeros((0, 4), np.uint8))]
+    gpal = rng.integers(0, 256, (16, 3), dtype=np.uint8)
+    gidx = rng.integers(0, 16, (5, 6))
+    gf = mif.gif(gidx, gpal)
+    at = gf.index(b"\x2c")
+    ps = mif.psd(img, 4, 8)
+    bad += [gf[:at] + b"\x3b",                                                       # no image at all
+            gf[:at + 10] + bytes([13]) + gf[at + 11:],                               # an LZW code size of 13
+            gf[:at] + b"\x99" + gf[at + 1:],                                         # an unknown block
+            mif.gif(gidx, gpal, screen=(4, 4)),                                       # the image does not fit the screen
+            gf[:10] + bytes([gf[10] & 0x7f]) + gf[13 + 48:],                          # neither a global nor a local colour table
+            patched(ps, 4, ">H", 2), patched(ps, 24, ">H", 4), patched(ps, 22, ">H", 12), patched(ps, 12, ">H", 17), patched(ps, len(ps) - img.size - 2, ">H", 2),     # version, CMYK, 12 bits, 17 channels, compression 2
+            mif.psd(img, 3, 8, rle=True)[:-40] + b"\x7f" * 40]                       # a literal run past the end of a channel
     for k, data in enumerate(bad):
         with pytest.raises(ValueError):
             g.image_decode(data)
@@ -148,7 +174,10 @@ def test_gltf_images_in_these_formats_reach_the_context(pbr, tmp_path):
     (tmp_path / "a.bin").write_bytes(raw[20 + jlen + 8:])
     doc["buffers"][0]["uri"] = "a.bin"
     opaque = tex.copy(); opaque[:, :, 3] = 255
-    for name, data, want in (("t.bmp", mif.bmp(tex, "32", 124), tex), ("t24.bmp", mif.bmp(tex, "24"), opaque), ("t.tga", mif.tga(tex, "32", rle=True), tex), ("t.ppm", mif.pnm(tex[:, :, :3]), opaque)):
+    gp = rng.integers(0, 256, (16, 3), dtype=np.uint8); gi = rng.integers(0, 16, (8, 8))
+    gimg = np.concatenate([gp[gi], np.full((8, 8, 1), 255, np.uint8)], 2)
+    for name, data, want in (("t.bmp", mif.bmp(tex, "32", 124), tex), ("t24.bmp", mif.bmp(tex, "24"), opaque), ("t.tga", mif.tga(tex, "32", rle=True), tex), ("t.ppm", mif.pnm(tex[:, :, :3]), opaque),
+                             ("t.gif", mif.gif(gi, gp, interlace=True), gimg), ("t.psd", mif.psd(opaque, 4, 8, rle=True), opaque)):
         (tmp_path / name).write_bytes(data)
         for uri in (name, "data:application/octet-stream;base64," + base64.b64encode(data).decode()):
             j = json.loads(json.dumps(doc))
