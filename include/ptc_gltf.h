@@ -49,8 +49,9 @@ int ptc_hdr_decode_rgb32f(const unsigned char* data, unsigned long long n, float
  * top: what stbi_load_from_memory(..., 4) gives (stb/stb_image.h stbi__bmp_load, stbi__tga_load, stbi__pnm_load), byte for byte (tests/test_misc_images.py against
  * oracle/_ref).  Also a Radiance .hdr file used as an 8-bit texture: every channel (float) pow(v, 1 / 2.2f) * 255 + 0.5f, clamped and truncated, alpha 255 (stbi__hdr_to_ldr at
  * its defaults); the FIRST image of a GIF (LZW, interlacing, local tables, transparency, the background index as the reference applies it); the merged image of an RGB
- * Photoshop PSD (8 / 16 bits, raw or PackBits, un-matted from white).  kind: 0 = by content, in the reference's order (BMP, GIF, PSD, PNM, Radiance, TGA — TGA has no
- * signature and is tried last), 1 = BMP, 2 = TGA, 3 = PNM, 4 = Radiance, 5 = GIF, 6 = PSD.  Softimage PIC is not decoded.  Same calling convention as ptc_png_decode_rgba8. */
+ * Photoshop PSD (8 / 16 bits, raw or PackBits, un-matted from white); Softimage PIC (uncompressed, pure and mixed run-length packets).  With PNG and JPEG that is every
+ * format the reference's stb build decodes.  kind: 0 = by content, in the reference's order (BMP, GIF, PSD, PIC, PNM, Radiance, TGA — TGA has no signature and is tried
+ * last), 1 = BMP, 2 = TGA, 3 = PNM, 4 = Radiance, 5 = GIF, 6 = PSD, 7 = PIC.  Same calling convention as ptc_png_decode_rgba8. */
 int ptc_image_decode_rgba8(int kind, const unsigned char* data, unsigned long long n, unsigned char* out, unsigned long long out_capacity,
                            int* w, int* h, char* err, int err_len);
 

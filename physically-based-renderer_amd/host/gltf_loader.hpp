@@ -469,16 +469,17 @@ inline FlatScene load(const std::string& path, int scene_index = -1, bool compos
       bytes = owned.data(); nbytes = owned.size();
     }
     Texture t;
-    // the order in which the reference's decoder tries the formats it knows (stb_image.h, stbi__load_main); Softimage PIC is not decoded here
+    // the order in which the reference's decoder tries the formats it knows (stb_image.h, stbi__load_main)
     if (pbr::image::is_png(bytes, nbytes)) t.rgba = pbr::image::decode_png(bytes, nbytes, t.w, t.h);
     else if (pbr::image::is_bmp(bytes, nbytes)) t.rgba = pbr::image::decode_bmp(bytes, nbytes, t.w, t.h);
     else if (pbr::image::is_gif(bytes, nbytes)) t.rgba = pbr::image::decode_gif(bytes, nbytes, t.w, t.h);
     else if (pbr::image::is_psd(bytes, nbytes)) t.rgba = pbr::image::decode_psd(bytes, nbytes, t.w, t.h);
+    else if (pbr::image::is_pic(bytes, nbytes)) t.rgba = pbr::image::decode_pic(bytes, nbytes, t.w, t.h);
     else if (pbr::image::is_jpeg(bytes, nbytes)) t.rgba = pbr::image::decode_jpeg(bytes, nbytes, t.w, t.h);
     else if (pbr::image::is_pnm(bytes, nbytes)) t.rgba = pbr::image::decode_pnm(bytes, nbytes, t.w, t.h);
     else if (pbr::image::is_hdr(bytes, nbytes)) t.rgba = pbr::image::decode_hdr_rgba8(bytes, nbytes, t.w, t.h);
     else if (pbr::image::is_tga(bytes, nbytes)) t.rgba = pbr::image::decode_tga(bytes, nbytes, t.w, t.h);
-    else throw std::runtime_error("image " + std::to_string(ii) + " is none of PNG, BMP, GIF, PSD, JPEG, PGM / PPM, Radiance, TGA");
+    else throw std::runtime_error("image " + std::to_string(ii) + " is none of PNG, BMP, GIF, PSD, PIC, JPEG, PGM / PPM, Radiance, TGA");
     if (t.w <= 0 || t.h <= 0) throw std::runtime_error("image " + std::to_string(ii) + " is empty");
     out.textures.push_back(std::move(t));
     return image_slot[(size_t)ii] = (int)out.textures.size() - 1;

@@ -1,8 +1,8 @@
-// misc_decode.hpp — the other file images the reference's image path takes: Windows BMP, Truevision TGA, binary PGM / PPM, Photoshop PSD, GIF.
+// misc_decode.hpp — the other file images the reference's image path takes: Windows BMP, Truevision TGA, binary PGM / PPM, Photoshop PSD, GIF, Softimage PIC.
 //
 // image::loadImage2D (src/pbr_engine/image/pbr/image/LoadImage.cpp:56-73) hands whatever bytes a glTF image holds to
 // stbi_load_from_memory(..., 4): besides PNG and JPEG (png_decode.hpp, jpeg_decode.hpp) that is BMP, GIF, PSD, PIC, PNM, HDR and TGA, tried
-// in that order (src/pbr_engine/image/stb/stb_image.h, stbi__load_main).  This header restates five of them (Radiance-as-texture is in image_io.hpp; Softimage PIC is not decoded) — the formats' own rules, plus
+// in that order (src/pbr_engine/image/stb/stb_image.h, stbi__load_main).  This header restates six of them (Radiance-as-texture is in image_io.hpp) — the formats' own rules, plus
 // the vendored decoder's choices where the formats leave room — so that the texels handed to ptc_add_texture_rgba8 are the reference's,
 // byte for byte (tests/test_misc_images.py against oracle/_ref, the reference's stb_image translation unit compiled in place, and against
 // fixtures generated from it):
@@ -554,5 +554,80 @@ inline std::vector<std::uint8_t> decode_gif(const std::uint8_t* d, std::size_t n
     } else if (tag == 0x3B) throw std::runtime_error("GIF: no image in the file");
     else throw std::runtime_error("GIF: unknown block");
   }
+}
+// ---- Softimage PIC: magic 53 80 F6 34, "PICT" at byte 88, big-endian size at 92; up to ten channel packets (8 bits each; channel mask 0x80 red ... 0x10 alpha), every
+// row holding each packet's channels uncompressed (type 0), as runs of (count, value) (type 1) or as mixed runs (type 2: count >= 128 a run of count - 127, or of a 16-bit
+// count when 128; below 128 that many + 1 literal pixels).  Channels no packet carries are 255.  Unlike the formats above, a file that ends early is refused (as there).
+inline bool is_pic(const std::uint8_t* d, std::size_t n) {
+  return n >= 92 && d[0] == 0x53 && d[1] == 0x80 && d[2] == 0xF6 && d[3] == 0x34 && d[88] == 'P' && d[89] == 'I' && d[90] == 'C' && d[91] == 'T';
+}
+
+inline std::vector<std::uint8_t> decode_pic(const std::uint8_t* d, std::size_t n, int& w_out, int& h_out) {
+  using namespace misc_detail;
+  if (!is_pic(d, n)) throw std::runtime_error("not a Softimage PIC image");
+  Bytes r(d, n);
+  r.skip(92);
+  auto be16 = [&]() { const int hi = r.u8(); return (hi << 8) | r.u8(); };
+  const int w = be16(), h = be16();
+  if (r.eof()) throw std::runtime_error("PIC: file too short");
+  check_area(w, h, 4);
+  r.skip(8);                                               // ratio, fields, pad
+  std::vector<std::uint8_t> out((std::size_t)w * (std::size_t)h * 4, 0xff);
+  struct Packet { int type, channel; } packets[10];
+  int n_packets = 0, chained;
+  do {
+    if (n_packets == 10) throw std::runtime_error("PIC: too many packets");
+    chained = r.u8();
+    const int size = r.u8();
+    packets[n_packets].type = r.u8(); packets[n_packets].channel = r.u8();
+    ++n_packets;
+    if (r.eof()) throw std::runtime_error("PIC: file too short");
+    if (size != 8) throw std::runtime_error("PIC: packet is not 8 bits per channel");
+  } while (chained);
+  auto read_value = [&](int channel, std::uint8_t* dst) {
+    for (int i = 0, mask = 0x80; i < 4; ++i, mask >>= 1)
+      if (channel & mask) { if (r.eof()) throw std::runtime_error("PIC: file too short"); dst[i] = (std::uint8_t)r.u8(); }
+  };
+  auto copy_value = [](int channel, std::uint8_t* dst, const std::uint8_t* src) {
+    for (int i = 0, mask = 0x80; i < 4; ++i, mask >>= 1) if (channel & mask) dst[i] = src[i];
+  };
+  for (int y = 0; y < h; ++y)
+    for (int k = 0; k < n_packets; ++k) {
+      const Packet& p = packets[k];
+      std::uint8_t* dst = &out[(std::size_t)y * (std::size_t)w * 4];
+      if (p.type == 0) { for (int x = 0; x < w; ++x, dst += 4) read_value(p.channel, dst); }
+      else if (p.type == 1) {
+        int left = w;
+        while (left > 0) {
+          int count = r.u8();
+          if (r.eof()) throw std::runtime_error("PIC: file too short");
+          if (count > left) count = left & 255;
+          std::uint8_t v[4];
+          read_value(p.channel, v);
+          for (int i = 0; i < count; ++i, dst += 4) copy_value(p.channel, dst, v);
+          left -= count;
+        }
+      } else if (p.type == 2) {
+        int left = w;
+        while (left > 0) {
+          int count = r.u8();
+          if (r.eof()) throw std::runtime_error("PIC: file too short");
+          if (count >= 128) {
+            count = count == 128 ? be16() : count - 127;
+            if (count > left) throw std::runtime_error("PIC: scanline overrun");
+            std::uint8_t v[4];
+            read_value(p.channel, v);
+            for (int i = 0; i < count; ++i, dst += 4) copy_value(p.channel, dst, v);
+          } else {
+            ++count;
+            if (count > left) throw std::runtime_error("PIC: scanline overrun");
+            for (int i = 0; i < count; ++i, dst += 4) read_value(p.channel, dst);
+          }
+          left -= count;
+        }
+      } else throw std::runtime_error("PIC: bad compression type");
+    }
+  w_out = w; h_out = h;
+  return out;
 }
 }  // namespace pbr::image

@@ -79,7 +79,7 @@ extern "C" int ptc_hdr_decode_rgb32f(const unsigned char* data, unsigned long lo
 }
 
 
-// BMP / TGA / binary PGM-PPM (host/misc_decode.hpp); kind: 0 = by content in the reference's order (BMP, GIF, PSD, PNM, Radiance, TGA), 1 BMP, 2 TGA, 3 PNM, 4 Radiance as an 8-bit texture, 5 GIF, 6 PSD
+// BMP / TGA / binary PGM-PPM (host/misc_decode.hpp); kind: 0 = by content in the reference's order (BMP, GIF, PSD, PIC, PNM, Radiance, TGA), 1 BMP, 2 TGA, 3 PNM, 4 Radiance as an 8-bit texture, 5 GIF, 6 PSD, 7 PIC
 extern "C" int ptc_image_decode_rgba8(int kind, const unsigned char* data, unsigned long long n, unsigned char* out, unsigned long long out_capacity, int* w, int* h, char* err, int err_len) {
   if (!data) { if (err && err_len > 0) std::snprintf(err, (size_t)err_len, "ptc_image_decode_rgba8: null argument"); return PTC_E_ARG; }
   return decode_into("ptc_image_decode_rgba8", [&](int& ww, int& hh) {
@@ -87,9 +87,10 @@ extern "C" int ptc_image_decode_rgba8(int kind, const unsigned char* data, unsig
     if (kind == 1 || (kind == 0 && pbr::image::is_bmp(data, nn))) return pbr::image::decode_bmp(data, nn, ww, hh);
     if (kind == 5 || (kind == 0 && pbr::image::is_gif(data, nn))) return pbr::image::decode_gif(data, nn, ww, hh);
     if (kind == 6 || (kind == 0 && pbr::image::is_psd(data, nn))) return pbr::image::decode_psd(data, nn, ww, hh);
+    if (kind == 7 || (kind == 0 && pbr::image::is_pic(data, nn))) return pbr::image::decode_pic(data, nn, ww, hh);
     if (kind == 3 || (kind == 0 && pbr::image::is_pnm(data, nn))) return pbr::image::decode_pnm(data, nn, ww, hh);
     if (kind == 4 || (kind == 0 && pbr::image::is_hdr(data, nn))) return pbr::image::decode_hdr_rgba8(data, nn, ww, hh);
     if (kind == 2 || (kind == 0 && pbr::image::is_tga(data, nn))) return pbr::image::decode_tga(data, nn, ww, hh);
-    throw std::runtime_error("not a BMP, GIF, PSD, PGM / PPM, Radiance or TGA image");
+    throw std::runtime_error("not a BMP, GIF, PSD, PIC, PGM / PPM, Radiance or TGA image");
   }, out, out_capacity, w, h, err, err_len);
 }

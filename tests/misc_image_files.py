@@ -235,6 +235,37 @@ def psd(img, channels=4, depth=8, rle=False):
     return head + struct.pack(">H", 1) + b"".join(struct.pack(">H", c) for c in counts) + b"".join(data)
 
 
+def pic(img, kinds=(2, 2), alpha=True):
+    """img: (h, w, 4) uint8 RGBA.  One packet for R+G+B and (alpha) one for A, of compression kinds[0] / kinds[1]: 0 raw, 1 pure runs, 2 mixed runs."""
+    h, w = img.shape[:2]
+    head = b"\x53\x80\xf6\x34" + struct.pack(">f", 0.0) + b"made by the test suite".ljust(80, b"\0") + b"PICT" + struct.pack(">HHfHH", w, h, 1.0, 3, 0)
+    packets = [(kinds[0], 0xE0, [0, 1, 2])] + ([(kinds[1], 0x10, [3])] if alpha else [])
+    for i, (kind, mask, _) in enumerate(packets):
+        head += bytes([1 if i + 1 < len(packets) else 0, 8, kind, mask])
+    body = bytearray()
+    for y in range(h):
+        for kind, mask, ch in packets:
+            px = [bytes(img[y, x, ch]) for x in range(w)]
+            if kind == 0:
+                body += b"".join(px)
+                continue
+            i = 0
+            while i < w:
+                j = i
+                while j + 1 < w and px[j + 1] == px[i] and j - i < (254 if kind == 1 else 127):
+                    j += 1
+                if kind == 1:
+                    body += bytes([j - i + 1]) + px[i]; i = j + 1
+                elif j > i:
+                    body += bytes([127 + (j - i + 1)]) + px[i]; i = j + 1
+                else:
+                    k = i
+                    while k + 1 < w and px[k + 1] != px[k] and k - i < 127:
+                        k += 1
+                    body += bytes([k - i]) + b"".join(px[i:k + 1]); i = k + 1
+    return head + bytes(body)
+
+
 def corpus(seed=11):
     """(name, bytes) of every variant, deterministic."""
     rng = np.random.default_rng(seed)
@@ -303,6 +334,9 @@ def corpus(seed=11):
         for depth in (8, 16):
             out.append((f"psd_{ch}ch_{depth}bit", psd(soft, ch, depth)))
         out.append((f"psd_{ch}ch_rle", psd(run if ch != 4 else soft, ch, 8, rle=True)))
+    for kinds in ((0, 0), (1, 1), (2, 2), (2, 0), (0, 1)):
+        out.append((f"pic_rgba_{kinds[0]}{kinds[1]}", pic(run, kinds, True)))
+        out.append((f"pic_rgb_{kinds[0]}", pic(img, kinds, False)))
     # Radiance files used as 8-bit textures (the writer is the library's own test helper: pbr_amd.gltf.hdr_encode)
     import os, sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "physically-based-renderer_amd"))

@@ -211,7 +211,7 @@ def test_image_sources_and_errors(pbr, tmp_path):
                      (lambda j: j["materials"][0]["normalTexture"].__setitem__("texCoord", 1), "TEXCOORD_0"),
                      (lambda j: j["materials"][0]["normalTexture"].__setitem__("index", 5), "texture index out of range"),
                      (lambda j: j["textures"][0].__setitem__("source", 3), "image source"),
-                     (lambda j: j["images"].__setitem__(0, {"uri": "a.bin"}), "none of PNG, BMP, GIF")):
+                     (lambda j: j["images"].__setitem__(0, {"uri": "a.bin"}), "none of PNG, BMP, GIF, PSD, PIC")):
         with pytest.raises(pbr.PtcError, match=msg):
             load(mut)
 

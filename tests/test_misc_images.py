@@ -1,4 +1,4 @@
-"""The BMP / TGA / PGM / PPM / GIF / PSD / Radiance-as-texture decoders of the glTF loader (host/misc_decode.hpp, ptc_image_decode_rgba8) against the REFERENCE's own decoder: image::loadImage2D hands a glTF
+"""The BMP / TGA / PGM / PPM / GIF / PSD / PIC / Radiance-as-texture decoders of the glTF loader (host/misc_decode.hpp, ptc_image_decode_rgba8) against the REFERENCE's own decoder: image::loadImage2D hands a glTF
 image's bytes to stbi_load_from_memory(..., 4) whatever format they are in (src/pbr_engine/image/pbr/image/LoadImage.cpp:56-73); oracle/_ref is that vendored stb_image
 translation unit compiled where it lies.  The committed fixture tests/golden/misc_images.npz was generated from it (tests/golden/make_misc_golden.py) and pins the decoders where the
 reference checkout is absent (the GPU box); with the checkout present every file of the corpus, random files and cut-short files are held against it directly."""
@@ -23,7 +23,7 @@ def g(pbr):
 def test_decoders_equal_the_fixtures_of_the_reference_stb(g):
     z = np.load(GOLD)
     names = [k for k in z.files if not k.endswith(":rgba")]
-    assert len(names) >= 85
+    assert len(names) >= 125
     for name in names:
         want = z[name + ":rgba"]
         got = g.image_decode(z[name].tobytes())
@@ -53,7 +53,8 @@ def test_decoders_equal_reference_stb_on_random_files(g, ora):
                  mif.pnm(rng.integers(0, 256, (h, w, 3)), bool(k % 2), 255, comment=bool(k % 4 == 0)),
                  mif.pnm(rng.integers(0, 65536, (h, w, 3)), bool(k % 3), 65535),
                  g.hdr_encode(rng.uniform(0, 3, (h, w, 3)) ** int(rng.integers(1, 6)) * (1e-3 if k % 4 == 0 else 1.0), rle=bool(k % 2)),      # a Radiance file as an 8-bit texture
-                 mif.psd(img, int(rng.integers(0, 7)), int(rng.choice([8, 16])), rle=False), mif.psd(img, int(rng.integers(1, 6)), 8, rle=True)]
+                 mif.psd(img, int(rng.integers(0, 7)), int(rng.choice([8, 16])), rle=False), mif.psd(img, int(rng.integers(1, 6)), 8, rle=True),
+                 mif.pic(img, (int(rng.integers(0, 3)), int(rng.integers(0, 3))), alpha=bool(k % 3))]
         gp = rng.integers(0, 256, (int(rng.choice([2, 4, 8, 32, 256])), 3), dtype=np.uint8)
         gi = rng.integers(0, len(gp), (h, w))
         if k % 2:
@@ -89,7 +90,7 @@ def test_decoders_equal_reference_stb_on_random_files(g, ora):
             want, got = ora.ref_stb_decode(data), g.image_decode(data)
             assert got.shape == want.shape and np.array_equal(got, want), (k, data[:32])
             n += 1
-    assert n > 1300
+    assert n > 1400
 
 
 def test_files_cut_short(g, ora):
@@ -145,7 +146,8 @@ def test_decoders_refuse_what_stb_refuses(g, ora):
             mif.gif(gidx, gpal, screen=(4, 4)),                                       # the image does not fit the screen
             gf[:10] + bytes([gf[10] & 0x7f]) + gf[13 + 48:],                          # neither a global nor a local colour table
             patched(ps, 4, ">H", 2), patched(ps, 24, ">H", 4), patched(ps, 22, ">H", 12), patched(ps, 12, ">H", 17), patched(ps, len(ps) - img.size - 2, ">H", 2),     # version, CMYK, 12 bits, 17 channels, compression 2
-            mif.psd(img, 3, 8, rle=True)[:-40] + b"\x7f" * 40]                       # a literal run past the end of a channel
+            mif.psd(img, 3, 8, rle=True)[:-40] + b"\x7f" * 40,                       # a literal run past the end of a channel
+            mif.pic(img, (2, 2))[:-5], mif.pic(img, (0, 0))[:-1], patched(mif.pic(img, (2, 2)), 105, "B", 4), patched(mif.pic(img, (2, 2)), 106, "B", 3)]     # PIC: cut short (refused there and here), 4 bits, compression 3
     for k, data in enumerate(bad):
         with pytest.raises(ValueError):
             g.image_decode(data)
@@ -177,7 +179,7 @@ def test_gltf_images_in_these_formats_reach_the_context(pbr, tmp_path):
     gp = rng.integers(0, 256, (16, 3), dtype=np.uint8); gi = rng.integers(0, 16, (8, 8))
     gimg = np.concatenate([gp[gi], np.full((8, 8, 1), 255, np.uint8)], 2)
     for name, data, want in (("t.bmp", mif.bmp(tex, "32", 124), tex), ("t24.bmp", mif.bmp(tex, "24"), opaque), ("t.tga", mif.tga(tex, "32", rle=True), tex), ("t.ppm", mif.pnm(tex[:, :, :3]), opaque),
-                             ("t.gif", mif.gif(gi, gp, interlace=True), gimg), ("t.psd", mif.psd(opaque, 4, 8, rle=True), opaque)):
+                             ("t.gif", mif.gif(gi, gp, interlace=True), gimg), ("t.psd", mif.psd(opaque, 4, 8, rle=True), opaque), ("t.pic", mif.pic(tex, (2, 1)), tex)):
         (tmp_path / name).write_bytes(data)
         for uri in (name, "data:application/octet-stream;base64," + base64.b64encode(data).decode()):
             j = json.loads(json.dumps(doc))
