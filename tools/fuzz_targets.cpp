@@ -24,3 +24,24 @@ int gltf_try(const char* path) {
 }
 }
 #endif
+#ifdef FUZZ_MISC
+#include "image_io.hpp"
+#include "misc_decode.hpp"
+// kind as ptc_image_decode_rgba8: 1 BMP, 2 TGA, 3 PNM, 4 Radiance as a texture, 5 GIF, 6 PSD, 7 PIC
+extern "C" int misc_try(int kind, const unsigned char* d, unsigned long long n) {
+  try {
+    int w, h;
+    std::vector<std::uint8_t> v;
+    switch (kind) {
+      case 1: v = pbr::image::decode_bmp(d, (size_t)n, w, h); break;
+      case 2: v = pbr::image::decode_tga(d, (size_t)n, w, h); break;
+      case 3: v = pbr::image::decode_pnm(d, (size_t)n, w, h); break;
+      case 4: v = pbr::image::decode_hdr_rgba8(d, (size_t)n, w, h); break;
+      case 5: v = pbr::image::decode_gif(d, (size_t)n, w, h); break;
+      case 6: v = pbr::image::decode_psd(d, (size_t)n, w, h); break;
+      default: v = pbr::image::decode_pic(d, (size_t)n, w, h); break;
+    }
+    return (int)(v.size() & 0x7fffffff);
+  } catch (std::exception const&) { return -1; }
+}
+#endif

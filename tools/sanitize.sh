@@ -2,7 +2,7 @@
 # Host-side AddressSanitizer + UBSan runs (CPU only; GPU sanitizers are not available on this pool).
 #   1. libptc.so / libptc_gltf.so with the HOST code instrumented (clang, -fno-gpu-sanitize), CPU test-suite on it
 #   2. the oracle instrumented (gcc), its CPU tests
-#   3. mutation fuzzers of the PNG decoder and the glTF loader (tools/fuzz_png.py, tools/fuzz_gltf.py)
+#   3. mutation fuzzers of the PNG / JPEG decoders, the glTF loader and the BMP / TGA / PNM / GIF / PSD / PIC / Radiance decoders (tools/fuzz_png.py, fuzz_jpeg.py, fuzz_gltf.py, fuzz_misc.py)
 #   4. ThreadSanitizer on the host thread pool: commit (parallel tree build, SAH and LBVH) + host refits of the full-size atrium on a description-only context
 # Everything is built into build_san/ (git-ignored).  usage: tools/sanitize.sh [fuzz-iterations]
 set -e
@@ -19,7 +19,7 @@ sys.path.insert(0, '$ROOT'); sys.path.insert(0, '$PKG')
 from pbr_amd import ptc, gltf
 ptc.LIB_PATH = '$OUT/libptc.so'; gltf._LIB = '$OUT/libptc_gltf.so'
 import pytest
-sys.exit(pytest.main(['-x', '-q', '-m', 'not gpu', '-p', 'no:cacheprovider'] + ['$ROOT/tests/' + t for t in ('test_host_logic.py', 'test_cabi.py', 'test_gltf.py', 'test_png.py', 'test_jpeg.py', 'test_textures_env.py')]))
+sys.exit(pytest.main(['-x', '-q', '-m', 'not gpu', '-p', 'no:cacheprovider'] + ['$ROOT/tests/' + t for t in ('test_host_logic.py', 'test_cabi.py', 'test_gltf.py', 'test_png.py', 'test_jpeg.py', 'test_misc_images.py', 'test_hdr.py', 'test_textures_env.py')]))
 P
 LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0 python $OUT/run_host.py
 gcc $SAN -std=c11 -fPIC -ffp-contract=off -mfma -pthread -shared -I$ROOT/oracle -o $OUT/libptc_oracle.so $ROOT/oracle/ptc_oracle.c -lm -lpthread
@@ -39,6 +39,8 @@ g++ $SAN -std=c++17 -fPIC -I$ROOT/include -I$PKG/host -shared -o $OUT/libgltf_fu
 LD_PRELOAD=$GA ASAN_OPTIONS=detect_leaks=0 python $ROOT/tools/fuzz_png.py $OUT $((ITERS * 10))
 LD_PRELOAD=$GA ASAN_OPTIONS=detect_leaks=0 python $ROOT/tools/fuzz_jpeg.py $OUT $((ITERS * 10))
 LD_PRELOAD=$GA ASAN_OPTIONS=detect_leaks=0 python $ROOT/tools/fuzz_gltf.py $OUT $ITERS
+g++ $SAN -std=c++17 -fPIC -I$ROOT/include -I$PKG/host -shared -o $OUT/libmisc_fuzz.so $ROOT/tools/fuzz_targets.cpp -DFUZZ_MISC
+LD_PRELOAD=$GA ASAN_OPTIONS=detect_leaks=0 python $ROOT/tools/fuzz_misc.py $OUT $((ITERS * 5))
 mkdir -p $OUT/tsan
 ( cd $PKG/csrc && /opt/rocm/bin/hipcc -fsanitize=thread -fno-gpu-sanitize -g -O1 --offload-arch=gfx950 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
     -fno-fast-math -I$ROOT/include -shared -o $OUT/tsan/libptc.so pt_kernels.hip pt_refit.hip pt_build.hip ptc_api.cpp ptc_scene.cpp )
