@@ -360,6 +360,12 @@ uint64_t ptc_debug_host_build_id(const ptc_ctx*);
  * (csrc/pt_refit.hip + csrc/pt_build.hip: the LBVH builder on a device context). */
 int ptc_debug_get_internals(ptc_ctx*, uint64_t out[8]);
 
+/* The host's share of a commit ON THE DEVICE (the LBVH builder on a device context: indices and material per primitive, materials, the emitter table from the
+ * emissive primitives alone, textures, environment tables — no flatten), computed again for the committed description and held against the host build, without a device.
+ * out: [0] primitives, [1] emitters, [2] indices + material per primitive agree, [3] emitter index per primitive, emitter table and cdf agree bit for bit, [4] material table,
+ * [5] textures / texture sets / environment tables, [6] shading-record stride and vertex count — 1 each when equal. */
+int ptc_debug_commit_host_parts(ptc_ctx*, uint64_t out[8]);
+
 /* The tables shading reads besides the BVH, as they lie in HBM: the per-primitive shading records (4 * stride floats each,
  * stride 5 or 12), the emitters (20 floats each) and their power cdf (max(n_lights, 1) floats).  Arrays may be NULL (sizes only).
  * With ptc_debug_get_bvh this is everything a refit rewrites: the tests hold the refit on the device against the one on the

@@ -1751,6 +1751,31 @@ int ptc_debug_refit_host_parts(ptc_ctx* c, uint64_t out[8]) {
   return PTC_OK;
 }
 
+// The host's share of a COMMIT on the device (ptc_build_skeleton), run without a device (CPU tests, sanitizer builds): describes the committed description again the way
+// device_commit does — no flatten, the emitter table from the emissive primitives alone — and holds it against the host build the context was committed with.
+// out: [0] primitives, [1] emitters, [2] 1 if world vertex indices and material per primitive agree, [3] 1 if the emitter index per primitive, the emitter table and its cdf
+// agree bit for bit, [4] 1 if the material table agrees, [5] 1 if textures, texture sets and environment tables agree, [6] 1 if shading-record stride and vertex count agree.
+int ptc_debug_commit_host_parts(ptc_ctx* c, uint64_t out[8]) {
+  if (!c || !out) return PTC_E_ARG;
+  if (!c->committed) return fail(c, PTC_E_STATE, "debug_commit_host_parts: scene not committed");
+  { int rr = refresh_host_copy(c); if (rr) return rr; }
+  if (!description_matches_commit(c)) return fail(c, PTC_E_STATE, kDescriptionChanged);
+  const HostBuilt& B = *c->built;
+  HostBuilt S;
+  const std::string e = ptc_build_skeleton(c->mats, c->meshes, c->insts, c->texs, c->env, c->toplet_budget, S);
+  if (!e.empty()) return fail(c, PTC_E_STATE, e);
+  for (int i = 0; i < 8; ++i) out[i] = 0;
+  auto same = [](const auto& a, const auto& b) { return a.size() == b.size() && (a.empty() || std::memcmp(a.data(), b.data(), a.size() * sizeof(a[0])) == 0); };
+  out[0] = S.n_tris; out[1] = S.n_lights;
+  out[2] = (S.n_tris == B.n_tris && same(S.widx, B.widx) && same(S.tri_mat, B.tri_mat)) ? 1u : 0u;
+  out[3] = (S.n_lights == B.n_lights && same(S.prim_light, B.prim_light) && same(S.lights, B.lights) && same(S.cdf, B.cdf)) ? 1u : 0u;
+  out[4] = same(S.mats, B.mats) ? 1u : 0u;
+  out[5] = (same(S.texels, B.texels) && same(S.tex_info, B.tex_info) && same(S.set_texels, B.set_texels) && same(S.set_info, B.set_info) && same(S.env, B.env) && same(S.env_marg, B.env_marg) &&
+            same(S.env_cond, B.env_cond) && same(S.env_marg_guide, B.env_marg_guide) && same(S.env_cond_guide, B.env_cond_guide) && S.env_w == B.env_w && S.env_h == B.env_h && S.env_ok == B.env_ok) ? 1u : 0u;
+  out[6] = (S.shade_stride == B.shade_stride && S.wverts.size() == B.wverts.size()) ? 1u : 0u;
+  return PTC_OK;
+}
+
 // The tables k_shade reads besides the BVH: shading records (4 * stride floats per primitive), emitters (20 floats each), their power cdf.
 // Sizes come back through the pointers; arrays may be null.
 int ptc_debug_get_shading_tables(ptc_ctx* c, uint32_t* stride, float* shade, uint32_t* n_lights, float* lights, float* cdf) {

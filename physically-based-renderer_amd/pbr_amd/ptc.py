@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "ptc_frame_begin", "ptc_frame_add_samples", "ptc_frame_reserve", "ptc_frame_resolve", "ptc_frame_checkpoint", "ptc_frame_restore", "ptc_frame_set_sample_range", "ptc_sync", "ptc_read_radiance_rgba32f",
     "ptc_radiance_device_ptr", "ptc_write_radiance_rgba32f", "ptc_tonemap_rgba8", "ptc_get_stats",
     "ptc_debug_trace_closest", "ptc_debug_trace_any", "ptc_debug_get_flat_scene", "ptc_debug_get_bvh", "ptc_debug_get_counters",
-    "ptc_debug_get_description", "ptc_debug_get_material", "ptc_debug_get_texture", "ptc_debug_get_internals", "ptc_debug_host_build_id", "ptc_debug_get_shading_tables", "ptc_debug_refit_host_parts",
+    "ptc_debug_get_description", "ptc_debug_get_material", "ptc_debug_get_texture", "ptc_debug_get_internals", "ptc_debug_host_build_id", "ptc_debug_get_shading_tables", "ptc_debug_refit_host_parts", "ptc_debug_commit_host_parts",
     "ptc_read_radiance_rgba16f", "ptc_radiance_rgba16f_device_ptr",
     "ptc_comm_unique_id", "ptc_comm_init", "ptc_comm_reduce_radiance", "ptc_comm_destroy",
     "ptc_group_create", "ptc_group_size", "ptc_group_scene_commit", "ptc_group_scene_refit", "ptc_group_ctx", "ptc_group_render", "ptc_group_last_error", "ptc_group_destroy",
@@ -128,6 +128,7 @@ def load_library():
     L.ptc_debug_host_build_id.restype = C.c_uint64
     L.ptc_debug_get_shading_tables.argtypes = [vp, u32p, fp, u32p, fp, fp]
     L.ptc_debug_refit_host_parts.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.ptc_debug_commit_host_parts.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.ptc_read_radiance_rgba16f.argtypes = [vp, C.POINTER(C.c_uint16)]
     L.ptc_radiance_rgba16f_device_ptr.argtypes = [vp]
     L.ptc_radiance_rgba16f_device_ptr.restype = vp
@@ -399,6 +400,13 @@ class PathTracer:
         d["commit_on_device"] = (d["refit_on_device"] >> 1) & 1
         d["refit_on_device"] &= 1
         return d
+
+    def commit_host_parts(self):
+        """The host's share of a commit on the device, checked against the host build (ptc_debug_commit_host_parts)."""
+        buf = (C.c_uint64 * 8)()
+        self._ck(self._L.ptc_debug_commit_host_parts(self._h, buf))
+        keys = ("n_tris", "n_lights", "indices_ok", "emitters_ok", "materials_ok", "tables_ok", "sizes_ok")
+        return {k: int(buf[i]) for i, k in enumerate(keys)}
 
     def refit_host_parts(self):
         """The host's share of a refit on the device, checked against the host build (ptc_debug_refit_host_parts)."""

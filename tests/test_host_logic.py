@@ -347,6 +347,31 @@ def test_host_share_of_the_device_refit(pbr, name, kw, builder):
     assert pt.refit_host_parts()["transforms_finite"] == 0
 
 
+@pytest.mark.parametrize("name,kw", [("cornell", {}), ("sphere10k", {}), ("atrium", {"scale": 0.05}), ("textured_objects", {}), ("textured_atrium", {"scale": 0.03, "tex_size": 32, "env_size": (32, 16)})])
+def test_host_share_of_the_device_commit(pbr, name, kw):
+    """ptc_scene_commit with the LBVH builder on a device context lets the device flatten and build (csrc/ptc_api.cpp device_commit, tested on the GPU); what the host
+    contributes needs none: ptc_build_skeleton — world vertex indices and material per primitive, the material table, the emitter index of every primitive with the emitter table
+    and its cdf from the emissive primitives ALONE (each vertex through its instance's matrix, no flatten), textures, texture sets, environment tables — must be, bit for bit, what
+    the full host build of the same description holds; also after the instances have moved and the scene was committed again, and with an emitter collapsed to zero area."""
+    import copy
+    d = copy.deepcopy(pbr.scenes.by_name(name, **kw))
+    for builder in ("lbvh", "sah"):
+        d.bvh_builder = builder
+        pt = pbr.PathTracer(pbr.DEVICE_NONE).load_scene(d)
+        r = pt.commit_host_parts()
+        assert r["n_tris"] == pt.stats()["n_triangles"] and r["n_lights"] == pt.stats()["n_emitters"], r
+        assert r["indices_ok"] == r["emitters_ok"] == r["materials_ok"] == r["tables_ok"] == r["sizes_ok"] == 1, r
+    for i, m in enumerate(_rotated(d, 2)):
+        if m is not None:
+            d.instances[i].t, d.instances[i].q_wxyz, d.instances[i].s = m[0], m[1], tuple(float(np.float32(x) * np.float32(1.3)) for x in m[2])
+    emissive = [i for i, it in enumerate(d.instances) if any(x > 0 for x in d.materials[d.meshes[it.mesh].material].emissive)]
+    if len(emissive) > 1:
+        d.instances[emissive[0]].s = (0.0, 1.0, 1.0)                       # zero area: emissive material, not an emitter
+    pt = pbr.PathTracer(pbr.DEVICE_NONE).load_scene(d)
+    r = pt.commit_host_parts()
+    assert r["indices_ok"] == r["emitters_ok"] == r["materials_ok"] == r["tables_ok"] == r["sizes_ok"] == 1 and r["n_lights"] == pt.stats()["n_emitters"], r
+
+
 @pytest.mark.parametrize("name,kw", [("sphere10k", {}), ("atrium", {"scale": 0.05}), ("textured_objects", {})])
 def test_refit_equals_oracle_and_keeps_the_topology(ora, pbr, name, kw):
     """ptc_update_instance + ptc_scene_refit against the oracle's: the refitted trees are identical bit for bit (same topology and slots as
