@@ -19,6 +19,8 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <memory>
 #include <string>
 #include <vector>
@@ -295,6 +297,18 @@ struct ScopedSpan {   // records a start/stop event pair around launches on one 
   ~ScopedSpan() { if (on) { (void)hipEventRecord(s.b, st); c->spans.push_back(s); } }
 };
 
+// pt_trace_blocks_per_cu asks the runtime four occupancy questions; the answer depends on the kernels and the LDS size alone (every device is a gfx950), so it is asked once per
+// size and process (sizes above 64 KiB also set a function attribute per device and are asked every time)
+int trace_blocks_per_cu_cached(size_t lds) {
+  static std::mutex mu;
+  static std::map<size_t, int> known;
+  if (lds > 64u * 1024u) return pt_trace_blocks_per_cu(lds);
+  { std::lock_guard<std::mutex> lock(mu); const auto it = known.find(lds); if (it != known.end()) return it->second; }
+  const int v = pt_trace_blocks_per_cu(lds);
+  if (v > 0) { std::lock_guard<std::mutex> lock(mu); known[lds] = v; }
+  return v;
+}
+
 int configure_launch(ptc_ctx* c) {
   // Traversal stack: at most one group of pending children per tree level, so a ray needs at most depth+1 entries.
   // `stack_lds` of them live in LDS (8 B each, 512 B per level and wave), the rest in a global overflow slab.
@@ -311,7 +325,7 @@ int configure_launch(ptc_ctx* c) {
     c->cfg.stack_lds = l;
     lds = pt_trace_lds_bytes(c->cfg, c->dsc);
     if (lds > 160u * 1024u) { if (l > 1 && !l_forced) continue; return fail(c, PTC_E_ARG, "configure_launch: staged tree top + stack exceed the 160 KiB of LDS"); }
-    per_cu = pt_trace_blocks_per_cu(lds);     // registers, static LDS and launch bounds included
+    per_cu = trace_blocks_per_cu_cached(lds);     // registers, static LDS and launch bounds included
     if (per_cu >= 8 || l <= 2 || l_forced) break;
   }
   if (per_cu < 1) return fail(c, PTC_E_DEVICE, "configure_launch: the trace kernels do not fit a CU with this LDS size");
@@ -749,7 +763,7 @@ bool description_matches_commit(const ptc_ctx* c) {
     if (in.mesh < 0 || (size_t)in.mesh >= c->meshes.size()) return false;
     nv += c->meshes[(size_t)in.mesh].v.size(); nt += c->meshes[(size_t)in.mesh].idx.size() / 3;
   }
-  return nv == c->built->wverts.size() && nt == c->built->n_tris;
+  return nv == c->built->n_wverts && nt == c->built->n_tris;
 }
 const char* const kDescriptionChanged = "scene_refit: the scene's meshes or instances changed since the commit (only transforms may)";
 
@@ -926,6 +940,7 @@ int refresh_host_copy(ptc_ctx* c) {
   HostBuilt& B = *c->built;
   B.recs.resize((size_t)B.n_units * 4);                                     // a tree or a commit made on the device left the host arrays unsized
   B.shade.resize((size_t)B.n_tris * B.shade_stride * 4);
+  B.wverts.resize(B.n_wverts);
   HIP_TRY(c, hipMemcpy(B.recs.data(), c->dsc.recs, B.recs.size() * 4, hipMemcpyDeviceToHost));
   HIP_TRY(c, hipMemcpy(B.shade.data(), c->dsc.shade, B.shade.size() * 4, hipMemcpyDeviceToHost));
   HIP_TRY(c, hipMemcpy(B.wverts.data(), c->drf.wverts, B.wverts.size() * sizeof(HostVertex), hipMemcpyDeviceToHost));
@@ -1109,7 +1124,10 @@ int commit_upload(ptc_ctx* c, std::chrono::steady_clock::time_point t0, bool ske
 // the launches follow the tree (its depth, the staged top): configuration, the lanes' copies of the scene, the statistics of a commit
 int commit_finish(ptc_ctx* c, std::chrono::steady_clock::time_point t0) {
   const HostBuilt& B = *c->built;
+  const bool timing = std::getenv("PTC_BUILD_TIMING") != nullptr;
+  const auto tc0 = std::chrono::steady_clock::now();
   { int rc2 = configure_launch(c); if (rc2) { free_all(c->scene_allocs); return rc2; } }
+  if (timing) std::fprintf(stderr, "    configure_launch            %7.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count());
   c->cfg.shade_tables_lds = pt_shade_tables_fit(c->dsc) ? 1 : 0;
   for (int l = 0; l < c->n_lanes; ++l) {
     const DevScene ds = lane_scene(c, l);
@@ -1127,13 +1145,24 @@ int commit_finish(ptc_ctx* c, std::chrono::steady_clock::time_point t0) {
 // vertices, writes the shading records and builds the tree (pt_refit.hip, pt_build.hip) — the arrays in HBM are byte for byte those of the host's LBVH commit
 // (tests/test_gpu_parity.py).  Returns PTC_OK, an error, or +1: "not this way" (fewer than two triangles): the caller commits on the host.
 int device_commit(ptc_ctx* c, std::chrono::steady_clock::time_point t0) {
+  const bool timing = std::getenv("PTC_BUILD_TIMING") != nullptr;      // phase times on stderr, as the host build prints them
+  auto tprev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "  %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tprev).count());
+    tprev = now;
+  };
   auto built = std::make_shared<HostBuilt>();
   const std::string e = ptc_build_skeleton(c->mats, c->meshes, c->insts, c->texs, c->env, c->toplet_budget, *built);
   if (!e.empty()) return fail(c, PTC_E_STATE, e);
   if (built->n_tris < 2u) return 1;
   c->built = built;
+  lap("describe (skeleton)");
   { int rc = commit_upload(c, t0, /*skeleton=*/true); if (rc) return rc; }
+  lap("free + tables upload");
   { int rc = ensure_refit_plan(c); if (rc) { free_all(c->scene_allocs); return rc; } }
+  lap("plan + its upload");
   {
     const int32_t *d_mat = nullptr, *d_light = nullptr;
     int rc = dev_upload(c, c->scene_allocs, &d_mat, built->tri_mat);
@@ -1143,7 +1172,9 @@ int device_commit(ptc_ctx* c, std::chrono::steady_clock::time_point t0) {
   }
   const int rd = device_rebuild(c, /*fresh=*/true);
   if (rd) { free_all(c->scene_allocs); c->refit_ready = false; return rd; }
+  lap("flatten + build on the device");
   const int rf = commit_finish(c, t0);
+  lap("launch configuration");
   c->commit_on_device = rf == PTC_OK;
   return rf;
 }
@@ -1772,7 +1803,7 @@ int ptc_debug_commit_host_parts(ptc_ctx* c, uint64_t out[8]) {
   out[4] = same(S.mats, B.mats) ? 1u : 0u;
   out[5] = (same(S.texels, B.texels) && same(S.tex_info, B.tex_info) && same(S.set_texels, B.set_texels) && same(S.set_info, B.set_info) && same(S.env, B.env) && same(S.env_marg, B.env_marg) &&
             same(S.env_cond, B.env_cond) && same(S.env_marg_guide, B.env_marg_guide) && same(S.env_cond_guide, B.env_cond_guide) && S.env_w == B.env_w && S.env_h == B.env_h && S.env_ok == B.env_ok) ? 1u : 0u;
-  out[6] = (S.shade_stride == B.shade_stride && S.wverts.size() == B.wverts.size()) ? 1u : 0u;
+  out[6] = (S.shade_stride == B.shade_stride && S.n_wverts == B.n_wverts && B.n_wverts == B.wverts.size()) ? 1u : 0u;
   return PTC_OK;
 }
 

@@ -148,6 +148,7 @@ struct HostMesh { std::vector<HostVertex> v; std::vector<uint32_t> idx; int mate
 struct HostInstance { int mesh; float m[16]; };   // column-major model matrix
 
 struct HostBuilt {
+  uint32_t n_wverts = 0;         // world vertices of the scene (wverts.size() once the array is on the host: a commit or a tree made on the device leaves it unsized until somebody asks)
   std::vector<HostVertex> wverts;
   std::vector<uint32_t> widx;
   std::vector<int32_t> tri_mat;

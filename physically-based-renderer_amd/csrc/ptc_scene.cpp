@@ -722,7 +722,7 @@ std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vec
   std::shared_ptr<Topology> topo;
   if (refit) {
     topo = std::static_pointer_cast<Topology>(B.topology);
-    if (!topo || B.n_tris != nt || B.wverts.size() != nv) return "scene_refit: the scene's meshes or instances changed since the commit (only transforms may)";
+    if (!topo || B.n_tris != nt || B.n_wverts != nv) return "scene_refit: the scene's meshes or instances changed since the commit (only transforms may)";
     toplet_budget = topo->toplet_budget;
   } else {
     B = HostBuilt();
@@ -736,6 +736,7 @@ std::string build_or_refit(const std::vector<HostMaterial>& mats, const std::vec
   std::vector<HostVertex>& wverts = refit ? wverts_new : B.wverts;
   std::vector<float>& wbt = refit ? wbt_new : topo->wbt;   // world bitangent per vertex (vertex.glsl:35)
   wverts.resize(nv);
+  B.n_wverts = (uint32_t)nv;
   wbt.resize(nv * 3);
   B.widx.resize(nt * 3);
   B.tri_mat.resize(nt);
@@ -1279,7 +1280,7 @@ std::string ptc_build_skeleton(const std::vector<HostMaterial>& mats, const std:
   for (const auto& in : insts) { nv += meshes[(size_t)in.mesh].v.size(); nt += meshes[(size_t)in.mesh].idx.size() / 3; }
   if (nt >= (1u << 28)) return "scene_commit: too many triangles";
   B = HostBuilt();
-  B.wverts.resize(nv);
+  B.n_wverts = (uint32_t)nv;       // the flatten is the device's: refresh_host_copy sizes and fills wverts when somebody asks
   B.widx.resize(nt * 3);
   B.tri_mat.resize(nt);
   B.n_tris = (uint32_t)nt;
