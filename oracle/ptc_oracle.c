@@ -1072,6 +1072,19 @@ static inline int qbox_hit(const wnode_t* n, int i, const ray_t* r, float tmin, 
   float x0 = fmaf((float)n->qlo[0][i], ax, bx), x1 = fmaf((float)n->qhi[0][i], ax, bx);
   float y0 = fmaf((float)n->qlo[1][i], ay, by), y1 = fmaf((float)n->qhi[1][i], ay, by);
   float z0 = fmaf((float)n->qlo[2][i], az, bz), z1 = fmaf((float)n->qhi[2][i], az, bz);
+#ifdef ORA_EXP_FP16_SLAB
+  /* EXPERIMENT (tools/tree_quality.py with an oracle built -DORA_EXP_FP16_SLAB; never part of the specification): what a slab test in packed fp16 would cost in visits.
+   * The planes as (1024 + q) * s + (b - 1024 s) with s, b - 1024 s and the result rounded to 11 bits, outward: every plane distance is widened by a bound on those three
+   * roundings, 2^-11 (|b - 1024 a| + 1279 |a| + |t|); the interval's ends likewise. */
+  {
+    const float u = 1.0f / 2048.0f;
+    const float ex0 = u * (fabsf(bx - 1024.0f * ax) + 1279.0f * fabsf(ax)), ey0 = u * (fabsf(by - 1024.0f * ay) + 1279.0f * fabsf(ay)), ez0 = u * (fabsf(bz - 1024.0f * az) + 1279.0f * fabsf(az));
+    const float xn = fmin2(x0, x1), xf = fmax2(x0, x1), yn = fmin2(y0, y1), yf = fmax2(y0, y1), zn = fmin2(z0, z1), zf = fmax2(z0, z1);
+    float tn16 = fmax2(fmax2(xn - (ex0 + u * fabsf(xn)), yn - (ey0 + u * fabsf(yn))), fmax2(zn - (ez0 + u * fabsf(zn)), tmin - u * fabsf(tmin)));
+    float tf16 = fmin2(fmin2(xf + (ex0 + u * fabsf(xf)), yf + (ey0 + u * fabsf(yf))), fmin2(zf + (ez0 + u * fabsf(zf)), tlimit + u * fabsf(tlimit)));
+    return tn16 <= tf16;
+  }
+#endif
   float tnear = fmax2(fmax2(fmin2(x0, x1), fmin2(y0, y1)), fmax2(fmin2(z0, z1), tmin));
   float tfar = fmin2(fmin2(fmax2(x0, x1), fmax2(y0, y1)), fmin2(fmax2(z0, z1), tlimit));
   return tnear <= tfar;
