@@ -73,6 +73,38 @@ def test_queues_follow_the_batches_and_events_stay_bounded(gpu):
     assert pt.stats()["paths"] == 200 * w * h and pt.internals()["spans_waiting"] == 0
 
 
+def test_timing_spans_follow_the_batch(gpu):
+    """ptc_stats' seconds: a small batch (<= 2^26 paths) runs k_trace_any(b) beside k_trace_closest(b + 1) on two streams, so it carries the batch's span only — per-kernel
+    spans would include each other, and their 54 event records were 0.2 ms of a 1080p x 1 spp frame (profiles/r04_interactive.txt); a large batch runs its kernels one after
+    the other and carries a span per kernel; PTC_TIMING=2 records per-kernel spans always, PTC_TIMING=0 none.  The images do not depend on any of it."""
+    d = gpu.scenes.cornell_box()
+    w, h = 512, 512
+
+    def run(env, spp):
+        old = os.environ.get("PTC_TIMING")
+        if env is None:
+            os.environ.pop("PTC_TIMING", None)
+        else:
+            os.environ["PTC_TIMING"] = env
+        try:
+            pt = gpu.PathTracer(0).load_scene(d)
+        finally:
+            os.environ.pop("PTC_TIMING", None)
+            if old is not None:
+                os.environ["PTC_TIMING"] = old
+        img = pt.render(w, h, spp, seed=2, max_bounces=3)
+        return img, pt.stats(), pt.internals()["events_created"]
+    img1, s1, e1 = run(None, 2)                                    # 524 k paths: overlapped
+    assert s1["seconds_render"] > 0 and s1["seconds_trace_closest"] == s1["seconds_trace_any"] == s1["seconds_shade"] == 0.0 and e1 <= 4
+    img2, s2, e2 = run("2", 2)
+    assert s2["seconds_trace_closest"] > 0 and s2["seconds_trace_any"] > 0 and s2["seconds_shade"] > 0 and e2 > 10
+    img0, s0, e0 = run("0", 2)
+    assert s0["seconds_render"] == 0.0 and e0 == 0
+    assert _bits_equal(img1, img2) and _bits_equal(img1, img0)
+    _, s3, _ = run(None, 300)                                      # 78.6 M paths in one batch: one kernel after the other, a span each
+    assert s3["seconds_trace_closest"] > 0 and s3["seconds_shade"] > 0 and s3["seconds_render"] >= s3["seconds_trace_closest"]
+
+
 def test_frame_reserve_allocates_full_batches_up_front(gpu):
     """ptc_frame_reserve: an offline render sizes its queues for full batches before it starts, so that no growth step (which
     drains the device and reallocates) falls into the render; the capacity then stays put and the image is the same."""
