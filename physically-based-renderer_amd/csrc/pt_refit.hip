@@ -131,40 +131,50 @@ __device__ inline void write_triangle(const DevRefit& r, uint32_t at, const floa
   r.recs[at + 2] = make_float4(c[0] - a[0], c[1] - a[1], c[2] - a[2], 0.0f);
 }
 
+// EIGHT lanes per node, one per child slot (round 4, second session).  One thread per node walked its eight slots one after the other: up to 16 triangles behind three dependent
+// loads each (record -> vertex index -> vertex) and ~60 correctly rounded divisions, 20-50 us per LEVEL whatever its size — 0.35 of the refit's 0.5 ms.  Now lane s of an octet
+// loads the box of slot s (an interior child's stored box, or its one or two triangles, whose records it rewrites), the octet exchanges the eight boxes (48 shuffles), every lane
+// derives the node's box, origin and first exponent from them — the arithmetic and the order of the one-thread version, so the bytes are the same —, and in the exponent search lane
+// s quantises slot s; the octet's verdict is a byte of a ballot.  Lane 0 packs and writes the node.
 __global__ __launch_bounds__(kNodeBlock) void k_refit_nodes(const DevRefit r, uint32_t first, uint32_t count, float glx, float gly, float glz, float gsx, float gsy, float gsz, float scene_area) {
-  const uint32_t i = blockIdx.x * kNodeBlock + threadIdx.x;
+  const uint32_t t = blockIdx.x * kNodeBlock + threadIdx.x;
+  const uint32_t i = t >> 3, sl = t & 7u;
+  const int oct0 = (int)(threadIdx.x & 63u & ~7u);          // first lane of this octet inside the wave
+  const bool live = i < count;                             // uniform over an octet
   unsigned long long my_cost = 0ull;
-  if (i < count) {
-  const uint32_t addr = r.level_nodes[first + i];
-  const uint4 head = reinterpret_cast<const uint4*>(r.recs)[addr];
-  const uint32_t imask = (head.z >> 8) & 255u, lmask = (head.z >> 16) & 255u, two = (head.z >> 24) & 255u, block = head.w;
-  const uint32_t used = imask | lmask;
-  const uint32_t tri_base = block + 4u * (uint32_t)__popc(imask);
-  float clo[3][8], chi[3][8];
-  uint32_t tris_below = 0;
-#pragma unroll
-  for (int sl = 0; sl < 8; ++sl) {
-    Box3 b;
-    for (int k = 0; k < 3; ++k) { b.lo[k] = INFINITY; b.hi[k] = -INFINITY; }
-    if ((imask >> sl) & 1u) {
-      const uint32_t child = block + 4u * (uint32_t)__popc(imask & ((1u << sl) - 1u));
-      const float* nb = r.nbox + (size_t)(child >> 2) * 6;
-      for (int k = 0; k < 3; ++k) { b.lo[k] = nb[k]; b.hi[k] = nb[3 + k]; }
-    } else if ((lmask >> sl) & 1u) {
-      const uint32_t at = tri_base + 3u * tris_below;
-      const float *pa, *pb, *pc;
-      b = triangle_box(r, at, pa, pb, pc);
-      write_triangle(r, at, pa, pb, pc);
-      ++tris_below;
-      if ((two >> sl) & 1u) {
-        const Box3 b2 = triangle_box(r, at + 3u, pa, pb, pc);
-        write_triangle(r, at + 3u, pa, pb, pc);
-        ++tris_below;
-        for (int k = 0; k < 3; ++k) { b.lo[k] = b2.lo[k] < b.lo[k] ? b2.lo[k] : b.lo[k]; b.hi[k] = b2.hi[k] > b.hi[k] ? b2.hi[k] : b.hi[k]; }
-      }
-    }
-    for (int k = 0; k < 3; ++k) { clo[k][sl] = b.lo[k]; chi[k][sl] = b.hi[k]; }
+  uint32_t addr = 0, imask = 0, lmask = 0, two = 0, block = 0, headz = 0;
+  if (live) {
+    addr = r.level_nodes[first + i];
+    const uint4 head = reinterpret_cast<const uint4*>(r.recs)[addr];
+    imask = (head.z >> 8) & 255u; lmask = (head.z >> 16) & 255u; two = (head.z >> 24) & 255u; block = head.w; headz = head.z;
   }
+  const uint32_t used = imask | lmask;
+  const bool mine = ((used >> sl) & 1u) != 0u;
+  Box3 b;
+  for (int k = 0; k < 3; ++k) { b.lo[k] = INFINITY; b.hi[k] = -INFINITY; }
+  if ((imask >> sl) & 1u) {
+    const uint32_t child = block + 4u * (uint32_t)__popc(imask & ((1u << sl) - 1u));
+    const float* nb = r.nbox + (size_t)(child >> 2) * 6;
+    for (int k = 0; k < 3; ++k) { b.lo[k] = nb[k]; b.hi[k] = nb[3 + k]; }
+  } else if ((lmask >> sl) & 1u) {
+    const uint32_t below = (1u << sl) - 1u;
+    const uint32_t tris_below = (uint32_t)__popc(lmask & below) + (uint32_t)__popc(two & lmask & below);
+    const uint32_t at = block + 4u * (uint32_t)__popc(imask) + 3u * tris_below;
+    const float *pa, *pb, *pc;
+    b = triangle_box(r, at, pa, pb, pc);
+    write_triangle(r, at, pa, pb, pc);
+    if ((two >> sl) & 1u) {
+      const Box3 b2 = triangle_box(r, at + 3u, pa, pb, pc);
+      write_triangle(r, at + 3u, pa, pb, pc);
+      for (int k = 0; k < 3; ++k) { b.lo[k] = b2.lo[k] < b.lo[k] ? b2.lo[k] : b.lo[k]; b.hi[k] = b2.hi[k] > b.hi[k] ? b2.hi[k] : b.hi[k]; }
+    }
+  }
+  // the eight boxes of the node, in every lane of its octet
+  float clo[3][8], chi[3][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { clo[k][j] = __shfl(b.lo[k], oct0 + j); chi[k][j] = __shfl(b.hi[k], oct0 + j); }
   const float glo[3] = {glx, gly, glz}, gstep[3] = {gsx, gsy, gsz};
   uint32_t oq[3], e3[3], wlo[3][2], whi[3][2];
   float nbx[6];
@@ -173,10 +183,10 @@ __global__ __launch_bounds__(kNodeBlock) void k_refit_nodes(const DevRefit r, ui
     float nlo = 0.0f, nhi = 0.0f;
     bool have = false;
 #pragma unroll
-    for (int sl = 0; sl < 8; ++sl) {
-      if (!((used >> sl) & 1u)) continue;
-      if (!have) { nlo = clo[k][sl]; nhi = chi[k][sl]; have = true; }
-      else { nlo = clo[k][sl] < nlo ? clo[k][sl] : nlo; nhi = chi[k][sl] > nhi ? chi[k][sl] : nhi; }
+    for (int j = 0; j < 8; ++j) {
+      if (!((used >> j) & 1u)) continue;
+      if (!have) { nlo = clo[k][j]; nhi = chi[k][j]; have = true; }
+      else { nlo = clo[k][j] < nlo ? clo[k][j] : nlo; nhi = chi[k][j] > nhi ? chi[k][j] : nhi; }
     }
     nbx[k] = nlo; nbx[3 + k] = nhi;
     // origin on the 16-bit scene grid, rounded down
@@ -193,52 +203,54 @@ __global__ __launch_bounds__(kNodeBlock) void k_refit_nodes(const DevRefit r, ui
     uint32_t e = (u >> 23) & 255u;
     if (u & 0x007fffffu) e += 1u;
     if (e < 1u) e = 1u;
-    for (;; ++e) {
-      const float sc = __uint_as_float(e << 23);
+    bool done = !live;
+    uint32_t ql = 255u, qh = 0u;           // an empty slot
+    for (;;) {
       bool ok = true;
-      uint32_t pl[2] = {0u, 0u}, ph[2] = {0u, 0u};
-#pragma unroll
-      for (int sl = 0; sl < 8; ++sl) {
-        uint32_t ql = 255u, qh = 0u;         // an empty slot
-        if ((used >> sl) & 1u) {
-          float fl = floorf((clo[k][sl] - org) / sc);
-          if (fl < 0.0f) fl = 0.0f;
-          if (fl > 255.0f) fl = 255.0f;
-          int q = (int)fl;
-          while (q > 0 && org + (float)q * sc > clo[k][sl]) --q;
-          ql = (uint32_t)q;
-          float ce = ceilf((chi[k][sl] - org) / sc);
-          if (ce < 0.0f) ce = 0.0f;
-          if (ce > 255.0f) { ok = false; ce = 255.0f; }
-          int q2 = (int)ce;
-          while (q2 < 255 && org + (float)q2 * sc < chi[k][sl]) ++q2;
-          if (org + (float)q2 * sc < chi[k][sl]) ok = false;
-          qh = (uint32_t)q2;
-        }
-        pl[sl >> 2] |= ql << (8 * (sl & 3));
-        ph[sl >> 2] |= qh << (8 * (sl & 3));
+      if (!done && mine) {
+        const float sc = __uint_as_float(e << 23);
+        float fl = floorf((b.lo[k] - org) / sc);
+        if (fl < 0.0f) fl = 0.0f;
+        if (fl > 255.0f) fl = 255.0f;
+        int q = (int)fl;
+        while (q > 0 && org + (float)q * sc > b.lo[k]) --q;
+        ql = (uint32_t)q;
+        float ce = ceilf((b.hi[k] - org) / sc);
+        if (ce < 0.0f) ce = 0.0f;
+        if (ce > 255.0f) { ok = false; ce = 255.0f; }
+        int q2 = (int)ce;
+        while (q2 < 255 && org + (float)q2 * sc < b.hi[k]) ++q2;
+        if (org + (float)q2 * sc < b.hi[k]) ok = false;
+        qh = (uint32_t)q2;
       }
-      if (ok) { wlo[k][0] = pl[0]; wlo[k][1] = pl[1]; whi[k][0] = ph[0]; whi[k][1] = ph[1]; break; }
+      const unsigned long long verdict = __ballot(done || ok);
+      if (!done) { if (((verdict >> oct0) & 0xffull) == 0xffull) done = true; else ++e; }
+      if (!__ballot(!done)) break;
     }
     e3[k] = e;
-  }
-  uint4* out = reinterpret_cast<uint4*>(r.recs) + addr;
-  out[0] = make_uint4(oq[0] | (oq[1] << 16), oq[2] | (e3[0] << 16) | (e3[1] << 24), e3[2] | (head.z & 0xffffff00u), block);
-  out[1] = make_uint4(wlo[0][0], wlo[0][1], wlo[1][0], wlo[1][1]);
-  out[2] = make_uint4(wlo[2][0], wlo[2][1], whi[0][0], whi[0][1]);
-  out[3] = make_uint4(whi[1][0], whi[1][1], whi[2][0], whi[2][1]);
-  float* nb = r.nbox + (size_t)(addr >> 2) * 6;
-  for (int k = 0; k < 6; ++k) nb[k] = nbx[k];
-  // surface-area cost of this node's children (ptc_stats.bvh_sa_cost): half_area(child) / half_area(scene) per used slot, a two-triangle leaf twice
-  if (scene_area > 0.0f) {
+    uint32_t pl[2] = {0u, 0u}, ph[2] = {0u, 0u};
 #pragma unroll
-    for (int sl = 0; sl < 8; ++sl) {
-      if (!((used >> sl) & 1u)) continue;
-      const float ex = chi[0][sl] - clo[0][sl], ey = chi[1][sl] - clo[1][sl], ez = chi[2][sl] - clo[2][sl];
-      const unsigned long long term = (unsigned long long)(((ex * ey + ey * ez + ez * ex) / scene_area) * PTC_SA_COST_ONE);
-      my_cost += ((two >> sl) & 1u) ? 2ull * term : term;
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t a = (uint32_t)__shfl((int)ql, oct0 + j), c = (uint32_t)__shfl((int)qh, oct0 + j);
+      pl[j >> 2] |= a << (8 * (j & 3));
+      ph[j >> 2] |= c << (8 * (j & 3));
     }
+    wlo[k][0] = pl[0]; wlo[k][1] = pl[1]; whi[k][0] = ph[0]; whi[k][1] = ph[1];
   }
+  if (live && sl == 0u) {
+    uint4* out = reinterpret_cast<uint4*>(r.recs) + addr;
+    out[0] = make_uint4(oq[0] | (oq[1] << 16), oq[2] | (e3[0] << 16) | (e3[1] << 24), e3[2] | (headz & 0xffffff00u), block);
+    out[1] = make_uint4(wlo[0][0], wlo[0][1], wlo[1][0], wlo[1][1]);
+    out[2] = make_uint4(wlo[2][0], wlo[2][1], whi[0][0], whi[0][1]);
+    out[3] = make_uint4(whi[1][0], whi[1][1], whi[2][0], whi[2][1]);
+    float* nb = r.nbox + (size_t)(addr >> 2) * 6;
+    for (int k = 0; k < 6; ++k) nb[k] = nbx[k];
+  }
+  // surface-area cost of this node's children (ptc_stats.bvh_sa_cost): half_area(child) / half_area(scene) per used slot, a two-triangle leaf twice
+  if (live && mine && scene_area > 0.0f) {
+    const float ex = b.hi[0] - b.lo[0], ey = b.hi[1] - b.lo[1], ez = b.hi[2] - b.lo[2];
+    const unsigned long long term = (unsigned long long)(((ex * ey + ey * ez + ez * ex) / scene_area) * PTC_SA_COST_ONE);
+    my_cost = ((two >> sl) & 1u) ? 2ull * term : term;
   }
   // one atomic per wave (a block is one wave): integer sum, the same bits in any order
   for (int d = 32; d >= 1; d >>= 1) my_cost += __shfl_xor(my_cost, d);
@@ -284,6 +296,6 @@ void pt_launch_refit_nodes(hipStream_t st, const DevRefit& r, const std::vector<
   for (size_t l = 0; l + 1 < level_first.size(); ++l) {
     const uint32_t first = level_first[l], count = level_first[l + 1] - first;
     if (!count) continue;
-    hipLaunchKernelGGL(k_refit_nodes, dim3((count + kNodeBlock - 1) / kNodeBlock), dim3(kNodeBlock), 0, st, r, first, count, gl[0], gl[1], gl[2], gs[0], gs[1], gs[2], scene_area);
+    hipLaunchKernelGGL(k_refit_nodes, dim3((count * 8u + kNodeBlock - 1) / kNodeBlock), dim3(kNodeBlock), 0, st, r, first, count, gl[0], gl[1], gl[2], gs[0], gs[1], gs[2], scene_area);      // eight lanes per node
   }
 }
