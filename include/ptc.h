@@ -217,7 +217,7 @@ int ptc_set_bvh_builder(ptc_ctx*, int builder);
  * build the emitter CDF, upload everything to HBM.  With PTC_BVH_SAH (the default) flatten and build run on the host's
  * thread pool (75 ms at 250 k triangles).  With PTC_BVH_LBVH on a device context the host only describes (indices,
  * materials, emitter table, textures) and the DEVICE flattens the vertices, writes the shading records and builds the
- * tree (csrc/pt_refit.hip, csrc/pt_build.hip): 4-8 ms at 250 k triangles, the arrays in HBM byte for byte those of the
+ * tree (csrc/pt_refit.hip, csrc/pt_build.hip): 3-5 ms at 250 k triangles, the arrays in HBM byte for byte those of the
  * host's LBVH commit (PTC_COMMIT=host in the environment keeps that path; ptc_debug_get_internals [7] bit 1 says which ran). */
 int ptc_scene_commit(ptc_ctx*);
 
